@@ -1,0 +1,161 @@
+/*
+ * spng_mi355.h -- C ABI of the MI355X-native PNG hot path (libspng_mi355.so).
+ *
+ * This is the drop-in boundary for swift-png's decode/encode hot path.  swift-png has no FFI of
+ * its own (it is pure Swift); the entry points below are what a Swift host would bind (module
+ * map / @_silgen_name) from inside the reference functions cited on each
+ * declaration.  Plain pointers and sizes only; every function returns an int32 status and never
+ * throws; the caller owns all memory; pointers are only used for the duration of the call
+ * (asynchronous calls: until spng_sync returns).
+ *
+ * Pointers named d_* are DEVICE pointers (HBM of the context's GPU); h_* / unprefixed are host
+ * pointers.  The compute path is HIP for gfx950 only; there is no CPU fallback: without a GPU
+ * spng_create fails with SPNG_E_DEVICE.
+ */
+#ifndef SPNG_MI355_H
+#define SPNG_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPNG_VERSION 0x000100
+
+/* ---- status codes --------------------------------------------------------------------------
+ * One code per case of the reference's error enums; payloads travel in spng_result.aux.      */
+enum {
+    SPNG_DONE = 0,                    /* LZ77.Inflator.push returned nil (LZ77.Inflator.swift:39-40) */
+    SPNG_NEED_MORE_INPUT = 1,         /* ... returned ()  (LZ77.Inflator.swift:46-47): truncated stream */
+    /* LZ77.StreamHeaderError, Sources/LZ77/Inflator/LZ77.StreamHeaderError.swift:6-28 */
+    SPNG_E_COMPRESSION_METHOD = 16,   /* invalidCompressionMethod(aux0) */
+    SPNG_E_WINDOW_SIZE = 17,          /* invalidWindowSize(exponent: aux0) */
+    SPNG_E_CHECK_BITS = 18,           /* invalidCheckBits */
+    SPNG_E_DICTIONARY = 19,           /* unexpectedDictionary */
+    /* LZ77.DecompressionError, Sources/LZ77/Inflator/LZ77.DecompressionError.swift:19-59 */
+    SPNG_E_STREAM_CHECKSUM = 32,      /* invalidStreamChecksum(declared: aux0, computed: aux1) */
+    SPNG_E_BLOCK_TYPE = 33,           /* invalidBlockTypeCode(aux0) */
+    SPNG_E_BLOCK_COUNT_PARITY = 34,   /* invalidBlockElementCountParity(aux0, aux1) */
+    SPNG_E_RUNLITERAL_COUNT = 35,     /* invalidHuffmanRunLiteralSymbolCount(aux0) */
+    SPNG_E_CODELENGTH_TABLE = 36,     /* invalidHuffmanCodelengthHuffmanTable */
+    SPNG_E_CODELENGTH_SEQUENCE = 37,  /* invalidHuffmanCodelengthSequence */
+    SPNG_E_HUFFMAN_TABLE = 38,        /* invalidHuffmanTable */
+    SPNG_E_STRING_REFERENCE = 39,     /* invalidStringReference */
+    /* PNG.DecodingError, Sources/PNG/Decoding/PNG.DecodingError.swift:5-44 */
+    SPNG_E_EXTRANEOUS_IMAGE_DATA = 48,         /* extraneousImageData */
+    SPNG_E_EXTRANEOUS_COMPRESSED_DATA = 49,    /* extraneousImageDataCompressedData (host side) */
+    SPNG_E_INCOMPLETE_DATASTREAM = 50,         /* incompleteImageDataCompressedDatastream (host side) */
+    /* boundary-level conditions with no reference counterpart */
+    SPNG_E_OUTPUT_CAPACITY = 64,      /* destination buffer too small */
+    SPNG_E_ARGUMENT = 65,             /* bad argument (null pointer, depth/channels combination, ...) */
+    SPNG_E_DEVICE = 66,               /* HIP error / no gfx950 device; see spng_last_error_string */
+    SPNG_E_REFERENCE_UNDEFINED = 67   /* malformed input on which the reference reads uninitialised
+                                         memory (unused distance code); no defined answer to match */
+};
+
+enum { SPNG_FORMAT_ZLIB = 0,          /* LZ77.Format.zlib  (PNG.Standard.common) */
+       SPNG_FORMAT_IOS = 1 };         /* LZ77.Format.ios   (raw DEFLATE, CgBI)   */
+
+typedef struct spng_ctx spng_ctx;     /* owns one device, one HIP stream, its workspaces; re-entrant per handle */
+
+/* Result of one unit of work (one stream / one image). */
+typedef struct spng_result {
+    int32_t  status;
+    int32_t  reserved;
+    uint64_t written;                 /* bytes produced (inflate: inflated bytes; deflate: stream bytes) */
+    uint64_t consumed;                /* compressed bytes consumed through the end of the stream */
+    uint64_t aux[2];                  /* error payload, see the status table */
+} spng_result;
+
+/* One zlib/raw-DEFLATE stream to inflate.  All pointers are device pointers. */
+typedef struct spng_stream_desc {
+    const void *d_src;  uint64_t src_len;     /* whole stream = concatenated IDAT payloads */
+    void       *d_dst;  uint64_t dst_cap;     /* inflated bytes */
+    int32_t     format; int32_t  reserved;
+} spng_stream_desc;
+
+/* One image.  d_rows is the inflated scanline stream (filter byte + pitch bytes per row, pass
+ * after pass; U bytes, spng_inflated_size); d_storage is PNG.Image.storage (S bytes,
+ * spng_storage_size).  d_rows is scratch for the decoder (it may be overwritten). */
+typedef struct spng_image_desc {
+    const void *d_idat;    uint64_t idat_len;   /* decode: input;  encode: unused            */
+    void       *d_rows;    uint64_t rows_cap;   /* >= U; decode: scratch, encode: output      */
+    void       *d_storage;                      /* S bytes                                     */
+    uint32_t    width, height;
+    uint8_t     depth;                          /* 1,2,4,8,16                                  */
+    uint8_t     channels;                       /* 1 (v / indexed), 2 (va), 3 (rgb), 4 (rgba)  */
+    uint8_t     interlaced;                     /* Adam7                                       */
+    uint8_t     format;                         /* SPNG_FORMAT_*                               */
+    uint32_t    reserved;
+} spng_image_desc;
+
+/* ---- utilities ----------------------------------------------------------------------------- */
+int32_t     spng_version(void);
+const char *spng_status_string(int32_t status);                 /* PNG.Error.message analogue      */
+const char *spng_last_error_string(void);                       /* last HIP error text, thread-local */
+/* U = sum over passes of (pitch+1)*rows   (PNG.Decoder.swift:59-84) */
+uint64_t    spng_inflated_size(uint32_t w, uint32_t h, int depth, int channels, int interlaced);
+/* S = w*h*ceil(volume/8)                  (PNG.Image.swift:73-74)   */
+uint64_t    spng_storage_size(uint32_t w, uint32_t h, int depth, int channels);
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* device: HIP ordinal.  stream: an existing hipStream_t to launch on (e.g. the caller's), or
+ * NULL to let the context create its own non-blocking stream. */
+int32_t spng_create(int device, void *stream, spng_ctx **out);
+void    spng_destroy(spng_ctx *ctx);
+void   *spng_stream(spng_ctx *ctx);                             /* the hipStream_t kernels launch on */
+int32_t spng_sync(spng_ctx *ctx);                               /* hipStreamSynchronize */
+
+/* Per-kernel timing with HIP events recorded on the context's stream around every launch. */
+enum { SPNG_K_INFLATE = 0, SPNG_K_UNFILTER = 1, SPNG_K_SCATTER = 2, SPNG_K_FILTER = 3,
+       SPNG_K_DEFLATE = 4, SPNG_K_ADLER = 5, SPNG_K_COUNT = 8 };
+int32_t spng_profile(spng_ctx *ctx, int enable);                /* enable/disable + reset counters  */
+int32_t spng_profile_get(spng_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
+
+/* ---- decode: device batch entry points (asynchronous on the context's stream) -------------- */
+/* replaces LZ77.Inflator.push/pull over whole streams: LZ77.Inflator.swift:30-61,
+ * LZ77.InflatorBuffers.swift:25-137, LZ77.InflatorBuffers.Stream.swift:59-429.
+ * d_results: device array of `count` spng_result, or NULL when h_results is given.
+ * h_results: host array filled after an implicit sync, or NULL for a fully asynchronous call. */
+int32_t spng_inflate_batch(spng_ctx *ctx, const spng_stream_desc *descs, uint32_t count,
+                           spng_result *d_results, spng_result *h_results);
+
+/* replaces the row walker PNG.Decoder.push (PNG.Decoder.swift:59-148), PNG.Decoder.defilter
+ * (:152-196) and PNG.Image.assign (PNG.Image.swift:186-285).  d_rows_len: device array of the
+ * number of valid bytes in each d_rows (NULL = U for every image). */
+int32_t spng_unfilter_batch(spng_ctx *ctx, const spng_image_desc *descs, uint32_t count,
+                            const uint64_t *d_rows_len,
+                            spng_result *d_results, spng_result *h_results);
+
+/* replaces PNG.Context.push(data:) end to end (PNG.Context.swift:88-102): concatenated IDAT ->
+ * storage.  The north-star entry point. */
+int32_t spng_decode_batch(spng_ctx *ctx, const spng_image_desc *descs, uint32_t count,
+                          spng_result *d_results, spng_result *h_results);
+
+/* ---- decode: host-pointer convenience (copies in/out, synchronous) ------------------------- */
+int32_t spng_inflate(spng_ctx *ctx, const void *src, uint64_t n, int32_t format,
+                     void *dst, uint64_t cap, spng_result *result);
+int32_t spng_unfilter(spng_ctx *ctx, const void *rows, uint64_t rows_len,
+                      uint32_t w, uint32_t h, int depth, int channels, int interlaced,
+                      void *storage, spng_result *result);
+int32_t spng_decode(spng_ctx *ctx, const void *idat, uint64_t n, int32_t format,
+                    uint32_t w, uint32_t h, int depth, int channels, int interlaced,
+                    void *storage, spng_result *result);
+/* Adler-32 of a host buffer computed on the device (LZ77.MRC32, Wrappers/LZ77.MRC32.swift:26-50) */
+int32_t spng_adler32(spng_ctx *ctx, const void *data, uint64_t n, uint32_t *out);
+
+/* ---- encode -------------------------------------------------------------------------------- */
+/* replaces PNG.Encoder.filter (PNG.Encoder.swift:132-204) + PNG.Image.collect
+ * (PNG.Image.swift:431-544): storage -> filtered rows with the reference's filter choice. */
+int32_t spng_filter_batch(spng_ctx *ctx, const spng_image_desc *descs, uint32_t count,
+                          spng_result *d_results, spng_result *h_results);
+int32_t spng_filter(spng_ctx *ctx, const void *storage,
+                    uint32_t w, uint32_t h, int depth, int channels, int interlaced,
+                    void *rows, spng_result *result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

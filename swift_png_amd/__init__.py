@@ -1,0 +1,329 @@
+"""swift_png_amd -- host-side mirror of swift-png's hot-path API over libspng_mi355.so.
+
+The product is the C-ABI library (include/spng_mi355.h, built from swift_png_amd/csrc/*.hip for
+gfx950).  swift-png itself is Swift; no Swift toolchain exists in this environment, so the host
+code above the C ABI is Python and mirrors the reference's seams for this path:
+
+    LZ77.Inflator              Sources/LZ77/Inflator/LZ77.Inflator.swift:8-62
+    PNG.Decoder.defilter       Sources/PNG/Decoding/PNG.Decoder.swift:152-196
+    PNG.Encoder.filter         Sources/PNG/Encoding/PNG.Encoder.swift:132-204
+    PNG.Context.push(data:)    Sources/PNG/Decoding/PNG.Context.swift:88-147
+
+PyTorch is used only for device memory and streams.  There is no CPU fallback: `load()` raises
+when the HIP library or the GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libspng_mi355.so"
+
+# ---- status vocabulary (include/spng_mi355.h) -------------------------------------------------
+DONE, NEED_MORE_INPUT = 0, 1
+E_COMPRESSION_METHOD, E_WINDOW_SIZE, E_CHECK_BITS, E_DICTIONARY = 16, 17, 18, 19
+(E_STREAM_CHECKSUM, E_BLOCK_TYPE, E_BLOCK_COUNT_PARITY, E_RUNLITERAL_COUNT, E_CODELENGTH_TABLE,
+ E_CODELENGTH_SEQUENCE, E_HUFFMAN_TABLE, E_STRING_REFERENCE) = range(32, 40)
+E_EXTRANEOUS_IMAGE_DATA, E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM = 48, 49, 50
+E_OUTPUT_CAPACITY, E_ARGUMENT, E_DEVICE, E_REFERENCE_UNDEFINED = 64, 65, 66, 67
+FORMAT_ZLIB, FORMAT_IOS = 0, 1
+K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER = 0, 1, 2, 3, 4, 5
+
+EXPORTS = [
+    "spng_version", "spng_status_string", "spng_last_error_string", "spng_inflated_size",
+    "spng_storage_size", "spng_create", "spng_destroy", "spng_stream", "spng_sync", "spng_profile",
+    "spng_profile_get", "spng_inflate_batch", "spng_unfilter_batch", "spng_decode_batch",
+    "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
+]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("reserved", ctypes.c_int32), ("written", ctypes.c_uint64),
+                ("consumed", ctypes.c_uint64), ("aux", ctypes.c_uint64 * 2)]
+
+
+class StreamDesc(ctypes.Structure):
+    _fields_ = [("d_src", ctypes.c_void_p), ("src_len", ctypes.c_uint64), ("d_dst", ctypes.c_void_p),
+                ("dst_cap", ctypes.c_uint64), ("format", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class ImageDesc(ctypes.Structure):
+    _fields_ = [("d_idat", ctypes.c_void_p), ("idat_len", ctypes.c_uint64), ("d_rows", ctypes.c_void_p),
+                ("rows_cap", ctypes.c_uint64), ("d_storage", ctypes.c_void_p), ("width", ctypes.c_uint32),
+                ("height", ctypes.c_uint32), ("depth", ctypes.c_uint8), ("channels", ctypes.c_uint8),
+                ("interlaced", ctypes.c_uint8), ("format", ctypes.c_uint8), ("reserved", ctypes.c_uint32)]
+
+
+# ---- error mirror --------------------------------------------------------------------------------
+class SpngError(Exception):
+    """Base of the mirrored reference errors; `.status` is the C-ABI code, `.aux` its payload."""
+
+    def __init__(self, status, aux=(0, 0)):
+        self.status, self.aux = status, tuple(aux)
+        super().__init__(f"{_NAMES.get(status, status)}{self.aux if any(self.aux) else ''}")
+
+
+class StreamHeaderError(SpngError):      # LZ77.StreamHeaderError
+    pass
+
+
+class DecompressionError(SpngError):     # LZ77.DecompressionError
+    pass
+
+
+class DecodingError(SpngError):          # PNG.DecodingError
+    pass
+
+
+_NAMES = {
+    16: "invalidCompressionMethod", 17: "invalidWindowSize", 18: "invalidCheckBits", 19: "unexpectedDictionary",
+    32: "invalidStreamChecksum", 33: "invalidBlockTypeCode", 34: "invalidBlockElementCountParity",
+    35: "invalidHuffmanRunLiteralSymbolCount", 36: "invalidHuffmanCodelengthHuffmanTable",
+    37: "invalidHuffmanCodelengthSequence", 38: "invalidHuffmanTable", 39: "invalidStringReference",
+    48: "extraneousImageData", 49: "extraneousImageDataCompressedData",
+    50: "incompleteImageDataCompressedDatastream", 64: "outputCapacity", 65: "invalidArgument",
+    66: "deviceError", 67: "referenceUndefined",
+}
+
+
+def raise_for(status, aux=(0, 0)):
+    if status in (DONE, NEED_MORE_INPUT):
+        return
+    if 16 <= status < 32:
+        raise StreamHeaderError(status, aux)
+    if 32 <= status < 48:
+        raise DecompressionError(status, aux)
+    if 48 <= status < 64:
+        raise DecodingError(status, aux)
+    raise SpngError(status, aux)
+
+
+# ---- library loading -----------------------------------------------------------------------------
+_lib = None
+
+
+def load_library():
+    """dlopens libspng_mi355.so and declares prototypes.  Needs no GPU (used by the symbol tests)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32
+    rp = ctypes.POINTER(Result)
+    lib.spng_version.restype = i32
+    lib.spng_status_string.restype = ctypes.c_char_p
+    lib.spng_status_string.argtypes = [i32]
+    lib.spng_last_error_string.restype = ctypes.c_char_p
+    lib.spng_inflated_size.restype = u64
+    lib.spng_inflated_size.argtypes = [u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.spng_storage_size.restype = u64
+    lib.spng_storage_size.argtypes = [u32, u32, ctypes.c_int, ctypes.c_int]
+    lib.spng_create.argtypes = [ctypes.c_int, vp, ctypes.POINTER(vp)]
+    lib.spng_destroy.restype = None
+    lib.spng_destroy.argtypes = [vp]
+    lib.spng_stream.restype = vp
+    lib.spng_stream.argtypes = [vp]
+    lib.spng_sync.argtypes = [vp]
+    lib.spng_profile.argtypes = [vp, ctypes.c_int]
+    lib.spng_profile_get.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
+    lib.spng_inflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), u32, vp, rp]
+    lib.spng_unfilter_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, vp, rp]
+    lib.spng_decode_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, rp]
+    lib.spng_filter_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, rp]
+    lib.spng_inflate.argtypes = [vp, vp, u64, i32, vp, u64, rp]
+    lib.spng_unfilter.argtypes = [vp, vp, u64, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, rp]
+    lib.spng_decode.argtypes = [vp, vp, u64, i32, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, rp]
+    lib.spng_adler32.argtypes = [vp, vp, u64, ctypes.POINTER(u32)]
+    lib.spng_filter.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, rp]
+    for name in EXPORTS:
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+_sessions = {}
+
+
+def load(device: int = 0) -> "Session":
+    """Returns the process-wide Session for `device`; raises if the HIP path cannot run."""
+    if device not in _sessions:
+        _sessions[device] = Session(device)
+    return _sessions[device]
+
+
+def inflated_size(w, h, depth, channels, interlaced) -> int:
+    return load_library().spng_inflated_size(w, h, depth, channels, int(bool(interlaced)))
+
+
+def storage_size(w, h, depth, channels) -> int:
+    return load_library().spng_storage_size(w, h, depth, channels)
+
+
+def _check(lib, st):
+    if st != DONE:
+        msg = lib.spng_last_error_string().decode() if st == E_DEVICE else lib.spng_status_string(st).decode()
+        raise SpngError(st) if st != E_DEVICE else RuntimeError(f"libspng_mi355: {msg}")
+
+
+class Session:
+    """One spng_ctx: a device, a HIP stream and its workspaces (re-entrant per handle)."""
+
+    def __init__(self, device: int = 0, use_torch_stream: bool = True):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("swift_png_amd needs an MI355X (gfx950); no HIP device is visible and there is "
+                               "no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.device = device
+        self.tdev = torch.device("cuda", device)
+        handle = ctypes.c_void_p()
+        stream = None
+        if use_torch_stream:
+            with torch.cuda.device(device):
+                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _check(self.lib, self.lib.spng_create(device, stream, ctypes.byref(handle)))
+        self.ctx = handle
+
+    def close(self):
+        if self.ctx:
+            self.lib.spng_destroy(self.ctx)
+            self.ctx = None
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def sync(self):
+        _check(self.lib, self.lib.spng_sync(self.ctx))
+
+    def profile(self, enable=True):
+        _check(self.lib, self.lib.spng_profile(self.ctx, int(enable)))
+
+    def profile_get(self, kernel):
+        ms, n = ctypes.c_double(0), ctypes.c_uint64(0)
+        _check(self.lib, self.lib.spng_profile_get(self.ctx, kernel, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def to_device(self, data):
+        t = self.torch
+        if isinstance(data, (bytes, bytearray, memoryview)):
+            if len(data) == 0:
+                return t.empty(0, dtype=t.uint8, device=self.tdev)
+            return t.frombuffer(bytearray(data), dtype=t.uint8).to(self.tdev)
+        return t.as_tensor(data, dtype=t.uint8).to(self.tdev)
+
+    def empty(self, n):
+        return self.torch.empty(max(int(n), 1), dtype=self.torch.uint8, device=self.tdev)
+
+    @staticmethod
+    def _ptr(tensor):
+        return ctypes.c_void_p(tensor.data_ptr() if tensor is not None and tensor.numel() else None)
+
+    # -- batch entry points (device tensors in, device tensors out) ------------------------------
+    def inflate_batch(self, streams, caps, fmt=FORMAT_ZLIB):
+        """streams: list of uint8 device tensors; caps: output capacities.
+        -> (list of output tensors, list[Result])"""
+        n = len(streams)
+        outs = [self.empty(c) for c in caps]
+        descs = (StreamDesc * n)()
+        for i, (s, o, c) in enumerate(zip(streams, outs, caps)):
+            f = fmt[i] if isinstance(fmt, (list, tuple)) else fmt
+            descs[i] = StreamDesc(self._ptr(s), s.numel(), self._ptr(o), int(c), f, 0)
+        res = (Result * n)()
+        _check(self.lib, self.lib.spng_inflate_batch(self.ctx, descs, n, None, res))
+        return outs, list(res)
+
+    def image_desc(self, idat, rows, storage, w, h, depth, channels, interlaced, fmt=FORMAT_ZLIB, rows_cap=None):
+        return ImageDesc(self._ptr(idat), idat.numel() if idat is not None else 0, self._ptr(rows),
+                         int(rows_cap if rows_cap is not None else rows.numel()), self._ptr(storage),
+                         w, h, depth, channels, int(bool(interlaced)), fmt, 0)
+
+    def decode_batch(self, descs, wait=True):
+        """PNG.Context.push for a batch.  wait=True: -> list[Result]; wait=False: results stay on the
+        device (fetch_results) and the call returns as soon as the kernels are enqueued."""
+        n = len(descs)
+        arr = descs if isinstance(descs, ctypes.Array) else (ImageDesc * n)(*descs)
+        if wait:
+            res = (Result * n)()
+            _check(self.lib, self.lib.spng_decode_batch(self.ctx, arr, n, None, res))
+            return list(res)
+        if getattr(self, "_dres", None) is None or self._dres.numel() < n * ctypes.sizeof(Result):
+            self._dres = self.empty(n * ctypes.sizeof(Result))
+        _check(self.lib, self.lib.spng_decode_batch(self.ctx, arr, n, self._ptr(self._dres), None))
+        return None
+
+    def fetch_results(self, n):
+        raw = bytes(self._dres[:n * ctypes.sizeof(Result)].cpu().numpy())
+        return list((Result * n).from_buffer_copy(raw))
+
+    def unfilter_batch(self, descs, rows_len=None):
+        n = len(descs)
+        arr = (ImageDesc * n)(*descs)
+        res = (Result * n)()
+        dl = None
+        if rows_len is not None:
+            dl = self.torch.tensor(list(rows_len), dtype=self.torch.int64, device=self.tdev)
+        _check(self.lib, self.lib.spng_unfilter_batch(self.ctx, arr, n, self._ptr(dl) if dl is not None else None,
+                                                      None, res))
+        return list(res)
+
+    def filter_batch(self, descs):
+        n = len(descs)
+        arr = (ImageDesc * n)(*descs)
+        res = (Result * n)()
+        _check(self.lib, self.lib.spng_filter_batch(self.ctx, arr, n, None, res))
+        return list(res)
+
+    # -- host-buffer conveniences ------------------------------------------------------------------
+    def inflate(self, data: bytes, fmt=FORMAT_ZLIB, cap=None):
+        """Whole-stream LZ77.Inflator: -> (status, bytes, consumed, aux)"""
+        cap = int(cap if cap is not None else max(1 << 16, 1100 * len(data)))
+        src = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+        dst = (ctypes.c_uint8 * max(cap, 1))()
+        res = Result()
+        _check(self.lib, self.lib.spng_inflate(self.ctx, src, len(data), fmt, dst, cap, ctypes.byref(res)))
+        return res.status, bytes(dst[:res.written]), res.consumed, (res.aux[0], res.aux[1])
+
+    def decode(self, idat: bytes, w, h, depth, channels, interlaced, fmt=FORMAT_ZLIB, storage=None):
+        """PNG.Context.push over the concatenated IDAT payload: -> (status, storage bytes, aux)"""
+        s = storage_size(w, h, depth, channels)
+        buf = (ctypes.c_uint8 * max(s, 1))()
+        if storage is not None:
+            ctypes.memmove(buf, bytes(storage), s)
+        src = (ctypes.c_uint8 * max(len(idat), 1)).from_buffer_copy(bytes(idat) or b"\0")
+        res = Result()
+        _check(self.lib, self.lib.spng_decode(self.ctx, src, len(idat), fmt, w, h, depth, channels,
+                                              int(bool(interlaced)), buf, ctypes.byref(res)))
+        return res.status, bytes(buf[:s]), (res.aux[0], res.aux[1])
+
+    def unfilter(self, rows: bytes, w, h, depth, channels, interlaced, storage=None):
+        s = storage_size(w, h, depth, channels)
+        buf = (ctypes.c_uint8 * max(s, 1))()
+        if storage is not None:
+            ctypes.memmove(buf, bytes(storage), s)
+        src = (ctypes.c_uint8 * max(len(rows), 1)).from_buffer_copy(bytes(rows) or b"\0")
+        res = Result()
+        _check(self.lib, self.lib.spng_unfilter(self.ctx, src, len(rows), w, h, depth, channels,
+                                                int(bool(interlaced)), buf, ctypes.byref(res)))
+        return res.status, bytes(buf[:s])
+
+    def filter(self, storage: bytes, w, h, depth, channels, interlaced) -> bytes:
+        u = inflated_size(w, h, depth, channels, interlaced)
+        src = (ctypes.c_uint8 * max(len(storage), 1)).from_buffer_copy(bytes(storage) or b"\0")
+        dst = (ctypes.c_uint8 * max(u, 1))()
+        res = Result()
+        _check(self.lib, self.lib.spng_filter(self.ctx, src, w, h, depth, channels, int(bool(interlaced)), dst,
+                                              ctypes.byref(res)))
+        return bytes(dst[:u])
+
+    def adler32(self, data: bytes) -> int:
+        src = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+        out = ctypes.c_uint32(0)
+        _check(self.lib, self.lib.spng_adler32(self.ctx, src, len(data), ctypes.byref(out)))
+        return out.value
+
+
+from .mirror import LZ77, PNG  # noqa: E402,F401

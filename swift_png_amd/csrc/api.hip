@@ -1,0 +1,652 @@
+// api.hip -- host side of libspng_mi355.so: the C ABI declared in include/spng_mi355.h.
+//
+// Everything here is plumbing: argument checks, job tables (the Adam7 / row geometry of
+// PNG.Decoder.push, Sources/PNG/Decoding/PNG.Decoder.swift:59-140, and of PNG.Encoder.pull,
+// Sources/PNG/Encoding/PNG.Encoder.swift:33-129), one pinned->device upload per call, kernel
+// launches on the context's stream and optional HIP-event timing around each launch.  There is
+// no CPU implementation of any hot-path function in this library.
+#include "common.hpp"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+namespace spng {
+
+static thread_local char g_err[512] = "";
+
+static int32_t fail_hip(hipError_t e, const char *what)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return SPNG_E_DEVICE;
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail_hip(e_, #expr); } while (0)
+
+// PNG.adam7 (PNG.Decoder.swift:6-15) and the sub-image geometry of :63-82
+int passes(uint32_t w, uint32_t h, int volume, int interlaced, Pass out[7])
+{
+    static const uint32_t A7[7][4] = {{0, 0, 3, 3}, {4, 0, 3, 3}, {0, 4, 2, 3}, {2, 0, 2, 2},
+                                      {0, 2, 1, 2}, {1, 0, 1, 1}, {0, 1, 0, 1}};
+    int n = 0;
+    if (!interlaced) {
+        if (w && h) out[n++] = Pass{0, 0, 1, 1, w, h, ((uint64_t)w * volume + 7) >> 3};
+        return n;
+    }
+    for (int z = 0; z < 7; ++z) {
+        const uint32_t bx = A7[z][0], by = A7[z][1], ex = A7[z][2], ey = A7[z][3];
+        const uint32_t sx = 1u << ex, sy = 1u << ey;
+        if (w + sx - bx - 1 < sx || h + sy - by - 1 < sy) continue;   // empty pass (:76-80)
+        const uint32_t sw = (w + sx - bx - 1) >> ex, sh = (h + sy - by - 1) >> ey;
+        if (!sw || !sh) continue;
+        out[n++] = Pass{bx, by, sx, sy, sw, sh, ((uint64_t)sw * volume + 7) >> 3};
+    }
+    return n;
+}
+
+static bool valid_format(int depth, int channels)
+{
+    if (channels < 1 || channels > 4) return false;
+    if (depth == 8 || depth == 16) return true;
+    return channels == 1 && (depth == 1 || depth == 2 || depth == 4);
+}
+
+}  // namespace spng
+
+using namespace spng;
+
+struct spng_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    // device + pinned workspaces for job tables
+    void *d_ws = nullptr;  size_t d_ws_cap = 0;
+    void *h_ws = nullptr;  size_t h_ws_cap = 0;
+    // profiling
+    bool profiling = false;
+    struct Span { int kernel; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    std::mutex mu;
+
+    int32_t reserve(size_t bytes)
+    {
+        if (bytes <= d_ws_cap) return SPNG_DONE;
+        // the previous tables may still be read by in-flight kernels
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (d_ws) { HIP_TRY(hipFree(d_ws)); d_ws = nullptr; }
+        if (h_ws) { HIP_TRY(hipHostFree(h_ws)); h_ws = nullptr; }
+        size_t cap = bytes + bytes / 2 + 4096;
+        HIP_TRY(hipMalloc(&d_ws, cap));
+        HIP_TRY(hipHostMalloc(&h_ws, cap, hipHostMallocDefault));
+        d_ws_cap = h_ws_cap = cap;
+        return SPNG_DONE;
+    }
+    hipEvent_t event()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        hipEventCreate(&e);
+        return e;
+    }
+};
+
+struct Timed {            // records a pair of events around a launch when profiling is on
+    spng_ctx *c; int k; hipEvent_t a = nullptr;
+    Timed(spng_ctx *c_, int k_) : c(c_), k(k_) { if (c->profiling) { a = c->event(); hipEventRecord(a, c->stream); } }
+    ~Timed() { if (a) { hipEvent_t b = c->event(); hipEventRecord(b, c->stream); c->spans.push_back({k, a, b}); } }
+};
+
+// simple bump allocator over the paired pinned/device workspaces
+struct Arena {
+    spng_ctx *c; size_t off = 0;
+    template <class T> T *host(size_t at) { return (T *)((char *)c->h_ws + at); }
+    template <class T> T *dev(size_t at) { return (T *)((char *)c->d_ws + at); }
+    size_t take(size_t bytes) { size_t at = off; off = (off + bytes + 255) & ~(size_t)255; return at; }
+};
+
+extern "C" {
+
+int32_t spng_version(void) { return SPNG_VERSION; }
+
+const char *spng_status_string(int32_t s)
+{
+    switch (s) {
+    case SPNG_DONE: return "done";
+    case SPNG_NEED_MORE_INPUT: return "need more input";
+    case SPNG_E_COMPRESSION_METHOD: return "invalid rfc-1950 compression method code";
+    case SPNG_E_WINDOW_SIZE: return "invalid rfc-1950 window size";
+    case SPNG_E_CHECK_BITS: return "invalid rfc-1950 header check bits";
+    case SPNG_E_DICTIONARY: return "unexpected rfc-1950 stream dictionary";
+    case SPNG_E_STREAM_CHECKSUM: return "invalid rfc-1950 checksum";
+    case SPNG_E_BLOCK_TYPE: return "invalid rfc-1951 block type code";
+    case SPNG_E_BLOCK_COUNT_PARITY: return "invalid rfc-1951 block element count parity";
+    case SPNG_E_RUNLITERAL_COUNT: return "invalid rfc-1951 run-literal symbol count";
+    case SPNG_E_CODELENGTH_TABLE: return "malformed rfc-1951 codelength huffman table";
+    case SPNG_E_CODELENGTH_SEQUENCE: return "invalid rfc-1951 codelength sequence";
+    case SPNG_E_HUFFMAN_TABLE: return "malformed rfc-1951 huffman table";
+    case SPNG_E_STRING_REFERENCE: return "invalid rfc-1951 string reference";
+    case SPNG_E_EXTRANEOUS_IMAGE_DATA: return "image data buffer not empty after decoding final scanline";
+    case SPNG_E_EXTRANEOUS_COMPRESSED_DATA: return "extraneous compressed image data after end of compressed stream";
+    case SPNG_E_INCOMPLETE_DATASTREAM: return "reached end-of-image chunk while compressed image data stream is incomplete";
+    case SPNG_E_OUTPUT_CAPACITY: return "destination buffer too small";
+    case SPNG_E_ARGUMENT: return "invalid argument";
+    case SPNG_E_DEVICE: return "device error";
+    case SPNG_E_REFERENCE_UNDEFINED: return "stream uses a distance code the reference leaves undefined";
+    default: return "unknown status";
+    }
+}
+
+const char *spng_last_error_string(void) { return g_err; }
+
+uint64_t spng_inflated_size(uint32_t w, uint32_t h, int depth, int channels, int interlaced)
+{
+    Pass p[7];
+    const int n = passes(w, h, depth * channels, interlaced, p);
+    uint64_t u = 0;
+    for (int i = 0; i < n; ++i) u += (p[i].pitch + 1) * (uint64_t)p[i].h;
+    return u;
+}
+
+uint64_t spng_storage_size(uint32_t w, uint32_t h, int depth, int channels)
+{
+    return (uint64_t)w * h * (uint64_t)((depth * channels + 7) >> 3);
+}
+
+int32_t spng_create(int device, void *stream, spng_ctx **out)
+{
+    if (!out) return SPNG_E_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || device < 0 || device >= count)
+        return fail_hip(e == hipSuccess ? hipErrorInvalidDevice : e, "spng_create: no such HIP device");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_err, sizeof g_err, "spng_create: device %d is %s; this library contains gfx950 code only",
+                 device, prop.gcnArchName);
+        return SPNG_E_DEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    spng_ctx *c = new spng_ctx;
+    c->device = device;
+    if (stream) c->stream = (hipStream_t)stream;
+    else {
+        hipError_t e2 = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e2 != hipSuccess) { delete c; return fail_hip(e2, "hipStreamCreateWithFlags"); }
+        c->owns_stream = true;
+    }
+    *out = c;
+    return SPNG_DONE;
+}
+
+void spng_destroy(spng_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto &s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    for (auto e : c->pool) hipEventDestroy(e);
+    if (c->d_ws) hipFree(c->d_ws);
+    if (c->h_ws) hipHostFree(c->h_ws);
+    if (c->owns_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void *spng_stream(spng_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int32_t spng_sync(spng_ctx *c)
+{
+    if (!c) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPNG_DONE;
+}
+
+int32_t spng_profile(spng_ctx *c, int enable)
+{
+    if (!c) return SPNG_E_ARGUMENT;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto &s : c->spans) { c->pool.push_back(s.a); c->pool.push_back(s.b); }
+    c->spans.clear();
+    c->profiling = enable != 0;
+    return SPNG_DONE;
+}
+
+int32_t spng_profile_get(spng_ctx *c, int kernel, double *total_ms, uint64_t *launches)
+{
+    if (!c || kernel < 0 || kernel >= SPNG_K_COUNT) return SPNG_E_ARGUMENT;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double t = 0; uint64_t n = 0;
+    for (auto &s : c->spans) if (s.kernel == kernel) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s.a, s.b));
+        t += ms; ++n;
+    }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = n;
+    return SPNG_DONE;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+namespace spng {
+
+__global__ void finish_decode_kernel(spng_result *results, const uint64_t *expected, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int32_t st = results[i].status;
+    // PNG.Decoder.swift:142-147: anything left in the inflator after the last row
+    if (st == SPNG_E_OUTPUT_CAPACITY ||
+        ((st == SPNG_DONE || st == SPNG_NEED_MORE_INPUT) && results[i].written > expected[i]))
+        results[i].status = SPNG_E_EXTRANEOUS_IMAGE_DATA;
+}
+
+__global__ void init_results_kernel(spng_result *results, const uint64_t *written, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    results[i].status = SPNG_DONE; results[i].reserved = 0;
+    results[i].written = written[i]; results[i].consumed = 0;
+    results[i].aux[0] = results[i].aux[1] = 0;
+}
+
+// Plans and launches the unfilter (+ scatter) stage for a batch.  rows_len_of(i) gives the device
+// address holding the number of valid inflated bytes of image i (or null).
+struct UnfilterPlan {
+    std::vector<UnfJob> unf[9];          // indexed by bpp
+    std::vector<ScatterJob> scat;
+    std::vector<uint32_t> scat_image;
+};
+
+static int32_t plan_unfilter(const spng_image_desc *descs, uint32_t count, UnfilterPlan &plan,
+                             const uint64_t *(*rows_len_of)(void *, uint32_t), void *user)
+{
+    for (uint32_t i = 0; i < count; ++i) {
+        const spng_image_desc &d = descs[i];
+        if (!valid_format(d.depth, d.channels) || !d.d_rows || !d.d_storage) return SPNG_E_ARGUMENT;
+        const int volume = d.depth * d.channels;
+        const uint32_t bpp = (uint32_t)(volume + 7) >> 3;
+        const uint64_t u = spng_inflated_size(d.width, d.height, d.depth, d.channels, d.interlaced);
+        if (d.rows_cap < u) return SPNG_E_ARGUMENT;
+        Pass p[7];
+        const int np = passes(d.width, d.height, volume, d.interlaced, p);
+        const bool direct = !d.interlaced && volume >= 8;   // rows land in storage as they are
+        uint64_t off = 0;
+        for (int z = 0; z < np; ++z) {
+            UnfJob j;
+            j.in = (const uint8_t *)d.d_rows + off;
+            j.in_stride = p[z].pitch + 1;
+            if (direct) { j.out = (uint8_t *)d.d_storage; j.out_stride = p[z].pitch; }
+            else        { j.out = (uint8_t *)d.d_rows + off + 1; j.out_stride = p[z].pitch + 1; }
+            j.stream_off = off;
+            j.rows_len = rows_len_of(user, i);
+            j.pitch = (uint32_t)p[z].pitch; j.rows = p[z].h; j.image = i; j.bpp = bpp;
+            plan.unf[bpp].push_back(j);
+            if (!direct) {
+                ScatterJob s;
+                s.rows = (const uint8_t *)d.d_rows + off + 1;
+                s.storage = (uint8_t *)d.d_storage;
+                s.row_stride = p[z].pitch + 1; s.stream_off = off; s.rows_len = j.rows_len;
+                s.sub_w = p[z].w; s.sub_h = p[z].h; s.width = d.width;
+                s.bx = p[z].bx; s.by = p[z].by; s.sx = p[z].sx; s.sy = p[z].sy;
+                s.depth = d.depth; s.channels = d.channels;
+                plan.scat.push_back(s);
+                plan.scat_image.push_back(i);
+            }
+            off += (p[z].pitch + 1) * (uint64_t)p[z].h;
+        }
+    }
+    return SPNG_DONE;
+}
+
+static size_t plan_bytes(const UnfilterPlan &plan)
+{
+    size_t b = 0;
+    for (int k = 1; k <= 8; ++k) b += plan.unf[k].size() * sizeof(UnfJob) + 256;
+    b += plan.scat.size() * (sizeof(ScatterJob) + 4) + 512;
+    return b;
+}
+
+// copies the plan into the arena (host side) and launches after the caller's upload
+struct PlanSlots { size_t unf[9]; size_t scat, scat_image; };
+
+static void stage_plan(const UnfilterPlan &plan, Arena &a, PlanSlots &slots)
+{
+    for (int k = 1; k <= 8; ++k) {
+        slots.unf[k] = a.take(plan.unf[k].size() * sizeof(UnfJob));
+        if (!plan.unf[k].empty())
+            memcpy(a.host<UnfJob>(slots.unf[k]), plan.unf[k].data(), plan.unf[k].size() * sizeof(UnfJob));
+    }
+    slots.scat = a.take(plan.scat.size() * sizeof(ScatterJob));
+    slots.scat_image = a.take(plan.scat.size() * 4);
+    if (!plan.scat.empty()) {
+        memcpy(a.host<ScatterJob>(slots.scat), plan.scat.data(), plan.scat.size() * sizeof(ScatterJob));
+        memcpy(a.host<uint32_t>(slots.scat_image), plan.scat_image.data(), plan.scat.size() * 4);
+    }
+}
+
+static int32_t launch_plan(spng_ctx *c, const UnfilterPlan &plan, Arena &a, const PlanSlots &slots,
+                           spng_result *d_results)
+{
+    {
+        Timed t(c, SPNG_K_UNFILTER);
+        for (int k = 1; k <= 8; ++k)
+            if (!plan.unf[k].empty())
+                HIP_TRY(launch_unfilter(a.dev<UnfJob>(slots.unf[k]), (uint32_t)plan.unf[k].size(), k,
+                                        d_results, c->stream));
+    }
+    if (!plan.scat.empty()) {
+        Timed t(c, SPNG_K_SCATTER);
+        uint64_t maxpix = 1;
+        for (auto &s : plan.scat) { uint64_t px = (uint64_t)s.sub_w * s.sub_h; if (px > maxpix) maxpix = px; }
+        uint32_t bx = (uint32_t)((maxpix + 255) / 256);
+        if (bx > 1024) bx = 1024;
+        HIP_TRY(launch_scatter(a.dev<ScatterJob>(slots.scat), (uint32_t)plan.scat.size(),
+                               a.dev<uint32_t>(slots.scat_image), d_results, bx, c->stream));
+    }
+    return SPNG_DONE;
+}
+
+static const uint64_t *rows_len_in_results(void *user, uint32_t i)
+{
+    return &((spng_result *)user)[i].written;
+}
+static const uint64_t *rows_len_in_array(void *user, uint32_t i)
+{
+    return user ? (const uint64_t *)user + i : nullptr;
+}
+
+}  // namespace spng
+
+extern "C" {
+
+int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t count,
+                           spng_result *d_results, spng_result *h_results)
+{
+    if (!c || (!descs && count) || (!d_results && !h_results && count)) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    const size_t need = count * (sizeof(InflateJob) + sizeof(spng_result)) + 1024;
+    if (int32_t st = c->reserve(need)) return st;
+    Arena a{c};
+    const size_t jobs = a.take(count * sizeof(InflateJob));
+    const size_t upload = a.off;
+    const size_t res = a.take(count * sizeof(spng_result));
+    for (uint32_t i = 0; i < count; ++i) {
+        if ((!descs[i].d_src && descs[i].src_len) || (!descs[i].d_dst && descs[i].dst_cap)) return SPNG_E_ARGUMENT;
+        a.host<InflateJob>(jobs)[i] = InflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst,
+                                                 descs[i].src_len, descs[i].dst_cap, descs[i].format, i};
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_ws, c->h_ws, upload, hipMemcpyHostToDevice, c->stream));
+    spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
+    {
+        Timed t(c, SPNG_K_INFLATE);
+        HIP_TRY(launch_inflate(a.dev<InflateJob>(jobs), count, dr, c->stream));
+    }
+    if (h_results) {
+        HIP_TRY(hipMemcpyAsync(h_results, dr, count * sizeof(spng_result), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SPNG_DONE;
+}
+
+int32_t spng_unfilter_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t count,
+                            const uint64_t *d_rows_len,
+                            spng_result *d_results, spng_result *h_results)
+{
+    if (!c || (!descs && count)) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    UnfilterPlan plan;
+    if (int32_t st = plan_unfilter(descs, count, plan, rows_len_in_array, (void *)d_rows_len)) return st;
+    const size_t need = plan_bytes(plan) + count * (sizeof(spng_result) + 16) + 1024;
+    if (int32_t st = c->reserve(need)) return st;
+    Arena a{c};
+    PlanSlots slots;
+    stage_plan(plan, a, slots);
+    const size_t expected = a.take(count * 8);
+    for (uint32_t i = 0; i < count; ++i)
+        a.host<uint64_t>(expected)[i] = spng_inflated_size(descs[i].width, descs[i].height, descs[i].depth,
+                                                           descs[i].channels, descs[i].interlaced);
+    const size_t upload = a.off;
+    const size_t res = a.take(count * sizeof(spng_result));
+    HIP_TRY(hipMemcpyAsync(c->d_ws, c->h_ws, upload, hipMemcpyHostToDevice, c->stream));
+    spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
+    // results: status DONE, written = rows_len (or U); then extraneous check
+    init_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(
+        dr, d_rows_len ? d_rows_len : a.dev<uint64_t>(expected), count);
+    HIP_TRY(hipGetLastError());
+    if (int32_t st = launch_plan(c, plan, a, slots, nullptr)) return st;
+    finish_decode_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, a.dev<uint64_t>(expected), count);
+    HIP_TRY(hipGetLastError());
+    if (h_results) {
+        HIP_TRY(hipMemcpyAsync(h_results, dr, count * sizeof(spng_result), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SPNG_DONE;
+}
+
+int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t count,
+                          spng_result *d_results, spng_result *h_results)
+{
+    if (!c || (!descs && count)) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    // results live on the device from the start: the unfilter jobs read `written` from them
+    const size_t res_bytes = count * sizeof(spng_result);
+    UnfilterPlan plan;
+    // two-phase: we need the device address of the results before planning
+    const size_t fixed = count * (sizeof(InflateJob) + 8) + res_bytes + 2048;
+    // conservative upper bound on plan size: 7 passes per image
+    if (int32_t st = c->reserve(fixed + (size_t)count * 7 * (sizeof(UnfJob) + sizeof(ScatterJob) + 4) + 8192)) return st;
+    Arena a{c};
+    const size_t res = a.take(res_bytes);                      // first, so its device address is stable
+    spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
+    if (int32_t st = plan_unfilter(descs, count, plan, rows_len_in_results, (void *)dr)) return st;
+    const size_t jobs = a.take(count * sizeof(InflateJob));
+    const size_t expected = a.take(count * 8);
+    for (uint32_t i = 0; i < count; ++i) {
+        const spng_image_desc &d = descs[i];
+        if (!d.d_idat && d.idat_len) return SPNG_E_ARGUMENT;
+        a.host<InflateJob>(jobs)[i] = InflateJob{(const uint8_t *)d.d_idat, (uint8_t *)d.d_rows, d.idat_len,
+                                                 d.rows_cap, d.format, i};
+        a.host<uint64_t>(expected)[i] = spng_inflated_size(d.width, d.height, d.depth, d.channels, d.interlaced);
+    }
+    PlanSlots slots;
+    stage_plan(plan, a, slots);
+    // upload everything except the results region at the front
+    const size_t first = (res_bytes + 255) & ~(size_t)255;
+    HIP_TRY(hipMemcpyAsync((char *)c->d_ws + first, (char *)c->h_ws + first, a.off - first,
+                           hipMemcpyHostToDevice, c->stream));
+    {
+        Timed t(c, SPNG_K_INFLATE);
+        HIP_TRY(launch_inflate(a.dev<InflateJob>(jobs), count, dr, c->stream));
+    }
+    if (int32_t st = launch_plan(c, plan, a, slots, dr)) return st;
+    finish_decode_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, a.dev<uint64_t>(expected), count);
+    HIP_TRY(hipGetLastError());
+    if (h_results) {
+        HIP_TRY(hipMemcpyAsync(h_results, dr, res_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SPNG_DONE;
+}
+
+// ---- host-pointer convenience wrappers ---------------------------------------------------------
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+};
+
+int32_t spng_inflate(spng_ctx *c, const void *src, uint64_t n, int32_t format,
+                     void *dst, uint64_t cap, spng_result *result)
+{
+    if (!c || (!src && n) || (!dst && cap) || !result) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf ds, dd;
+    HIP_TRY(ds.alloc(n)); HIP_TRY(dd.alloc(cap));
+    HIP_TRY(hipMemcpyAsync(ds.p, src, n, hipMemcpyHostToDevice, c->stream));
+    spng_stream_desc d{ds.p, n, dd.p, cap, format, 0};
+    if (int32_t st = spng_inflate_batch(c, &d, 1, nullptr, result)) return st;
+    if (result->written) HIP_TRY(hipMemcpy(dst, dd.p, result->written, hipMemcpyDeviceToHost));
+    return SPNG_DONE;
+}
+
+int32_t spng_unfilter(spng_ctx *c, const void *rows, uint64_t rows_len,
+                      uint32_t w, uint32_t h, int depth, int channels, int interlaced,
+                      void *storage, spng_result *result)
+{
+    if (!c || (!rows && rows_len) || !storage || !result || !valid_format(depth, channels)) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t u = spng_inflated_size(w, h, depth, channels, interlaced);
+    const uint64_t s = spng_storage_size(w, h, depth, channels);
+    const uint64_t take = rows_len < u ? rows_len : u;
+    DevBuf dr, dst, dl;
+    HIP_TRY(dr.alloc(u)); HIP_TRY(dst.alloc(s)); HIP_TRY(dl.alloc(8));
+    HIP_TRY(hipMemcpyAsync(dr.p, rows, take, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dst.p, storage, s, hipMemcpyHostToDevice, c->stream));   // keep undecoded rows
+    HIP_TRY(hipMemcpyAsync(dl.p, &rows_len, 8, hipMemcpyHostToDevice, c->stream));
+    spng_image_desc d{};
+    d.d_rows = dr.p; d.rows_cap = u; d.d_storage = dst.p; d.width = w; d.height = h;
+    d.depth = (uint8_t)depth; d.channels = (uint8_t)channels; d.interlaced = (uint8_t)(interlaced != 0);
+    if (int32_t st = spng_unfilter_batch(c, &d, 1, (const uint64_t *)dl.p, nullptr, result)) return st;
+    HIP_TRY(hipMemcpy(storage, dst.p, s, hipMemcpyDeviceToHost));
+    return SPNG_DONE;
+}
+
+int32_t spng_decode(spng_ctx *c, const void *idat, uint64_t n, int32_t format,
+                    uint32_t w, uint32_t h, int depth, int channels, int interlaced,
+                    void *storage, spng_result *result)
+{
+    if (!c || (!idat && n) || !storage || !result || !valid_format(depth, channels)) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t u = spng_inflated_size(w, h, depth, channels, interlaced);
+    const uint64_t s = spng_storage_size(w, h, depth, channels);
+    DevBuf di, dr, dst;
+    HIP_TRY(di.alloc(n)); HIP_TRY(dr.alloc(u + 4096)); HIP_TRY(dst.alloc(s));
+    HIP_TRY(hipMemcpyAsync(di.p, idat, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dst.p, storage, s, hipMemcpyHostToDevice, c->stream));
+    spng_image_desc d{};
+    d.d_idat = di.p; d.idat_len = n; d.d_rows = dr.p; d.rows_cap = u + 4096; d.d_storage = dst.p;
+    d.width = w; d.height = h; d.depth = (uint8_t)depth; d.channels = (uint8_t)channels;
+    d.interlaced = (uint8_t)(interlaced != 0); d.format = (uint8_t)format;
+    if (int32_t st = spng_decode_batch(c, &d, 1, nullptr, result)) return st;
+    HIP_TRY(hipMemcpy(storage, dst.p, s, hipMemcpyDeviceToHost));
+    return SPNG_DONE;
+}
+
+
+int32_t spng_adler32(spng_ctx *c, const void *data, uint64_t n, uint32_t *out)
+{
+    if (!c || (!data && n) || !out) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t chunk = 1u << 16;
+    const uint32_t blocks = (uint32_t)((n + chunk - 1) / chunk);
+    uint32_t s1 = 1, s2 = 0;
+    if (blocks) {
+        DevBuf dd, dp;
+        HIP_TRY(dd.alloc(n)); HIP_TRY(dp.alloc((size_t)blocks * 16));
+        HIP_TRY(hipMemcpyAsync(dd.p, data, n, hipMemcpyHostToDevice, c->stream));
+        {
+            Timed t(c, SPNG_K_ADLER);
+            HIP_TRY(launch_adler_partial((const uint8_t *)dd.p, n, chunk, (uint64_t *)dp.p, blocks, c->stream));
+        }
+        std::vector<uint64_t> part((size_t)blocks * 2);
+        HIP_TRY(hipMemcpyAsync(part.data(), dp.p, (size_t)blocks * 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (uint32_t i = 0; i < blocks; ++i) {
+            const uint64_t len = n - (uint64_t)i * chunk < chunk ? n - (uint64_t)i * chunk : chunk;
+            s2 = (uint32_t)((s2 + (len % 65521) * s1 + part[2 * i + 1] % 65521) % 65521);
+            s1 = (uint32_t)((s1 + part[2 * i] % 65521) % 65521);
+        }
+    }
+    *out = s2 << 16 | s1;
+    return SPNG_DONE;
+}
+
+int32_t spng_filter_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t count,
+                          spng_result *d_results, spng_result *h_results)
+{
+    if (!c || (!descs && count)) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    std::vector<FilterJob> jobs;
+    std::vector<uint64_t> sizes(count);
+    uint32_t max_rows = 1;
+    for (uint32_t i = 0; i < count; ++i) {
+        const spng_image_desc &d = descs[i];
+        if (!valid_format(d.depth, d.channels) || !d.d_rows || !d.d_storage) return SPNG_E_ARGUMENT;
+        const int volume = d.depth * d.channels;
+        sizes[i] = spng_inflated_size(d.width, d.height, d.depth, d.channels, d.interlaced);
+        if (d.rows_cap < sizes[i]) return SPNG_E_ARGUMENT;
+        Pass p[7];
+        const int np = passes(d.width, d.height, volume, d.interlaced, p);
+        uint64_t off = 0;
+        for (int z = 0; z < np; ++z) {
+            FilterJob j;
+            j.storage = (const uint8_t *)d.d_storage;
+            j.rows = (uint8_t *)d.d_rows + off;
+            j.row_stride = p[z].pitch + 1;
+            j.sub_w = p[z].w; j.sub_h = p[z].h; j.width = d.width;
+            j.bx = p[z].bx; j.by = p[z].by; j.sx = p[z].sx; j.sy = p[z].sy;
+            j.depth = d.depth; j.channels = d.channels; j.pitch = (uint32_t)p[z].pitch;
+            jobs.push_back(j);
+            if (p[z].h > max_rows) max_rows = p[z].h;
+            off += (p[z].pitch + 1) * (uint64_t)p[z].h;
+        }
+    }
+    const size_t need = jobs.size() * sizeof(FilterJob) + count * (sizeof(spng_result) + 8) + 2048;
+    if (int32_t st = c->reserve(need)) return st;
+    Arena a{c};
+    const size_t jslot = a.take(jobs.size() * sizeof(FilterJob));
+    const size_t wslot = a.take(count * 8);
+    if (!jobs.empty()) memcpy(a.host<FilterJob>(jslot), jobs.data(), jobs.size() * sizeof(FilterJob));
+    memcpy(a.host<uint64_t>(wslot), sizes.data(), count * 8);
+    const size_t upload = a.off;
+    const size_t res = a.take(count * sizeof(spng_result));
+    HIP_TRY(hipMemcpyAsync(c->d_ws, c->h_ws, upload, hipMemcpyHostToDevice, c->stream));
+    spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
+    {
+        Timed t(c, SPNG_K_FILTER);
+        HIP_TRY(launch_filter(a.dev<FilterJob>(jslot), (uint32_t)jobs.size(), max_rows, c->stream));
+    }
+    init_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, a.dev<uint64_t>(wslot), count);
+    HIP_TRY(hipGetLastError());
+    if (h_results) {
+        HIP_TRY(hipMemcpyAsync(h_results, dr, count * sizeof(spng_result), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SPNG_DONE;
+}
+
+int32_t spng_filter(spng_ctx *c, const void *storage,
+                    uint32_t w, uint32_t h, int depth, int channels, int interlaced,
+                    void *rows, spng_result *result)
+{
+    if (!c || !storage || !rows || !result || !valid_format(depth, channels)) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t u = spng_inflated_size(w, h, depth, channels, interlaced);
+    const uint64_t s = spng_storage_size(w, h, depth, channels);
+    DevBuf dr, dst;
+    HIP_TRY(dr.alloc(u)); HIP_TRY(dst.alloc(s));
+    HIP_TRY(hipMemcpyAsync(dst.p, storage, s, hipMemcpyHostToDevice, c->stream));
+    spng_image_desc d{};
+    d.d_rows = dr.p; d.rows_cap = u; d.d_storage = dst.p; d.width = w; d.height = h;
+    d.depth = (uint8_t)depth; d.channels = (uint8_t)channels; d.interlaced = (uint8_t)(interlaced != 0);
+    if (int32_t st = spng_filter_batch(c, &d, 1, nullptr, result)) return st;
+    HIP_TRY(hipMemcpy(rows, dr.p, u, hipMemcpyDeviceToHost));
+    return SPNG_DONE;
+}
+
+}  // extern "C"

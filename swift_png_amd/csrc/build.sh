@@ -1,0 +1,11 @@
+#!/bin/bash
+# Builds libspng_mi355.so in-tree for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+OUT=../libspng_mi355.so
+SRCS="api.hip unfilter.hip inflate.hip encode.hip"
+newest=$(ls -t $SRCS common.hpp ../../include/spng_mi355.h build.sh | head -1)
+if [ -f "$OUT" ] && [ "$OUT" -nt "$newest" ]; then exit 0; fi
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
+    -o "$OUT" $SRCS ${SPNG_EXTRA_FLAGS:-}

@@ -1,0 +1,78 @@
+// common.hpp -- shared host/device declarations for libspng_mi355.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/spng_mi355.h"
+
+namespace spng {
+
+// One unfilter job = one dependency chain of scanlines: a whole non-interlaced image or one
+// Adam7 sub-image (PNG.Decoder.swift:59-140).  Rows are `in_stride` apart starting at `in`
+// (which points at the first row's filter byte); defiltered bytes of row y go to
+// out + y*out_stride.  For 8/16-bit non-interlaced images `out` is PNG.Image.storage itself;
+// otherwise the rows are defiltered in place (out = in + 1) and a scatter kernel follows.
+struct UnfJob {
+    const uint8_t *in;
+    uint8_t       *out;
+    uint64_t       in_stride;     // pitch + 1
+    uint64_t       out_stride;
+    uint64_t       stream_off;    // offset of `in` inside the image's inflated stream
+    const uint64_t *rows_len;     // device pointer to the number of valid inflated bytes, or null
+    uint32_t       pitch;         // bytes per row without the filter byte
+    uint32_t       rows;
+    uint32_t       image;         // index into the result array
+    uint32_t       bpp;           // "delay": ceil(volume / 8)
+};
+
+// One scatter job: defiltered rows of one (sub-)image -> PNG.Image.storage (PNG.Image.assign,
+// PNG.Image.swift:186-285), including MSB-first expansion of 1/2/4-bit samples.
+struct ScatterJob {
+    const uint8_t *rows;          // first row's first data byte
+    uint8_t       *storage;
+    uint64_t       row_stride;    // pitch + 1
+    uint64_t       stream_off;
+    const uint64_t *rows_len;
+    uint32_t       sub_w, sub_h;  // sub-image size in pixels
+    uint32_t       width;         // full image width
+    uint32_t       bx, by, sx, sy;
+    uint32_t       depth, channels;
+};
+
+// One filter job (encode): storage -> filtered rows of one (sub-)image
+// (PNG.Encoder.pull + PNG.Image.collect + PNG.Encoder.filter).
+struct FilterJob {
+    const uint8_t *storage;
+    uint8_t       *rows;          // first row's filter byte
+    uint64_t       row_stride;    // pitch + 1
+    uint32_t       sub_w, sub_h;
+    uint32_t       width;
+    uint32_t       bx, by, sx, sy;
+    uint32_t       depth, channels;
+    uint32_t       pitch;
+};
+
+struct InflateJob {
+    const uint8_t *src;
+    uint8_t       *dst;
+    uint64_t       src_len;
+    uint64_t       dst_cap;
+    int32_t        format;
+    uint32_t       image;
+};
+
+// PNG.adam7, PNG.Decoder.swift:6-15
+struct Pass { uint32_t bx, by, sx, sy, w, h; uint64_t pitch; };
+int passes(uint32_t w, uint32_t h, int volume, int interlaced, Pass out[7]);
+
+// kernel launchers (each returns the hipError_t of the launch)
+hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, spng_result *d_results,
+                           hipStream_t stream);
+hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32_t *d_job_image,
+                          const spng_result *d_results, uint32_t blocks_x, hipStream_t stream);
+hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results,
+                          hipStream_t stream);
+hipError_t launch_filter(const FilterJob *d_jobs, uint32_t count, uint32_t max_rows, hipStream_t stream);
+hipError_t launch_adler_partial(const uint8_t *d, uint64_t n, uint32_t chunk, uint64_t *d_out, uint32_t blocks,
+                                hipStream_t stream);
+
+}  // namespace spng

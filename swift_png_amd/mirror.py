@@ -1,0 +1,123 @@
+"""Python mirror of the reference's own API for the hot path, delegating to the C ABI.
+
+Names, argument meaning and error behaviour follow the Swift originals so that the parity tests
+read like the reference's tests.  State that the reference keeps as a resumable state machine
+(LZ77.InflatorState, PNG.Decoder.row/pass) is kept here as "bytes pushed so far": the device path
+decodes whole streams, so every push re-runs the stream from its start (results are identical by
+construction; the streaming cost model is not -- see DESIGN.md "Out of scope").
+"""
+from __future__ import annotations
+
+from . import (DONE, FORMAT_IOS, FORMAT_ZLIB, NEED_MORE_INPUT, DecodingError,
+               E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM, E_OUTPUT_CAPACITY)
+
+_DELAY_FORMATS = {1: (8, 1), 2: (8, 2), 3: (8, 3), 4: (8, 4), 6: (16, 3), 8: (16, 4)}
+
+
+class LZ77:
+    class Format:
+        zlib = FORMAT_ZLIB
+        ios = FORMAT_IOS
+
+    class Inflator:
+        """LZ77.Inflator (Sources/LZ77/Inflator/LZ77.Inflator.swift:8-62)."""
+
+        def __init__(self, format=FORMAT_ZLIB, session=None):
+            from . import load
+            self._s = session or load()
+            self._format = format
+            self._in = bytearray()
+            self._out = b""
+            self._cursor = 0
+            self._terminal = False
+
+        def push(self, data) -> object:
+            """Returns None once a complete stream has been received, () while it wants more."""
+            from . import raise_for
+            if self._terminal:
+                return None                      # .terminal: remaining input is ignored (:38-40)
+            self._in += bytes(data)
+            cap = max(1 << 16, 1100 * len(self._in))
+            while True:
+                status, out, _, aux = self._s.inflate(bytes(self._in), self._format, cap)
+                if status != E_OUTPUT_CAPACITY:
+                    break
+                cap *= 4                         # the reference's output buffer is unbounded
+            raise_for(status, aux)
+            self._out = out
+            self._terminal = status == DONE
+            return None if self._terminal else ()
+
+        def pull(self, count=None):
+            if count is None:                    # pull() -> everything available (:58-61)
+                data, self._cursor = self._out[self._cursor:], len(self._out)
+                return data
+            if len(self._out) - self._cursor < count:
+                return None                      # pull(_:) -> nil (:53-56)
+            data = self._out[self._cursor:self._cursor + count]
+            self._cursor += count
+            return data
+
+
+class PNG:
+    class Standard:
+        common = FORMAT_ZLIB
+        ios = FORMAT_IOS
+
+    class Decoder:
+        @staticmethod
+        def defilter(line: bytes, last: bytes, delay: int, session=None) -> bytes:
+            """PNG.Decoder.defilter(_:last:delay:) (PNG.Decoder.swift:152-196).  `line` and `last`
+            are pitch+1 bytes (index 0 = filter byte).  delay must be a real PNG pixel stride
+            (1, 2, 3, 4, 6 or 8)."""
+            from . import load
+            s = session or load()
+            pitch = len(line) - 1
+            depth, channels = _DELAY_FORMATS[delay]
+            assert pitch % delay == 0
+            rows = bytes([0]) + bytes(last[1:]) + bytes(line)
+            _, storage = s.unfilter(rows, pitch // delay, 2, depth, channels, False)
+            return bytes(line[:1]) + storage[pitch:]
+
+    class Encoder:
+        @staticmethod
+        def filter(line: bytes, last: bytes, delay: int, session=None) -> bytes:
+            """PNG.Encoder.filter(_:last:delay:) (PNG.Encoder.swift:132-204): line[0] == 0."""
+            from . import load
+            s = session or load()
+            pitch = len(line) - 1
+            depth, channels = _DELAY_FORMATS[delay]
+            assert pitch % delay == 0
+            rows = s.filter(bytes(last[1:]) + bytes(line[1:]), pitch // delay, 2, depth, channels, False)
+            return rows[pitch + 1:]
+
+    class Context:
+        """PNG.Context (Sources/PNG/Decoding/PNG.Context.swift:56-147), image side reduced to the
+        fields that cross the boundary: size, pixel depth/channels, interlacing, standard."""
+
+        def __init__(self, size, depth, channels, interlaced=False, standard=FORMAT_ZLIB, session=None):
+            from . import load, storage_size
+            self._s = session or load()
+            self.size, self.depth, self.channels = tuple(size), depth, channels
+            self.interlaced, self.standard = bool(interlaced), standard
+            self.storage = bytes(storage_size(size[0], size[1], depth, channels))
+            self._idat = bytearray()
+            self._continue = True                # PNG.Decoder.continue (:22-23)
+
+        def push(self, data: bytes):
+            """push(data:) (:88-102): one call per IDAT chunk."""
+            from . import raise_for
+            if not self._continue:
+                raise DecodingError(E_EXTRANEOUS_COMPRESSED_DATA)     # PNG.Decoder.swift:51-55
+            self._idat += bytes(data)
+            w, h = self.size
+            status, storage, aux = self._s.decode(bytes(self._idat), w, h, self.depth, self.channels,
+                                                  self.interlaced, self.standard, self.storage)
+            raise_for(status, aux)
+            self.storage = storage
+            self._continue = status == NEED_MORE_INPUT
+
+        def push_ancillary_iend(self):
+            """push(ancillary: IEND) (:137-142)."""
+            if self._continue:
+                raise DecodingError(E_INCOMPLETE_DATASTREAM)

@@ -1,0 +1,331 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same inputs, against
+the committed PngSuite goldens, and through the reference-shaped Python mirror.  Bit-exact."""
+import hashlib
+import json
+import zlib
+
+import numpy as np
+import pytest
+
+import pnghelp as ph
+from test_oracle_decode import _dynamic_header, _payloads
+
+pytestmark = pytest.mark.gpu
+TABLE = json.loads((ph.GOLDEN / "pngsuite.json").read_text())
+
+
+def _same_inflate(gpu, data, fmt=0, cap=None):
+    cap = cap if cap is not None else max(1 << 16, 1100 * len(data))
+    want = ph.orc_inflate(data, fmt, cap)
+    got = gpu.inflate(data, fmt, cap)
+    assert got[0] == want[0], (got[0], want[0])
+    assert got[1] == want[1]
+    assert got[3] == want[3]
+    if want[0] == 0:
+        assert got[2] == want[2]
+    return got
+
+
+@pytest.mark.parametrize("level", [0, 1, 6, 9])
+@pytest.mark.parametrize("kind", sorted(_payloads()))
+def test_inflate_vs_oracle(gpu, kind, level):
+    s = gpu.load()
+    data = _payloads()[kind]
+    z = zlib.compress(data, level)
+    st, out, consumed, _ = _same_inflate(s, z, 0, len(data) + 16)
+    assert (st, out, consumed) == (0, data, len(z))
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    raw = co.compress(data) + co.flush()
+    st, out, consumed, _ = _same_inflate(s, raw, 1, len(data) + 16)
+    assert (st, out, consumed) == (0, data, len(raw))
+
+
+def test_inflate_fixed_and_window_sizes(gpu):
+    s = gpu.load()
+    data = b"abcabcabcabc" * 50 + bytes(range(200))
+    co = zlib.compressobj(9, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    _same_inflate(s, co.compress(data) + co.flush())
+    rng = np.random.default_rng(11)
+    # long-distance matches (beyond the 32 KiB - 258 LDS window) and every wbits
+    block = rng.integers(0, 256, 40000, dtype=np.uint8).tobytes()
+    big = block[:32600] + block[:300] + block[100:33000] + block[:5000]
+    for wbits in (9, 12, 15):
+        co = zlib.compressobj(9, zlib.DEFLATED, wbits)
+        z = co.compress(big) + co.flush()
+        st, out, _, _ = _same_inflate(s, z, 0, len(big) + 16)
+        assert st == 0 and out == big
+
+
+def test_inflate_truncated_and_capacity(gpu):
+    s = gpu.load()
+    data = _payloads()["text"]
+    z = zlib.compress(data, 6)
+    for cut in (0, 1, 2, 3, 10, len(z) // 2, len(z) - 5, len(z) - 1):
+        st, out, _, _ = _same_inflate(s, z[:cut], 0, len(data) + 16)
+        assert st == 1 and data.startswith(out)
+    for cap in (0, 1, 100, len(data) - 1):
+        got = s.inflate(z, 0, cap)
+        want = ph.orc_inflate(z, 0, cap)
+        assert got[0] == want[0] == 64
+    z0 = zlib.compress(_payloads()["noise"], 0)            # stored blocks, truncated mid-block
+    for cut in (7, 100, 65535 + 20, len(z0) - 3):
+        _same_inflate(s, z0[:cut], 0, 80000)
+
+
+def test_inflate_error_vocabulary(gpu):
+    s = gpu.load()
+    good = zlib.compress(b"hello hello hello hello", 9)
+    bad = bytearray(good); bad[-1] ^= 1
+    cases = [
+        (b"\x77\x01" + good[2:], 0), (b"\x88\x01" + good[2:], 0), (b"\x78\x02" + good[2:], 0),
+        (b"\x78\x20" + good[2:], 0), (bytes(bad), 0), (b"\x78\x01\x07", 0),
+        (b"\x78\x01\x01\x03\x00\xfc\xfe\x00\x00\x00", 0),
+        (bytes([0x05 | (31 << 3) & 0xff, (31 >> 5), 0, 0, 0, 0, 0, 0]), 1),
+        (bytes([0x05, 0, 0, 0, 0, 0, 0, 0, 0, 0]), 1),
+        (_dynamic_header(257, 1, [1, 0, 0, 1], "1" + "00"), 1),
+    ]
+    clens = [0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1]
+    cases.append((_dynamic_header(257, 1, clens, "1" + "1111111" + "1" + "1111111"), 1))
+    cases.append((_dynamic_header(257, 1, clens, "1" + "1111111" + "1" + format(120 - 11, "07b")[::-1]), 1))
+    bits = "1" + "10" + "0000001" + "00000"
+    cases.append((bytes(int("".join(reversed(bits[i:i + 8].ljust(8, "0"))), 2) for i in range(0, len(bits), 8)) + b"\0\0", 1))
+    seen = set()
+    for data, fmt in cases:
+        seen.add(_same_inflate(s, data, fmt, 4096)[0])
+    assert seen == {16, 17, 18, 19, 32, 33, 34, 35, 36, 37, 38, 39}
+
+
+def test_inflate_batch_many_streams(gpu):
+    s = gpu.load()
+    rng = np.random.default_rng(5)
+    datas, zs = [], []
+    for i in range(70):
+        n = int(rng.integers(0, 200000))
+        d = (rng.integers(0, 256, n, dtype=np.uint8) * (rng.random(n) < rng.random())).astype(np.uint8).tobytes()
+        datas.append(d)
+        zs.append(zlib.compress(d, int(rng.integers(0, 10))))
+    outs, res = s.inflate_batch([s.to_device(z) for z in zs], [len(d) + 32 for d in datas])
+    for d, z, o, r in zip(datas, zs, outs, res):
+        assert r.status == 0 and r.written == len(d) and r.consumed == len(z)
+        assert bytes(o[:len(d)].cpu().numpy()) == d
+
+
+FORMATS = [(1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (8, 2), (16, 2), (8, 3), (16, 3), (8, 4), (16, 4)]
+
+
+@pytest.mark.parametrize("interlaced", [False, True])
+@pytest.mark.parametrize("depth,channels", FORMATS)
+def test_unfilter_vs_oracle(gpu, depth, channels, interlaced):
+    s = gpu.load()
+    rng = np.random.default_rng(depth * 100 + channels * 10 + interlaced)
+    for (w, h) in [(1, 1), (3, 2), (8, 8), (33, 70), (130, 131), (257, 65)]:
+        u = gpu.inflated_size(w, h, depth, channels, interlaced)
+        rows = rng.integers(0, 256, u, dtype=np.uint8)
+        # put a valid-ish filter byte at the start of every row (plus a few invalid ones: treated as None)
+        off = 0
+        for p in _passes(w, h, depth * channels, interlaced):
+            for y in range(p[1]):
+                rows[off] = rng.integers(0, 6) if rng.random() < 0.9 else rng.integers(5, 256)
+                off += p[0] + 1
+        st_o, want = ph.orc_unfilter(rows.tobytes(), w, h, depth, channels, interlaced)
+        st_g, got = s.unfilter(rows.tobytes(), w, h, depth, channels, interlaced)
+        assert st_g == st_o == 0
+        assert got == want.tobytes(), (w, h)
+
+
+def _passes(w, h, volume, interlaced):
+    if not interlaced:
+        return [((w * volume + 7) >> 3, h)]
+    out = []
+    for bx, by, ex, ey in [(0, 0, 3, 3), (4, 0, 3, 3), (0, 4, 2, 3), (2, 0, 2, 2), (0, 2, 1, 2), (1, 0, 1, 1), (0, 1, 0, 1)]:
+        sw, sh = (w + (1 << ex) - bx - 1) >> ex, (h + (1 << ey) - by - 1) >> ey
+        if sw > 0 and sh > 0:
+            out.append(((sw * volume + 7) >> 3, sh))
+    return out
+
+
+@pytest.mark.parametrize("ft", [0, 1, 2, 3, 4])
+def test_unfilter_single_filter_wide(gpu, ft):
+    """Rows wider than several tiles and taller than several 64-row bands, one filter type."""
+    s = gpu.load()
+    rng = np.random.default_rng(ft)
+    w, h = 1000, 200
+    rows = rng.integers(0, 256, (h, 1 + 4 * w), dtype=np.uint8)
+    rows[:, 0] = ft
+    st, want = ph.orc_unfilter(rows.tobytes(), w, h, 8, 4, False)
+    st2, got = s.unfilter(rows.tobytes(), w, h, 8, 4, False)
+    assert st == st2 == 0 and got == want.tobytes()
+
+
+def test_unfilter_short_and_extraneous(gpu):
+    s = gpu.load()
+    rng = np.random.default_rng(9)
+    w, h = 40, 100
+    rows = rng.integers(0, 256, (h, 1 + 4 * w), dtype=np.uint8)
+    rows[:, 0] = rng.integers(0, 5, h)
+    full = rows.tobytes()
+    sentinel = bytes([0xAB]) * (w * h * 4)
+    for n in (0, 1, 161, 160, 161 * 70 + 5, len(full) - 1):
+        st_o, want = ph.orc_unfilter(full[:n], w, h, 8, 4, False)
+        st_g, got = s.unfilter(full[:n], w, h, 8, 4, False, storage=sentinel)
+        assert st_g == st_o == 0
+        done = (n // 161) * 160
+        assert got[:done] == want.tobytes()[:done]
+        assert got[done:] == sentinel[done:]                 # undecoded rows are left untouched
+    st_g, got = s.unfilter(full + b"\0", w, h, 8, 4, False)
+    assert st_g == 48 and got == ph.orc_unfilter(full, w, h, 8, 4, False)[1].tobytes()
+
+
+@pytest.mark.parametrize("name", sorted(TABLE))
+def test_pngsuite_golden(gpu, name):
+    s = gpu.load()
+    png = ph.parse_png((ph.GOLDEN / "pngsuite" / name).read_bytes())
+    st, storage, _ = s.decode(png.idat, png.width, png.height, png.depth, png.channels, png.interlaced, png.fmt)
+    assert st == 0
+    assert hashlib.sha256(storage).hexdigest() == TABLE[name]["storage_sha256"]
+    rgba = ph.unpack_rgba16(np.frombuffer(storage, np.uint8), png).astype("<u2")
+    assert hashlib.sha256(rgba.tobytes()).hexdigest() == TABLE[name]["rgba16_sha256"]
+
+
+def test_decode_batch_mixed(gpu):
+    """One spng_decode_batch call over every PngSuite fixture at once (mixed formats, Adam7, CgBI)."""
+    s = gpu.load()
+    names = sorted(TABLE)
+    pngs = [ph.parse_png((ph.GOLDEN / "pngsuite" / n).read_bytes()) for n in names]
+    keep, descs = [], []
+    for p in pngs:
+        u = gpu.inflated_size(p.width, p.height, p.depth, p.channels, p.interlaced)
+        idat, rows = s.to_device(p.idat), s.empty(u + 4096)
+        storage = s.empty(gpu.storage_size(p.width, p.height, p.depth, p.channels))
+        keep.append((idat, rows, storage))
+        descs.append(s.image_desc(idat, rows, storage, p.width, p.height, p.depth, p.channels, p.interlaced, p.fmt))
+    res = s.decode_batch(descs)
+    for n, p, (_, _, storage), r in zip(names, pngs, keep, res):
+        assert r.status == 0, n
+        size = gpu.storage_size(p.width, p.height, p.depth, p.channels)
+        assert hashlib.sha256(bytes(storage[:size].cpu().numpy())).hexdigest() == TABLE[n]["storage_sha256"], n
+    # asynchronous form: results stay on the device
+    s.decode_batch(descs, wait=False)
+    s.sync()
+    assert [r.status for r in s.fetch_results(len(descs))] == [0] * len(descs)
+
+
+def test_decode_errors_and_partial(gpu):
+    s = gpu.load()
+    rng = np.random.default_rng(2)
+    rows = rng.integers(0, 256, (8, 1 + 32), dtype=np.uint8)
+    rows[:, 0] = rng.integers(0, 5, 8)
+    cases = {
+        "extra": zlib.compress(rows.tobytes() + b"\x00", 6),
+        "short": zlib.compress(rows.tobytes()[:-40], 6),
+        "trunc": zlib.compress(rows.tobytes(), 6)[:-6],
+        "badsum": zlib.compress(rows.tobytes(), 6)[:-1] + b"\x00",
+        "ok": zlib.compress(rows.tobytes(), 6),
+    }
+    for k, z in cases.items():
+        png = ph.Png(8, 8, 8, 6, False, False, z)
+        st_o, want, aux_o = ph.orc_decode(png)
+        st_g, got, aux_g = s.decode(z, 8, 8, 8, 4, False, 0, storage=bytes(256))
+        assert (st_g, aux_g) == (st_o, aux_o), k
+        assert got == want.tobytes(), k
+
+
+def test_config1_stored_blocks(gpu):
+    """BASELINE config 1: 256x256 RGBA8, filter=Sub, level 0 (stored blocks)."""
+    s = gpu.load()
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (256, 1024), dtype=np.uint8)
+    rows = np.zeros((256, 1025), dtype=np.uint8)
+    rows[:, 0] = 1
+    rows[:, 1:5] = img[:, :4]
+    rows[:, 5:] = img[:, 4:] - img[:, :-4]
+    z = zlib.compress(rows.tobytes(), 0)
+    st, storage, _ = s.decode(z, 256, 256, 8, 4, False)
+    assert st == 0 and storage == img.tobytes()
+
+
+def test_mirror_inflator_and_context(gpu):
+    """The reference-shaped API: LZ77.Inflator push/pull (Snippets/LZ77/StreamingZlib.swift) and
+    PNG.Context.push per IDAT chunk (PNG.Image.swift:385-389)."""
+    data = _payloads()["text"]
+    z = zlib.compress(data, 9)
+    inf = gpu.LZ77.Inflator()
+    assert inf.push(z[:100]) == ()
+    assert inf.pull(len(data)) is None
+    assert inf.push(z[100:]) is None
+    assert inf.pull(10) == data[:10]
+    assert inf.pull() == data[10:]
+    with pytest.raises(gpu.DecompressionError) as e:
+        gpu.LZ77.Inflator().push(z[:-1] + bytes([z[-1] ^ 1]))
+    assert e.value.status == 32
+    # multi-IDAT image (oi9n2c16: 229 chunks) pushed chunk by chunk
+    name = "common/oi4n2c16.png"
+    png = ph.parse_png((ph.GOLDEN / "pngsuite" / name).read_bytes())
+    ctx = gpu.PNG.Context((png.width, png.height), png.depth, png.channels, png.interlaced, png.fmt)
+    pos = 0
+    for n in png.idat_chunks:
+        ctx.push(png.idat[pos:pos + n]); pos += n
+    ctx.push_ancillary_iend()
+    assert hashlib.sha256(ctx.storage).hexdigest() == TABLE[name]["storage_sha256"]
+    with pytest.raises(gpu.DecodingError):
+        ctx.push(b"\0")                                        # extraneousImageDataCompressedData
+
+
+@pytest.mark.parametrize("delay", [1, 2, 3, 4, 6, 8])
+def test_mirror_filter_defilter_roundtrip(gpu, delay):
+    """PNGTests/Filtering.swift:9-64: Encoder.filter -> Decoder.defilter identity, and both agree
+    with the oracle row functions."""
+    rng = np.random.default_rng(delay)
+    pitch = 24 * delay
+    last = bytes([0]) + bytes(pitch)
+    orc = ph.oracle()
+    for _ in range(6):
+        line = bytes([0]) + rng.integers(0, 256, pitch, dtype=np.uint8).tobytes()
+        filtered = gpu.PNG.Encoder.filter(line, last, delay)
+        a, b = np.frombuffer(line, np.uint8).copy(), np.frombuffer(last, np.uint8).copy()
+        out = np.zeros(pitch + 1, np.uint8)
+        orc.orc_filter_row(ph._ptr(a), ph._ptr(b), pitch + 1, delay, ph._ptr(out))
+        assert filtered == out.tobytes()
+        restored = gpu.PNG.Decoder.defilter(filtered, last, delay)
+        assert restored[1:] == line[1:]
+        last = line
+
+
+@pytest.mark.parametrize("interlaced", [False, True])
+@pytest.mark.parametrize("depth,channels", FORMATS)
+def test_filter_vs_oracle(gpu, depth, channels, interlaced):
+    s = gpu.load()
+    rng = np.random.default_rng(depth + channels)
+    for (w, h) in [(1, 1), (9, 5), (64, 33), (131, 17)]:
+        n = gpu.storage_size(w, h, depth, channels)
+        hi = (1 << depth) if depth < 8 else 256
+        if rng.random() < 0.5:
+            storage = rng.integers(0, hi, n, dtype=np.uint8)
+        else:                                                 # smooth content so that all filters get chosen
+            storage = ((np.arange(n) // max(1, (depth * channels + 7) // 8) * 3) % hi).astype(np.uint8)
+        want = ph.orc_filter(storage, w, h, depth, channels, interlaced)
+        got = s.filter(storage.tobytes(), w, h, depth, channels, interlaced)
+        assert got == want, (w, h)
+
+
+def test_adler32(gpu):
+    s = gpu.load()
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 5552, 65536, 65537, 300000):
+        d = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert s.adler32(d) == zlib.adler32(d)
+
+
+def test_synthetic_4k_image_roundtrip(gpu):
+    """One image of the benchmark workload, end to end: GPU filter == oracle filter; zlib level 6;
+    GPU decode == the original raster (size-independent property for the full-size config)."""
+    from swift_png_amd import synth
+    s = gpu.load()
+    img = synth.image(3, 4096, 4096)
+    rows = s.filter(img.tobytes(), 4096, 4096, 8, 4, False)
+    assert hashlib.sha256(rows).digest() == hashlib.sha256(ph.orc_filter(img.reshape(-1), 4096, 4096, 8, 4, False)).digest()
+    hist = np.bincount(np.frombuffer(rows, np.uint8).reshape(4096, 16385)[:, 0], minlength=5)
+    assert (hist > 0).sum() >= 3                              # "mixed filters"
+    z = zlib.compress(rows, 6)
+    st, storage, _ = s.decode(z, 4096, 4096, 8, 4, False)
+    assert st == 0 and storage == img.tobytes()
