@@ -10,20 +10,30 @@
 // lane r works on unit t - r.  The value lane r needs from the row above is exactly what lane r-1
 // produced one step earlier, and arrives through a single DPP wave_shr:1 move -- no LDS, no
 // barrier.  The left neighbour and the upper-left neighbour are register carries.
+// A workgroup of NW waves owns one scanline chain (image / Adam7 sub-image): wave w takes bands
+// w, w+NW, ... and the bands run as a software pipeline, band j trailing band j-1 by three tiles.
+// The row above a band (last row of the previous band) is read back from the output raster with
+// L1-bypassing (sc1) loads; per-wave progress counters in LDS order producer and consumer (the
+// producer drains its stores with vmcnt(0) before publishing).  No workgroup barriers in the loop.
 //
 // Memory.  Row r of a tile covers the *skewed* window of units [T*P - r, (T+1)*P - r): since
 // rows are pitch+1 bytes apart (never aligned) the loads are unaligned 16-byte loads anyway, so
-// the skew costs nothing, and inside LDS every lane walks the same column index.  Tiles are
-// staged with 16 B/lane coalesced global loads (16 consecutive lanes cover one 256-byte row
-// segment), reconstructed in place in LDS, and written back with 16 B/lane stores.  The row above
-// the band (the band's own previous output row, or zeros for the first row of a pass:
-// PNG.Decoder.swift:83-84) is staged as LDS row 0 and feeds lane 0.
+// the skew costs nothing, and inside LDS every lane walks the same column index.  The loads of
+// tile i+1 are issued (16 B/lane, 16 consecutive lanes cover one row segment) before tile i is
+// reconstructed and are committed to LDS after it has been written back, so HBM latency hides
+// under the arithmetic.  Tiles are reconstructed in place in LDS and written back with 16 B/lane
+// stores.  Rows are padded to TB+16 bytes so that the per-lane 16-byte column accesses are
+// bank-conflict free.
 #include "common.hpp"
 
 namespace spng {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) U128u { u32x4 v; };       // 16 bytes, alignment 1
+
+#ifndef SPNG_UNF_NW
+#define SPNG_UNF_NW 4                                    // waves per scanline chain
+#endif
 
 template <int BPP> struct Cfg {
     static constexpr int P    = (BPP <= 4) ? 64 : 32;    // units per tile window
@@ -44,6 +54,30 @@ __device__ __forceinline__ u32x4 load_window(const uint8_t *p, int64_t off, int6
     for (int k = 0; k < 16; ++k) {
         int64_t i = off + k;
         uint32_t b = (i >= 0 && i < pitch) ? p[i] : 0u;
+        w[k >> 2] |= b << (8 * (k & 3));
+    }
+    v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    return v;
+}
+
+// same, for bytes another wave of this workgroup wrote: bypass this CU's L1 (sc1 / nt loads are
+// served by the XCD's L2, where the producer's write-through stores already are)
+__device__ __forceinline__ u32x4 load_window_l2(const uint8_t *p, int64_t off, int64_t pitch)
+{
+    u32x4 v = {0, 0, 0, 0};
+    if (off + 16 <= 0 || off >= pitch) return v;
+    if (off >= 0 && off + 16 <= pitch && (((uintptr_t)(p + off)) & 7) == 0) {
+        const unsigned long long *q = (const unsigned long long *)(p + off);
+        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.x = (uint32_t)lo; v.y = (uint32_t)(lo >> 32); v.z = (uint32_t)hi; v.w = (uint32_t)(hi >> 32);
+        return v;
+    }
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int64_t i = off + k;
+        uint32_t b = (i >= 0 && i < pitch) ? __builtin_nontemporal_load(p + i) : 0u;
         w[k >> 2] |= b << (8 * (k & 3));
     }
     v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
@@ -81,16 +115,108 @@ __device__ __forceinline__ bool skip_status(int32_t s)
     return (s >= 16 && s < 48) || s == SPNG_E_REFERENCE_UNDEFINED;
 }
 
+// ---- reconstruction of one tile: generic byte-wise form (any bpp) ----------------------------
+template <int BPP, int P>
+__device__ __forceinline__ void reconstruct_generic(uint8_t *tile, int rowb, int lane, uint32_t ft,
+                                                    int64_t ux0, uint32_t (&o)[BPP], uint32_t (&bprev)[BPP])
+{
+    uint8_t *mine = tile + (1 + lane) * rowb;
+#pragma unroll 2
+    for (int t = 0; t < P; ++t) {
+        const bool interior = ux0 + t > 0;               // unit 0 has no left / upper-left neighbour
+        uint32_t b[BPP];
+#pragma unroll
+        for (int k = 0; k < BPP; ++k) b[k] = from_lane_above(o[k], tile[t * BPP + k]);
+#pragma unroll
+        for (int k = 0; k < BPP; ++k) {
+            const uint32_t a = interior ? o[k] : 0u;
+            const uint32_t c = interior ? bprev[k] : 0u;
+            const uint32_t x = mine[t * BPP + k];
+            uint32_t pred = 0;
+            if (ft == 1) pred = a;
+            else if (ft == 2) pred = b[k];
+            else if (ft == 3) pred = (a + b[k]) >> 1;
+            else if (ft == 4) pred = paeth(a, b[k], c);
+            o[k] = (x + pred) & 0xffu;
+            mine[t * BPP + k] = (uint8_t)o[k];
+            bprev[k] = b[k];
+        }
+    }
+}
+
+// ---- reconstruction of one tile: 4 bytes per unit, two packed-u16 halves per dword -----------
+// even bytes live in `lo` (x & 0x00ff00ff), odd bytes in `hi` ((x >> 8) & 0x00ff00ff); sums of two
+// bytes cannot carry across the 16-bit lanes, signed differences use the packed-i16 VALU ops.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t paeth_pk(uint32_t a, uint32_t b, uint32_t c)
+{
+    const s16x2 va = __builtin_bit_cast(s16x2, a), vb = __builtin_bit_cast(s16x2, b), vc = __builtin_bit_cast(s16x2, c);
+    const s16x2 d0 = vb - vc, d1 = va - vc, ds = d0 + d1;
+    const s16x2 pa = __builtin_elementwise_max(d0, -d0), pb = __builtin_elementwise_max(d1, -d1),
+                pc = __builtin_elementwise_max(ds, -ds);
+    const s16x2 fifteen = {15, 15};
+    const uint32_t nota = __builtin_bit_cast(uint32_t, (pb - pa) >> fifteen) | __builtin_bit_cast(uint32_t, (pc - pa) >> fifteen);
+    const uint32_t usec = __builtin_bit_cast(uint32_t, (pc - pb) >> fifteen);
+    const uint32_t bc = (c & usec) | (b & ~usec);
+    return (bc & nota) | (a & ~nota);
+}
+
+template <int P, bool FIRST>
+__device__ __forceinline__ void reconstruct4(uint8_t *tile, int rowb, int lane, uint32_t ft, int64_t ux0,
+                                             uint32_t &o, uint32_t &bprev)
+{
+    constexpr uint32_t M = 0x00ff00ffu;
+    const uint32_t m_sub = ft == 1 ? M : 0u, m_up = ft == 2 ? M : 0u, m_avg = ft == 3 ? M : 0u,
+                   m_pae = ft == 4 ? M : 0u;
+    const bool any_pae = __any(ft == 4);
+    u32x4 *mine = (u32x4 *)(tile + (1 + lane) * rowb);
+    const u32x4 *top = (const u32x4 *)tile;
+    uint32_t a_lo = o & M, a_hi = (o >> 8) & M, c_lo = bprev & M, c_hi = (bprev >> 8) & M;
+#pragma unroll 2
+    for (int t4 = 0; t4 < P / 4; ++t4) {
+        const u32x4 raw = mine[t4], tp = top[t4];
+        uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
+        const uint32_t tq[4] = {tp.x, tp.y, tp.z, tp.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t b = from_lane_above(o, tq[k]);
+            const uint32_t b_lo = b & M, b_hi = (b >> 8) & M;
+            uint32_t p_lo = (a_lo & m_sub) | (b_lo & m_up) | (((a_lo + b_lo) >> 1) & m_avg);
+            uint32_t p_hi = (a_hi & m_sub) | (b_hi & m_up) | (((a_hi + b_hi) >> 1) & m_avg);
+            if (any_pae) {
+                p_lo |= paeth_pk(a_lo, b_lo, c_lo) & m_pae;
+                p_hi |= paeth_pk(a_hi, b_hi, c_hi) & m_pae;
+            }
+            uint32_t x_lo = ((r[k] & M) + p_lo) & M, x_hi = (((r[k] >> 8) & M) + p_hi) & M;
+            if (FIRST) {
+                // units left of the row start produce zeros, so that unit 0 sees a = c = 0
+                const uint32_t live = (ux0 + t4 * 4 + k >= 0) ? M : 0u;
+                x_lo &= live; x_hi &= live;
+            }
+            o = x_lo | x_hi << 8;
+            r[k] = o;
+            c_lo = b_lo; c_hi = b_hi; a_lo = x_lo; a_hi = x_hi;
+            bprev = b;
+        }
+        u32x4 w; w.x = r[0]; w.y = r[1]; w.z = r[2]; w.w = r[3];
+        mine[t4] = w;
+    }
+}
+
 template <int BPP>
-__global__ __launch_bounds__(64) void unfilter_kernel(const UnfJob *__restrict__ jobs,
-                                                      const spng_result *__restrict__ results)
+__global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob *__restrict__ jobs,
+                                                                     const spng_result *__restrict__ results)
 {
     using C = Cfg<BPP>;
-    __shared__ __attribute__((aligned(16))) uint8_t tile[65 * C::ROWB];
+    constexpr int NW = SPNG_UNF_NW;
+    __shared__ __attribute__((aligned(16))) uint8_t tiles[NW][65 * C::ROWB];
+    __shared__ uint32_t done[NW];                        // tiles completed by each wave
 
     const UnfJob job = jobs[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (results && skip_status(results[job.image].status)) return;
+    if (threadIdx.x < NW) done[threadIdx.x] = 0;
+    __syncthreads();
 
     uint32_t rows = job.rows;
     if (job.rows_len) {
@@ -102,77 +228,94 @@ __global__ __launch_bounds__(64) void unfilter_kernel(const UnfJob *__restrict__
     const int64_t pitch = job.pitch;
     const uint32_t W = job.pitch / BPP;
     const uint32_t ntiles = (W + 63 + C::P - 1) / C::P;
+    const uint32_t nbands = (rows + 63) / 64;
+    uint8_t *tile = tiles[wave];
 
-    for (uint32_t band = 0; band * 64 < rows; ++band) {
-        const uint32_t row = band * 64 + lane;
-        const bool active = row < rows;
-        const uint32_t ft = active ? job.in[(uint64_t)row * job.in_stride] : 0u;
-        if (band) {
-            // the row above this band was written by this wave's previous band: wait for those
-            // stores and drop this CU's (possibly stale) L1 lines before re-reading them.
-            // (same CU, hence same XCD L2: no L2 write-back needed, only vmcnt(0) + buffer_inv.)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // staging registers for the next tile
+    u32x4 R[C::CPR], Rtop;
+    auto issue = [&](uint32_t band, uint32_t T) {
+#pragma unroll
+        for (int m = 0; m < C::CPR; ++m) {
+            const int i = lane + 64 * m, r = i / C::CPR, cj = i % C::CPR;
+            const uint32_t rw = band * 64 + r;
+            u32x4 v = {0, 0, 0, 0};
+            if (rw < rows)
+                v = load_window(job.in + (uint64_t)rw * job.in_stride + 1,
+                                ((int64_t)T * C::P - r) * BPP + 16 * cj, pitch);
+            R[m] = v;
         }
+        Rtop = u32x4{0, 0, 0, 0};
+        if (band && lane < C::CPR)
+            Rtop = load_window_l2(job.out + (uint64_t)(band * 64 - 1) * job.out_stride,
+                                  (int64_t)T * C::TB + 16 * lane, pitch);
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int m = 0; m < C::CPR; ++m) {
+            const int i = lane + 64 * m, r = i / C::CPR, cj = i % C::CPR;
+            *(u32x4 *)(tile + (1 + r) * C::ROWB + 16 * cj) = R[m];
+        }
+        if (lane < C::CPR) *(u32x4 *)(tile + 16 * lane) = Rtop;
+    };
+    // band j tile T needs the last row of band j-1 on units [T*P, T*P+P): produced by band j-1's
+    // tiles T and T+1.  `done` of the producing wave counts tiles over all of its bands.
+    auto ready = [&](uint32_t band, uint32_t T) -> bool {
+        if (!band) return true;
+        const uint32_t pw = (band - 1) % NW, pk = (band - 1) / NW;
+        const uint32_t need = pk * ntiles + (T + 1 < ntiles ? T + 1 : ntiles - 1) + 1;
+        return __hip_atomic_load(&done[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
+    };
+    auto wait_ready = [&](uint32_t band, uint32_t T) {
+        while (!ready(band, T)) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+
+    uint32_t count = 0;                                  // tiles this wave has completed
+    bool staged = false;                                 // R holds the tile about to be processed
+    for (uint32_t band = wave; band < nbands; band += NW) {
+        const uint32_t row = band * 64 + lane;
+        const uint32_t ft = row < rows ? job.in[(uint64_t)row * job.in_stride] : 0u;
         uint32_t o[BPP], bprev[BPP];
 #pragma unroll
         for (int k = 0; k < BPP; ++k) { o[k] = 0; bprev[k] = 0; }
 
         for (uint32_t T = 0; T < ntiles; ++T) {
-            // ---- stage: 65 row windows -> LDS
-            for (int i = lane; i < 65 * C::CPR; i += 64) {
-                const int rr = i / C::CPR, cj = i % C::CPR;
-                u32x4 v = {0, 0, 0, 0};
-                if (rr == 0) {
-                    if (band)
-                        v = load_window(job.out + (uint64_t)(band * 64 - 1) * job.out_stride,
-                                        (int64_t)T * C::TB + 16 * cj, pitch);
-                } else {
-                    const int r = rr - 1;
-                    const uint32_t rw = band * 64 + r;
-                    if (rw < rows)
-                        v = load_window(job.in + (uint64_t)rw * job.in_stride + 1,
-                                        ((int64_t)T * C::P - r) * BPP + 16 * cj, pitch);
-                }
-                *(u32x4 *)(tile + rr * C::ROWB + 16 * cj) = v;
+            if (!staged) { wait_ready(band, T); issue(band, T); }
+            commit();
+            staged = false;
+            // prefetch the next tile of this wave while this one is reconstructed
+            uint32_t nb = band, nT = T + 1;
+            if (nT == ntiles) { nb = band + NW; nT = 0; }
+            if (nb < nbands && ready(nb, nT)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                issue(nb, nT);
+                staged = true;
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS tile written before it is read
 
-            // ---- reconstruct P units per lane, in place
-            uint8_t *mine = tile + (1 + lane) * C::ROWB;
             const int64_t ux0 = (int64_t)T * C::P - lane;
-#pragma unroll 4
-            for (int t = 0; t < C::P; ++t) {
-                const bool interior = ux0 + t > 0;          // unit 0 has no left / upper-left neighbour
-                uint32_t b[BPP];
-#pragma unroll
-                for (int k = 0; k < BPP; ++k) b[k] = from_lane_above(o[k], tile[t * BPP + k]);
-#pragma unroll
-                for (int k = 0; k < BPP; ++k) {
-                    const uint32_t a = interior ? o[k] : 0u;
-                    const uint32_t c = interior ? bprev[k] : 0u;
-                    const uint32_t x = mine[t * BPP + k];
-                    uint32_t pred = 0;
-                    if (ft == 1) pred = a;
-                    else if (ft == 2) pred = b[k];
-                    else if (ft == 3) pred = (a + b[k]) >> 1;
-                    else if (ft == 4) pred = paeth(a, b[k], c);
-                    o[k] = (x + pred) & 0xffu;
-                    mine[t * BPP + k] = (uint8_t)o[k];
-                    bprev[k] = b[k];
-                }
+            if constexpr (BPP == 4) {
+                if (T == 0) reconstruct4<C::P, true>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
+                else        reconstruct4<C::P, false>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
+            } else {
+                reconstruct_generic<BPP, C::P>(tile, C::ROWB, lane, ft, ux0, o, bprev);
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
-            // ---- write back the 64 row windows
-            for (int i = lane; i < 64 * C::CPR; i += 64) {
-                const int r = i / C::CPR, cj = i % C::CPR;
+            // write back the 64 row windows
+#pragma unroll
+            for (int m = 0; m < C::CPR; ++m) {
+                const int i = lane + 64 * m, r = i / C::CPR, cj = i % C::CPR;
                 const uint32_t rw = band * 64 + r;
                 if (rw < rows)
                     store_window(job.out + (uint64_t)rw * job.out_stride,
                                  ((int64_t)T * C::P - r) * BPP + 16 * cj, pitch,
                                  *(const u32x4 *)(tile + (1 + r) * C::ROWB + 16 * cj));
             }
-            __syncthreads();
+            // publish: stores drained (they are in the XCD's L2 once acknowledged), then the counter
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ++count;
+            if (lane == 0) __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -181,13 +324,14 @@ hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, s
                            hipStream_t stream)
 {
     if (!count) return hipSuccess;
+    constexpr int T = SPNG_UNF_NW * 64;
     switch (bpp) {
-    case 1: unfilter_kernel<1><<<count, 64, 0, stream>>>(d_jobs, d_results); break;
-    case 2: unfilter_kernel<2><<<count, 64, 0, stream>>>(d_jobs, d_results); break;
-    case 3: unfilter_kernel<3><<<count, 64, 0, stream>>>(d_jobs, d_results); break;
-    case 4: unfilter_kernel<4><<<count, 64, 0, stream>>>(d_jobs, d_results); break;
-    case 6: unfilter_kernel<6><<<count, 64, 0, stream>>>(d_jobs, d_results); break;
-    case 8: unfilter_kernel<8><<<count, 64, 0, stream>>>(d_jobs, d_results); break;
+    case 1: unfilter_kernel<1><<<count, T, 0, stream>>>(d_jobs, d_results); break;
+    case 2: unfilter_kernel<2><<<count, T, 0, stream>>>(d_jobs, d_results); break;
+    case 3: unfilter_kernel<3><<<count, T, 0, stream>>>(d_jobs, d_results); break;
+    case 4: unfilter_kernel<4><<<count, T, 0, stream>>>(d_jobs, d_results); break;
+    case 6: unfilter_kernel<6><<<count, T, 0, stream>>>(d_jobs, d_results); break;
+    case 8: unfilter_kernel<8><<<count, T, 0, stream>>>(d_jobs, d_results); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
