@@ -19,7 +19,7 @@ import os
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libspng_mi355.so"
+LIB_PATH = Path(os.environ.get("SPNG_LIB", _HERE / "libspng_mi355.so"))   # SPNG_LIB: tuning builds only
 
 # ---- status vocabulary (include/spng_mi355.h) -------------------------------------------------
 DONE, NEED_MORE_INPUT = 0, 1

@@ -35,8 +35,16 @@ struct __attribute__((packed)) U128u { u32x4 v; };       // 16 bytes, alignment 
 #define SPNG_UNF_NW 4                                    // waves per scanline chain
 #endif
 
+#ifndef SPNG_UNF_P4
+#define SPNG_UNF_P4 64                                   // tile width in units for bpp <= 4
+#endif
+#ifndef SPNG_UNF_P8
+#define SPNG_UNF_P8 32                                   // tile width in units for bpp > 4
+#endif
+
 template <int BPP> struct Cfg {
-    static constexpr int P    = (BPP <= 4) ? 64 : 32;    // units per tile window
+    static constexpr int P    = (BPP <= 4) ? SPNG_UNF_P4 : SPNG_UNF_P8;   // units per tile window
+    static constexpr int K    = (63 + P - 1) / P;        // producer tiles a consumer tile reaches into
     static constexpr int TB   = P * BPP;                 // bytes per row per tile (multiple of 16)
     static constexpr int ROWB = TB + 16;                 // LDS row stride: conflict-free b128 columns
     static constexpr int CPR  = TB / 16;                 // 16-byte chunks per row
@@ -148,6 +156,7 @@ __device__ __forceinline__ void reconstruct_generic(uint8_t *tile, int rowb, int
 // even bytes live in `lo` (x & 0x00ff00ff), odd bytes in `hi` ((x >> 8) & 0x00ff00ff); sums of two
 // bytes cannot carry across the 16-bit lanes, signed differences use the packed-i16 VALU ops.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ uint32_t paeth_pk(uint32_t a, uint32_t b, uint32_t c)
 {
     const s16x2 va = __builtin_bit_cast(s16x2, a), vb = __builtin_bit_cast(s16x2, b), vc = __builtin_bit_cast(s16x2, c);
@@ -155,20 +164,20 @@ __device__ __forceinline__ uint32_t paeth_pk(uint32_t a, uint32_t b, uint32_t c)
     const s16x2 pa = __builtin_elementwise_max(d0, -d0), pb = __builtin_elementwise_max(d1, -d1),
                 pc = __builtin_elementwise_max(ds, -ds);
     const s16x2 fifteen = {15, 15};
-    const uint32_t nota = __builtin_bit_cast(uint32_t, (pb - pa) >> fifteen) | __builtin_bit_cast(uint32_t, (pc - pa) >> fifteen);
-    const uint32_t usec = __builtin_bit_cast(uint32_t, (pc - pb) >> fifteen);
+    // sign masks per 16-bit lane; `opaque` keeps them bit masks (v_bfi) instead of per-half compares
+    const uint32_t nota = opaque(__builtin_bit_cast(uint32_t, ((pb - pa) | (pc - pa)) >> fifteen));
+    const uint32_t usec = opaque(__builtin_bit_cast(uint32_t, (pc - pb) >> fifteen));
     const uint32_t bc = (c & usec) | (b & ~usec);
     return (bc & nota) | (a & ~nota);
 }
 
-template <int P, bool FIRST>
+template <int P, bool FIRST, bool PAETH>
 __device__ __forceinline__ void reconstruct4(uint8_t *tile, int rowb, int lane, uint32_t ft, int64_t ux0,
                                              uint32_t &o, uint32_t &bprev)
 {
     constexpr uint32_t M = 0x00ff00ffu;
     const uint32_t m_sub = ft == 1 ? M : 0u, m_up = ft == 2 ? M : 0u, m_avg = ft == 3 ? M : 0u,
                    m_pae = ft == 4 ? M : 0u;
-    const bool any_pae = __any(ft == 4);
     u32x4 *mine = (u32x4 *)(tile + (1 + lane) * rowb);
     const u32x4 *top = (const u32x4 *)tile;
     uint32_t a_lo = o & M, a_hi = (o >> 8) & M, c_lo = bprev & M, c_hi = (bprev >> 8) & M;
@@ -183,7 +192,7 @@ __device__ __forceinline__ void reconstruct4(uint8_t *tile, int rowb, int lane, 
             const uint32_t b_lo = b & M, b_hi = (b >> 8) & M;
             uint32_t p_lo = (a_lo & m_sub) | (b_lo & m_up) | (((a_lo + b_lo) >> 1) & m_avg);
             uint32_t p_hi = (a_hi & m_sub) | (b_hi & m_up) | (((a_hi + b_hi) >> 1) & m_avg);
-            if (any_pae) {
+            if (PAETH) {
                 p_lo |= paeth_pk(a_lo, b_lo, c_lo) & m_pae;
                 p_hi |= paeth_pk(a_hi, b_hi, c_hi) & m_pae;
             }
@@ -257,16 +266,21 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         }
         if (lane < C::CPR) *(u32x4 *)(tile + 16 * lane) = Rtop;
     };
-    // band j tile T needs the last row of band j-1 on units [T*P, T*P+P): produced by band j-1's
-    // tiles T and T+1.  `done` of the producing wave counts tiles over all of its bands.
+    // band j tile T needs the last row of band j-1 on units [T*P, T*P+P): lane 63 of band j-1 is 63
+    // units behind, so they come from its tiles T .. T+K.  `done` of the producing wave counts the
+    // tiles (over all of its bands) whose stores have been drained.
     auto ready = [&](uint32_t band, uint32_t T) -> bool {
         if (!band) return true;
         const uint32_t pw = (band - 1) % NW, pk = (band - 1) / NW;
-        const uint32_t need = pk * ntiles + (T + 1 < ntiles ? T + 1 : ntiles - 1) + 1;
+        const uint32_t need = pk * ntiles + (T + C::K < ntiles ? T + C::K : ntiles - 1) + 1;
         return __hip_atomic_load(&done[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
     };
     auto wait_ready = [&](uint32_t band, uint32_t T) {
-        while (!ready(band, T)) __builtin_amdgcn_s_sleep(4);
+        uint32_t spins = 0;
+        while (!ready(band, T)) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 26)) __builtin_trap();  // a protocol bug must fault, not hang the GPU
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
 
@@ -275,6 +289,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
     for (uint32_t band = wave; band < nbands; band += NW) {
         const uint32_t row = band * 64 + lane;
         const uint32_t ft = row < rows ? job.in[(uint64_t)row * job.in_stride] : 0u;
+        const bool any_pae = __any(ft == 4);            // no Paeth row in this band: skip its arithmetic
         uint32_t o[BPP], bprev[BPP];
 #pragma unroll
         for (int k = 0; k < BPP; ++k) { o[k] = 0; bprev[k] = 0; }
@@ -283,25 +298,51 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
             if (!staged) { wait_ready(band, T); issue(band, T); }
             commit();
             staged = false;
-            // prefetch the next tile of this wave while this one is reconstructed
+            // prefetch the next tile of this wave while this one is reconstructed.  If its producer
+            // (another wave) is not far enough ahead yet, fall back behind it *now*: publish what is
+            // pending and wait, so that from here on the prefetch always overlaps the arithmetic.
             uint32_t nb = band, nT = T + 1;
             if (nT == ntiles) { nb = band + NW; nT = 0; }
-            if (nb < nbands && ready(nb, nT)) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                issue(nb, nT);
-                staged = true;
+            if (nb < nbands) {
+                bool ok = ready(nb, nT);
+                // Blocking here is deadlock-free only if nothing the awaited tile depends on is a tile
+                // this wave has not published yet: (nb, nT) reaches back to tile nT + NW*K of this
+                // wave's band nb - NW.  Same band: that band is complete.  Next band (we are in the
+                // last tile of the current one): only when the chain stops short of this tile.
+                const bool may_block = NW > 1 && nb && (nb == band || (uint32_t)(NW * C::K) + 1 < ntiles);
+                if (!ok && may_block) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0 && count)
+                        __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    wait_ready(nb, nT);
+                    ok = true;
+                }
+                if (ok) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    issue(nb, nT);
+                    staged = true;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS tile written before it is read
 
             const int64_t ux0 = (int64_t)T * C::P - lane;
+#ifndef SPNG_UNF_NOCOMPUTE        // tuning builds only: measure the memory pipeline alone
             if constexpr (BPP == 4) {
-                if (T == 0) reconstruct4<C::P, true>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
-                else        reconstruct4<C::P, false>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
+                if (T == 0)       reconstruct4<C::P, true, true>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
+                else if (any_pae) reconstruct4<C::P, false, true>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
+                else              reconstruct4<C::P, false, false>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
             } else {
                 reconstruct_generic<BPP, C::P>(tile, C::ROWB, lane, ft, ux0, o, bprev);
             }
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
+            // The stores of the previous tile (and the prefetch loads) have had the whole
+            // reconstruction to complete: drain, then publish the previous tile.  Publishing one
+            // tile late keeps the store latency off the critical path.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && count)
+                __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             // write back the 64 row windows
 #pragma unroll
             for (int m = 0; m < C::CPR; ++m) {
@@ -312,12 +353,18 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
                                  ((int64_t)T * C::P - r) * BPP + 16 * cj, pitch,
                                  *(const u32x4 *)(tile + (1 + r) * C::ROWB + 16 * cj));
             }
-            // publish: stores drained (they are in the XCD's L2 once acknowledged), then the counter
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ++count;
-            if (lane == 0) __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // a tile that could not be prefetched depends on this one (or a later one): publish now
+            if (!staged) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
+    // last tile of this wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, spng_result *d_results,
