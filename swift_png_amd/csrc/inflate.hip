@@ -9,22 +9,28 @@
 //   Adler-32           Sources/LZ77/Wrappers/LZ77.MRC32.swift:26-50
 // with the same accept/reject behaviour and error vocabulary (status codes in spng_mi355.h).
 //
-// Design (v1).  A DEFLATE stream is one serial dependency chain (bit position of token k+1
-// depends on token k), so the unit of parallelism is the stream: one 64-lane wave per stream, 4
-// waves per CU -> 1024 streams in flight on the chip.  Inside a wave:
-//   * the symbol decode is wave-uniform (every lane computes the same scalar state; the compiler
-//     keeps most of it on the scalar unit) with LDS-resident tables: a 2^9-entry lit/len LUT and a
-//     2^8-entry distance LUT whose 32-bit entries already carry base value + extra-bit count, and
-//     a canonical first-code/count fallback for the rare longer codes.  Tables are rebuilt
-//     cooperatively (ballot/popcount ranking, lanes fill LUT replicas in parallel) per block --
-//     swift-png's own encoder emits a dynamic block every <= 2047 tokens, so this is hot;
-//   * compressed input is staged through a 2 KiB LDS ring with coalesced 16 B/lane loads;
-//   * output goes to a 32 KiB LDS ring (the whole DEFLATE window), so LZ77 back-references are
-//     LDS->LDS copies done by all 64 lanes (overlapping runs replicate via i mod distance), and
-//     is flushed to HBM in aligned 4 KiB pieces with 16 B/lane coalesced stores; only the few
-//     references that reach beyond 32 KiB - run go through HBM (already flushed);
-//   * Adler-32 is folded into the flush (udot4 weighted sums + wave reduction), so the inflated
-//     bytes are never re-read.
+// Design.  A DEFLATE stream is one serial dependency chain (the bit position of token k+1 depends
+// on token k), so the unit of parallelism is the stream: one 64-lane wave per stream, 4 waves per
+// CU -> 1024 streams in flight on the chip.  Inside the wave the chain is attacked two ways:
+//   * speculative literal runs: every lane looks up the lit/len LUT (LDS) at bit offset
+//     position + lane, all 64 offsets at once; the true chain of symbol boundaries through those
+//     64 bits is then resolved on the scalar unit (v_readlane hop per symbol, ~10 cycles instead
+//     of an LDS round trip per symbol), the lanes on the chain form a ballot-style mask, and each
+//     of them stores its literal at (output position + popcount(mask below me)).  One LDS latency
+//     therefore buys every literal that fits in 64 bits (6-8 for PNG residuals);
+//   * the token on which a run stops (match, end of block, long code) is decoded wave-uniformly
+//     from the same LUT entry; its LZ77 copy is done by all 64 lanes as a second, parallel pass
+//     (overlapping runs replicate via i mod distance).
+// Tables are LDS resident: a 2^9-entry lit/len LUT and a 2^8-entry distance LUT whose 32-bit
+// entries already carry base value + extra-bit count, and a canonical first-code/count fallback
+// for the rare longer codes.  They are rebuilt cooperatively per block (ballot/popcount ranking,
+// lanes fill LUT replicas in parallel) -- swift-png's own encoder emits a dynamic block every
+// <= 2047 tokens, so this is hot.  Compressed input is staged through a 2 KiB LDS ring with
+// coalesced 16 B/lane loads and read through a 6-dword register window; output goes to a 32 KiB
+// LDS ring (the whole DEFLATE window), so back-references are LDS->LDS copies, and is flushed to
+// HBM in aligned 4 KiB pieces with 16 B/lane coalesced stores; only references that reach beyond
+// 32 KiB - run go through HBM (already flushed).  Adler-32 is folded into the flush (v_sad_u8 /
+// v_dot4 weighted sums + wave reduction), so the inflated bytes are never re-read.
 #include "common.hpp"
 
 namespace spng {
@@ -33,9 +39,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) U128u { u32x4 v; };
 
 static constexpr int RING = 32768;           // output window in LDS (power of two)
-static constexpr int INR = 2048;             // input ring (two 1 KiB halves)
+static constexpr int INR = 1024;             // input ring (two 512-byte halves)
+static constexpr int HALF = INR / 2;
 static constexpr int FLUSH = 4096;           // flush granularity
-static constexpr int LBITS = 9, DBITS = 8, MBITS = 7;
+static constexpr int WINOUT = 1024;          // most bytes one speculative window may produce
+// Literals of a window are stored before its back-references are resolved, up to WINOUT bytes
+// ahead of a reference; a source is still intact in the ring if it is not further back than this.
+static constexpr uint32_t LDS_REACH = RING - WINOUT - 258 - 16;
+static constexpr int LBITS = 10, DBITS = 8, MBITS = 7;
+
+// Wave-uniform values loaded through the vector path (LDS) are pinned to scalar registers so that
+// the whole bit reader and the symbol-boundary chain run on the scalar unit.
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)UNI(v >> 32) << 32 | UNI((uint32_t)v); }
 
 // LUT entry: [3:0] code length (0 = longer than the LUT index), [7:4] extra bits,
 // [9:8] kind, [31:16] literal / base run / base distance.
@@ -74,14 +90,14 @@ struct Tree {                    // canonical description for codes longer than 
     uint16_t first[16], count[16], offset[16];
 };
 
-struct Lds {
+struct Lds {                       // 40,208 bytes: four streams per CU
     uint8_t  ring[RING];
     uint8_t  in[INR];
-    uint32_t lit[1 << LBITS];
+    uint32_t lit[1 << LBITS];      // the code-length-code LUT (2^MBITS entries) lives here while a
+                                   // dynamic header is parsed, i.e. before this table is built
     uint32_t dist[1 << DBITS];
-    uint32_t sorted_lit[288];
-    uint32_t sorted_dist[32];
-    uint32_t meta[1 << MBITS];
+    uint16_t sorted_lit[288];      // symbols in canonical order, for codes longer than the LUT index
+    uint16_t sorted_dist[32];
     uint8_t  lens[464];            // 286 + 32 code lengths + worst-case RLE overshoot (138)
     Tree     tlit, tdist;
 };
@@ -98,7 +114,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // `normalizing` restates validate(symbols:normalizing:) (:112-135): 0 or 1 used symbol of length 1
 // gives a stub whose unused half the reference leaves uninitialised (K_UNDEF here).
 template <int KIND>
-__device__ bool build(const uint8_t *lens, int n, uint32_t *lut, int lbits, uint32_t *sorted, Tree *tree,
+__device__ bool build(const uint8_t *lens, int n, uint32_t *lut, int lbits, uint16_t *sorted, Tree *tree,
                       bool normalizing, int lane)
 {
     uint32_t cnt[16];
@@ -164,7 +180,7 @@ __device__ bool build(const uint8_t *lens, int n, uint32_t *lut, int lbits, uint
         }
         if (my) {
             const uint32_t e = KIND == 0 ? litlen_entry(s, my) : KIND == 1 ? dist_entry(s, my) : meta_entry(s, my);
-            sorted[o + rank] = e;
+            sorted[o + rank] = (uint16_t)s;
             if ((int)my <= lbits) {
                 const uint32_t rev = __brev(f + rank) >> (32 - my);
                 for (int j = rev; j < size; j += 1 << my) lut[j] = e;
@@ -175,67 +191,93 @@ __device__ bool build(const uint8_t *lens, int n, uint32_t *lut, int lbits, uint
     return true;
 }
 
+// Bit reader: a window of six consecutive stream dwords held in (wave-uniform) registers.
 struct Reader {
-    uint64_t buf;        // unread bits, LSB first
-    uint32_t cnt;        // number of valid bits in buf
-    uint64_t next;       // byte offset of the next dword to fetch (multiple of 4)
-    uint32_t ahead;      // dword at `next`, already fetched from the LDS ring
+    uint32_t w0, w1, w2, w3, n0;         // dwords wd .. wd+4, pinned to scalar registers
+    uint32_t n1;                         // dword wd+5 as it came back from LDS (pinned one shift later,
+                                         // so that its latency never sits on the critical path)
+    uint64_t wd;                         // dword index of w0
+    uint32_t bit;                        // position inside w0, 0..31
 };
 
-// stage 1 KiB of the stream starting at `from` (multiple of 1024) into the input ring; bytes past
-// the end read as zero (the reference pads 48 zero bits, LZ77.InflatorIn.swift:130-133)
+// stage HALF bytes of the stream starting at `from` (multiple of HALF) into the input ring; bytes
+// past the end read as zero (the reference pads 48 zero bits, LZ77.InflatorIn.swift:130-133)
 __device__ void stage(Lds &s, const uint8_t *src, uint64_t n, uint64_t from, int lane)
 {
-    const uint64_t off = from + (uint64_t)lane * 16;
-    u32x4 v = {0, 0, 0, 0};
-    if (off + 16 <= n) v = ((const U128u *)(src + off))->v;
-    else if (off < n) {
-        uint32_t w[4] = {0, 0, 0, 0};
-        for (int k = 0; k < 16; ++k) if (off + k < n) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
-        v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+    if (lane < HALF / 16) {
+        const uint64_t off = from + (uint64_t)lane * 16;
+        u32x4 v = {0, 0, 0, 0};
+        if (off + 16 <= n) v = ((const U128u *)(src + off))->v;
+        else if (off < n) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; ++k) if (off + k < n) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
+            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        }
+        *(u32x4 *)(s.in + ((from + lane * 16) & (INR - 1))) = v;
     }
-    *(u32x4 *)(s.in + ((from + lane * 16) & (INR - 1))) = v;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+}
+__device__ __forceinline__ uint32_t dword_at(const Lds &s, uint64_t d)
+{
+    return *(const uint32_t *)(s.in + ((d * 4) & (INR - 1)));
 }
 
 __device__ __forceinline__ void seek(Lds &s, Reader &r, const uint8_t *src, uint64_t n, uint64_t byte, int lane)
 {
-    const uint64_t a = byte & ~(uint64_t)3;
-    stage(s, src, n, a & ~(uint64_t)1023, lane);
-    stage(s, src, n, (a & ~(uint64_t)1023) + 1024, lane);
-    const uint32_t w = *(const uint32_t *)(s.in + (a & (INR - 1)));
-    const uint32_t sh = 8 * (uint32_t)(byte & 3);
-    r.buf = w >> sh; r.cnt = 32 - sh; r.next = a + 4;
-    if ((r.next & 1023) == 0) stage(s, src, n, r.next + 1024, lane);
-    r.ahead = *(const uint32_t *)(s.in + (r.next & (INR - 1)));
+    const uint64_t h = byte & ~(uint64_t)(HALF - 1);
+    stage(s, src, n, h, lane);
+    stage(s, src, n, h + HALF, lane);
+    r.wd = uni64(byte >> 2); r.bit = UNI(8 * (uint32_t)(byte & 3));
+    r.w0 = UNI(dword_at(s, r.wd));     r.w1 = UNI(dword_at(s, r.wd + 1)); r.w2 = UNI(dword_at(s, r.wd + 2));
+    r.w3 = UNI(dword_at(s, r.wd + 3)); r.n0 = UNI(dword_at(s, r.wd + 4)); r.n1 = dword_at(s, r.wd + 5);
 }
-
-// after this, cnt >= 33
-__device__ __forceinline__ void refill(Lds &s, Reader &r, const uint8_t *src, uint64_t n, int lane)
+__device__ __forceinline__ void shift(Lds &s, Reader &r, const uint8_t *src, uint64_t n, int lane)
 {
-    if (r.cnt <= 32) {
-        r.buf |= (uint64_t)r.ahead << r.cnt;
-        r.cnt += 32;
-        r.next += 4;
-        if ((r.next & 1023) == 0) stage(s, src, n, r.next + 1024, lane);
-        r.ahead = *(const uint32_t *)(s.in + (r.next & (INR - 1)));
-    }
+    r.w0 = r.w1; r.w1 = r.w2; r.w2 = r.w3; r.w3 = r.n0; r.n0 = UNI(r.n1);
+    r.wd = uni64(r.wd + 1);
+    const uint64_t d = r.wd + 5;
+    if (((d * 4) & (HALF - 1)) == 0) stage(s, src, n, d * 4, lane);
+    r.n1 = dword_at(s, d);
 }
-__device__ __forceinline__ uint32_t take(Reader &r, uint32_t k)
+__device__ __forceinline__ void advance(Lds &s, Reader &r, const uint8_t *src, uint64_t n, int lane, uint32_t k)
 {
-    const uint32_t v = (uint32_t)r.buf & ((1u << k) - 1);
-    r.buf >>= k; r.cnt -= k;
+    r.bit = UNI(r.bit + k);
+    while (r.bit >= 32) { shift(s, r, src, n, lane); r.bit = UNI(r.bit - 32); }
+}
+__device__ __forceinline__ uint32_t peek32(const Reader &r) { return __builtin_amdgcn_alignbit(r.w1, r.w0, r.bit); }
+__device__ __forceinline__ uint64_t peek64(const Reader &r)
+{
+    return (uint64_t)__builtin_amdgcn_alignbit(r.w2, r.w1, r.bit) << 32 | __builtin_amdgcn_alignbit(r.w1, r.w0, r.bit);
+}
+// 32 stream bits starting `rel` bits after the current position (bit + rel <= 127)
+__device__ __forceinline__ uint32_t peek32_at(const Reader &r, uint32_t rel)
+{
+    const uint32_t a = r.w0, b = r.w1, c = r.w2, d = r.w3, e = r.n0;   // by value: stays in registers
+    const uint32_t off = r.bit + rel, sel = off >> 5;
+    const uint32_t lo = sel == 0 ? a : (sel == 1 ? b : (sel == 2 ? c : d));
+    const uint32_t hi = sel == 0 ? b : (sel == 1 ? c : (sel == 2 ? d : e));
+    return __builtin_amdgcn_alignbit(hi, lo, off & 31);
+}
+#define TAKE(k) take(s, r, src, n, lane, (k))
+__device__ __forceinline__ uint32_t take(Lds &s, Reader &r, const uint8_t *src, uint64_t n, int lane, uint32_t k)
+{
+    const uint32_t v = peek32(r) & ((1u << k) - 1);          // k <= 16
+    advance(s, r, src, n, lane, k);
     return v;
 }
-__device__ __forceinline__ uint64_t bitpos(const Reader &r) { return r.next * 8 - r.cnt; }
+__device__ __forceinline__ uint64_t bitpos(const Reader &r) { return r.wd * 32 + r.bit; }
 
-// canonical decode of a code longer than the LUT index (uniform)
-__device__ __forceinline__ uint32_t decode_long(const Reader &r, const Tree &t, const uint32_t *sorted, int lbits)
+// canonical decode of a code longer than the LUT index (uniform); `bits` = next >= 15 stream bits
+template <int KIND>
+__device__ __forceinline__ uint32_t decode_long(uint32_t bits, const Tree &t, const uint16_t *sorted, int lbits)
 {
-    const uint32_t v = __brev((uint32_t)r.buf) >> 17;          // next 15 bits, MSB first
+    const uint32_t v = __brev(bits) >> 17;                     // next 15 bits, MSB first
     for (int l = lbits + 1; l < 16; ++l) {
-        const uint32_t d = (v >> (15 - l)) - t.first[l];
-        if (d < t.count[l]) return sorted[t.offset[l] + d];
+        const uint32_t d = (v >> (15 - l)) - UNI(t.first[l]);
+        if (d < UNI(t.count[l])) {
+            const uint32_t sym = UNI(sorted[UNI(t.offset[l]) + d]);
+            return KIND == 0 ? litlen_entry(sym, l) : dist_entry(sym, l);
+        }
     }
     return entry(15, 0, K_UNDEF, 0);                           // unreachable for complete codes
 }
@@ -243,17 +285,23 @@ __device__ __forceinline__ uint32_t decode_long(const Reader &r, const Tree &t, 
 struct Out {
     uint8_t *dst; uint64_t cap;
     uint64_t pos, flushed;
-    uint32_t s1, s2;                                           // Adler-32 state (MRC32.swift:14-24)
+    // Adler-32 (MRC32.swift:26-50) in a form that needs no cross-lane traffic until the very end:
+    // with S = sum b_i and I = sum i*b_i over the whole stream of N bytes,
+    //     s1 = 1 + S,   s2 = N + N*S - I      (mod 65521)
+    // so every lane just accumulates its share of S and I (mod 65521) while flushing.
+    uint32_t accS, accI;
+    uint32_t base;                                             // flushed mod 65521 (uniform)
 };
 
-// flush ring bytes [flushed, upto) to HBM and fold them into the Adler-32 state
-__device__ void flush(Lds &s, Out &o, uint64_t upto, int lane)
+#define LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+
+// flush ring bytes [flushed, upto) to HBM and fold them into the lane's Adler-32 accumulators
+__device__ __attribute__((always_inline)) void flush(Lds &s, Out &o, uint64_t upto, int lane)
 {
-    __syncthreads();
+    LDS_ORDER();
     while (o.flushed < upto) {
         const uint64_t rem = upto - o.flushed;
         const uint32_t n = rem > FLUSH ? FLUSH : (uint32_t)rem;
-        uint32_t l1 = 0, l2 = 0;
         for (uint32_t off = lane * 16; off < n; off += 1024) {
             const u32x4 v = *(const u32x4 *)(s.ring + ((o.flushed + off) & (RING - 1)));
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -264,28 +312,71 @@ __device__ void flush(Lds &s, Out &o, uint64_t upto, int lane)
                 for (uint32_t k = 0; k < valid; ++k) o.dst[o.flushed + off + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
                 for (uint32_t k = valid; k < 16; ++k) w[k >> 2] &= ~(0xffu << (8 * (k & 3)));
             }
-            // A = sum b_j, B = sum (16 - j) b_j over the 16-byte piece
-            uint32_t A = 0, B = 0;
+            // A = sum b_j, J = sum j*b_j over the 16-byte piece at stream offset g = flushed + off
+            uint32_t A = 0, J = 0;
             A = __builtin_amdgcn_sad_u8(w[0], 0, A); A = __builtin_amdgcn_sad_u8(w[1], 0, A);
             A = __builtin_amdgcn_sad_u8(w[2], 0, A); A = __builtin_amdgcn_sad_u8(w[3], 0, A);
-            B = __builtin_amdgcn_udot4(w[0], 0x0d0e0f10u, B, false);
-            B = __builtin_amdgcn_udot4(w[1], 0x090a0b0cu, B, false);
-            B = __builtin_amdgcn_udot4(w[2], 0x05060708u, B, false);
-            B = __builtin_amdgcn_udot4(w[3], 0x01020304u, B, false);
-            l1 += A;
-            l2 += (n - off - 16 + 0u) * A + B;                 // bytes of this flush after the piece: n-off-16
+            J = __builtin_amdgcn_udot4(w[0], 0x03020100u, J, false);
+            J = __builtin_amdgcn_udot4(w[1], 0x07060504u, J, false);
+            J = __builtin_amdgcn_udot4(w[2], 0x0b0a0908u, J, false);
+            J = __builtin_amdgcn_udot4(w[3], 0x0f0e0d0cu, J, false);
+            uint32_t g = o.base + off;                         // < 65521 + 4096
+            g = g >= 65521 ? g - 65521 : g;
+            o.accS += A;                                       // <= 4080 per piece
+            o.accI = (o.accI + g * A + J) % 65521;             // 65520*4080 + 30600 + 65520 < 2^32
         }
-        // (a final piece shorter than 16 bytes is handled by the zeroed bytes: its weight
-        //  n-off-16 is negative mod 2^32 and cancels against B's 16-j weights exactly)
-        l2 %= 65521;
-        const uint32_t t1 = wave_sum(l1), t2 = wave_sum(l2);
-        o.s2 = (o.s2 + (n % 65521) * o.s1 % 65521 + t2) % 65521;
-        o.s1 = (o.s1 + t1) % 65521;
-        o.flushed += n;
+        o.accS %= 65521;
+        o.flushed = uni64(o.flushed + n);
+        o.base = UNI((o.base + n) % 65521);
     }
-    __syncthreads();
+    LDS_ORDER();
 }
 
+// cooperative LZ77 copy of `count` (<= 258) bytes from `offset` back (InflatorOut.expand,
+// InflatorOut.swift:124-139: forward byte copy, an overlapping run replicates).  All loads are
+// issued before the first store; sources are always below `pos`, so they never alias the stores.
+__device__ __forceinline__ void copy_match(Lds &s, const Out &o, uint64_t pos, uint32_t count, uint32_t offset, int lane)
+{
+    if (count <= 64 && offset >= count && offset <= LDS_REACH) {      // the common case: one pass, no overlap
+        if ((uint32_t)lane < count)
+            s.ring[(pos + lane) & (RING - 1)] = s.ring[(pos - offset + lane) & (RING - 1)];
+        return;
+    }
+    uint32_t v[5];
+    if (offset <= LDS_REACH) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t i = lane + 64 * j;
+            if (i < count) {
+                const uint32_t k = offset >= count ? i : i % offset;
+                v[j] = s.ring[(pos - offset + k) & (RING - 1)];
+            }
+        }
+    } else {
+        // the source may already be overwritten in the ring; it was flushed to HBM long ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const uint32_t i = lane + 64 * j;
+            if (i < count) v[j] = o.dst[pos - offset + i];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const uint32_t i = lane + 64 * j;
+        if (i < count) s.ring[(pos + i) & (RING - 1)] = (uint8_t)v[j];
+    }
+}
+
+#ifdef SPNG_INFLATE_PROF
+#define PROF_DECL uint64_t pt[8] = {0,0,0,0,0,0,0,0}, pc[8] = {0,0,0,0,0,0,0,0}, p_t0 = 0;
+#define PROF_BEGIN() p_t0 = __builtin_readcyclecounter()
+#define PROF_END(k) do { pt[k] += __builtin_readcyclecounter() - p_t0; pc[k] += 1; } while (0)
+#else
+#define PROF_DECL
+#define PROF_BEGIN()
+#define PROF_END(k)
+#endif
 #define FAIL(code, a0, a1) do { status = (code); aux0 = (a0); aux1 = (a1); goto done; } while (0)
 
 __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restrict__ jobs,
@@ -296,39 +387,39 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
     const int lane = threadIdx.x;
     const uint8_t *src = job.src;
     const uint64_t n = job.src_len, total = n * 8;
+    const unsigned long long below = (1ull << lane) - 1;
 
     int32_t status = SPNG_NEED_MORE_INPUT;
     uint64_t aux0 = 0, aux1 = 0;
-    Out o = { job.dst, job.dst_cap, 0, 0, 1, 0 };
+    PROF_DECL
+    Out o = { job.dst, job.dst_cap, 0, 0, 0, 0, 0 };
     Reader r;
     seek(s, r, src, n, 0, lane);
 
     // .initial (InflatorBuffers.swift:92-104, StreamHeader.swift:16-54)
     if (job.format != SPNG_FORMAT_IOS) {
         if (16 > total) goto done;
-        const uint32_t cm = take(r, 4);
+        const uint32_t cm = TAKE(4);
         if (cm != 8) FAIL(SPNG_E_COMPRESSION_METHOD, cm, 0);
-        const uint32_t e = take(r, 4);
+        const uint32_t e = TAKE(4);
         if (e >= 8) FAIL(SPNG_E_WINDOW_SIZE, e + 8, 0);
-        const uint32_t flags = take(r, 8);
+        const uint32_t flags = TAKE(8);
         if (((e << 12 | 8 << 8) + flags) % 31 != 0) FAIL(SPNG_E_CHECK_BITS, 0, 0);
         if (flags & 0x20) FAIL(SPNG_E_DICTIONARY, 0, 0);
     }
 
     for (;;) {
         // .metadata: readBlockMetadata (InflatorBuffers.Stream.swift:59-141)
-        refill(s, r, src, n, lane);
+        PROF_BEGIN();
         if (bitpos(r) + 3 > total) goto done;
-        const uint32_t bfinal = take(r, 1);
-        const uint32_t type = take(r, 2);
+        const uint32_t bfinal = TAKE(1);
+        const uint32_t type = TAKE(2);
         if (type == 0) {
             const uint64_t boundary = (bitpos(r) + 7) & ~(uint64_t)7;
             if (boundary + 32 > total) goto done;
-            take(r, (uint32_t)(boundary - bitpos(r)));
-            refill(s, r, src, n, lane);
-            const uint32_t l = take(r, 16);
-            refill(s, r, src, n, lane);
-            const uint32_t m = take(r, 16);
+            TAKE((uint32_t)(boundary - bitpos(r)));
+            const uint32_t l = TAKE(16);
+            const uint32_t m = TAKE(16);
             if (l != (~m & 0xffffu)) FAIL(SPNG_E_BLOCK_COUNT_PARITY, l, m);
             // readBlock(upTo:) (:384-399): copies as many of the LEN bytes as the input holds
             const uint64_t from = boundary / 8 + 4;
@@ -337,11 +428,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
             for (uint64_t done_ = 0; done_ < have;) {
                 const uint64_t piece = have - done_ < 1024 ? have - done_ : 1024;
                 for (uint64_t i = lane; i < piece; i += 64) s.ring[(o.pos + i) & (RING - 1)] = src[from + done_ + i];
-                __syncthreads();
-                o.pos += piece; done_ += piece;
+                LDS_ORDER();
+                o.pos = uni64(o.pos + piece); done_ += piece;
                 if (o.pos - o.flushed >= FLUSH) flush(s, o, o.pos & ~(uint64_t)15, lane);
             }
-            if (have < l) { r.next = (n + 3) & ~(uint64_t)3; r.cnt = 0; r.buf = 0; goto done; }
+            if (have < l) { r.wd = (n + 3) >> 2; r.bit = 0; goto done; }
             seek(s, r, src, n, from + l, lane);
         } else if (type == 1 || type == 2) {
             if (type == 1) {
@@ -354,36 +445,33 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
                 build<1>(s.lens, 32, s.dist, DBITS, s.sorted_dist, &s.tdist, false, lane);
             } else {
                 if (bitpos(r) - 3 + 17 > total) goto done;
-                const uint32_t literals = 257 + take(r, 5);
-                const uint32_t distances = 1 + take(r, 5);
-                const uint32_t codelengths = 4 + take(r, 4);
+                const uint32_t literals = 257 + TAKE(5);
+                const uint32_t distances = 1 + TAKE(5);
+                const uint32_t codelengths = 4 + TAKE(4);
                 if (bitpos(r) + 3 * (uint64_t)codelengths > total) goto done;
                 if (literals > 286) FAIL(SPNG_E_RUNLITERAL_COUNT, literals, 0);
                 // 19 code-length-code lengths in zig-zag order (:120-125)
                 uint64_t packed = 0;                           // 19 x 3 bits = 57 bits
-                for (uint32_t i = 0; i < codelengths; ++i) {
-                    refill(s, r, src, n, lane);
-                    packed |= (uint64_t)take(r, 3) << (3 * i);
-                }
+                for (uint32_t i = 0; i < codelengths; ++i) packed |= (uint64_t)TAKE(3) << (3 * i);
                 if (lane < 19) {
                     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
                     s.lens[order[lane]] = (uint32_t)lane < codelengths ? (uint8_t)((packed >> (3 * lane)) & 7) : 0;
                 }
                 __syncthreads();
-                if (!build<2>(s.lens, 19, s.meta, MBITS, s.sorted_lit, &s.tlit, false, lane))
+                if (!build<2>(s.lens, 19, s.lit, MBITS, s.sorted_lit, &s.tlit, false, lane))
                     FAIL(SPNG_E_CODELENGTH_TABLE, 0, 0);
 
                 // .tables: readBlockTables (:144-263), sequential RLE decode of the code lengths
                 const uint32_t want = literals + distances;
                 uint32_t have = 0, last = 0;
                 while (have < want) {
-                    refill(s, r, src, n, lane);
                     if (bitpos(r) >= total) goto done;
-                    const uint32_t e = s.meta[(uint32_t)r.buf & ((1 << MBITS) - 1)];
+                    const uint32_t bits = peek32(r);
+                    const uint32_t e = UNI(s.lit[bits & ((1 << MBITS) - 1)]);
                     const uint32_t len = e & 15, sym = e >> 16;
                     if (bitpos(r) + len > total) goto done;
                     if (sym < 16) {
-                        take(r, len);
+                        advance(s, r, src, n, lane, len);
                         if (lane == 0) s.lens[have] = (uint8_t)sym;
                         last = sym; have += 1;
                         continue;
@@ -395,71 +483,146 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
                     } else if (sym == 17) { element = 0; extra = 3; base = 3; }
                     else                  { element = 0; extra = 7; base = 11; }
                     if (bitpos(r) + len + extra > total) goto done;
-                    take(r, len);
-                    const uint32_t reps = base + take(r, extra);
+                    const uint32_t reps = base + ((bits >> len) & ((1u << extra) - 1));
+                    advance(s, r, src, n, lane, len + extra);
                     for (uint32_t i = lane; i < reps; i += 64) s.lens[have + i] = (uint8_t)element;
                     last = element; have += reps;
                 }
                 __syncthreads();
                 if (have != want) FAIL(SPNG_E_CODELENGTH_SEQUENCE, 0, 0);
-                                const bool okd = build<1>(s.lens + literals, (int)distances, s.dist, DBITS, s.sorted_dist,
+                const bool okd = build<1>(s.lens + literals, (int)distances, s.dist, DBITS, s.sorted_dist,
                                           &s.tdist, true, lane);
                 const bool okl = build<0>(s.lens, (int)literals, s.lit, LBITS, s.sorted_lit, &s.tlit,
                                           false, lane);
                 if (!okl || !okd) FAIL(SPNG_E_HUFFMAN_TABLE, 0, 0);
             }
 
+            PROF_END(6);
             // .compressed: readBlock(with:) (:266-381)
             for (;;) {
-                refill(s, r, src, n, lane);
                 const uint64_t b0 = bitpos(r);
                 if (b0 >= total) goto done;
-                uint32_t e = s.lit[(uint32_t)r.buf & ((1 << LBITS) - 1)];
-                if ((e & 15) == 0) e = decode_long(r, s.tlit, s.sorted_lit, LBITS);
+                // ---- speculative window: lane i decodes the whole token that would start at bit
+                //      b0 + i (lit/len LUT, extra bits, distance LUT, extra bits)
+                PROF_BEGIN();
+                const uint32_t lo = peek32_at(r, (uint32_t)lane), hi = peek32_at(r, (uint32_t)lane + 32);
+                uint32_t e = s.lit[lo & ((1 << LBITS) - 1)];
+                const uint32_t len1 = e & 15, kind1 = (e >> 8) & 3, cx = (e >> 4) & 15;
+                const uint32_t run = (e >> 16) + ((lo >> len1) & ((1u << cx) - 1));
+                const uint32_t p2 = len1 + cx;                                   // <= 14
+                const uint32_t dbits = (uint32_t)(((uint64_t)hi << 32 | lo) >> p2);
+                const uint32_t d = s.dist[dbits & ((1 << DBITS) - 1)];
+                const uint32_t dl = d & 15, ox = (d >> 4) & 15;
+                const uint32_t dist = (d >> 16) + ((dbits >> dl) & ((1u << ox) - 1));
+                const bool is_lit = kind1 == K_LIT && len1 != 0;
+                // anything unusual (long codes, undefined codes, zero runs/offsets, end of block,
+                // tokens running past the input) ends the chain and is decoded the slow way
+                const bool is_match = kind1 == K_MATCH && len1 != 0 && dl != 0 && ((d >> 8) & 3) == K_MATCH &&
+                                      run != 0 && dist != 0;
+                const uint32_t tlen = is_lit ? len1 : p2 + dl + ox;              // <= 48
+                const bool ok = (is_lit || is_match) && b0 + lane + tlen <= total;
+                const uint32_t step = ok ? tlen : 0;
+                const uint32_t outlen = is_lit ? 1u : run;
+
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                PROF_END(0); PROF_BEGIN();
+                // ---- resolve the true chain of token boundaries through the window (scalar unit)
+                uint32_t p = 0, acc = 0, offs = 0;
+                unsigned long long chain = 0;
+                const uint64_t room = o.cap - o.pos;
+                const uint32_t maxout = UNI(room < WINOUT ? (uint32_t)room : (uint32_t)WINOUT);
+                // Taken scalar branches cost far more than the arithmetic here, so the walk is
+                // unrolled and branch-free: once a hop fails `good` stays false and nothing moves.
+                bool good = true;
+#pragma unroll
+                for (int hop = 0; hop < 8; ++hop) {
+                    const uint32_t q = p < 63 ? p : 63;
+                    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)q);
+                    const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)outlen, (int)q);
+                    good = good & (p < 64) & (st != 0) & (acc + ol <= maxout);
+                    offs = ((uint32_t)lane == q) & good ? acc : offs;
+                    chain |= good ? 1ull << q : 0ull;
+                    acc += good ? ol : 0u;
+                    p += good ? st : 0u;
+                }
+                while (good && p < 64) {                       // more than eight tokens in 64 bits: rare
+                    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)p);
+                    if (!st) break;
+                    const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)outlen, (int)p);
+                    if (acc + ol > maxout) break;
+                    offs = (uint32_t)lane == p ? acc : offs;
+                    chain |= 1ull << p;
+                    acc += ol; p += st;
+                }
+                PROF_END(1);
+                if (chain) {
+                    PROF_BEGIN();
+                    const bool mine = (chain >> lane) & 1;
+                    // literals first (no token ever reads a later token's bytes) ...
+                    if (mine && is_lit) s.ring[(o.pos + offs) & (RING - 1)] = (uint8_t)(e >> 16);
+                    LDS_ORDER();
+                    // ... then the back-references, in stream order
+                    unsigned long long mm = __ballot(mine && !is_lit);
+                    while (mm) {
+                        const int l = __ffsll((long long)mm) - 1;
+                        mm &= mm - 1;
+                        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)run, l);
+                        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)dist, l);
+                        const uint64_t at = o.pos + (uint32_t)__builtin_amdgcn_readlane((int)offs, l);
+                        if (off > at) { o.pos = uni64(at); FAIL(SPNG_E_STRING_REFERENCE, 0, 0); }
+                        copy_match(s, o, at, cnt, off, lane);
+                        LDS_ORDER();
+                    }
+                    o.pos = uni64(o.pos + acc);
+                    PROF_END(2); PROF_BEGIN();
+                    advance(s, r, src, n, lane, p);
+                    PROF_END(3); PROF_BEGIN();
+                    if (o.pos - o.flushed >= FLUSH) flush(s, o, o.pos & ~(uint64_t)15, lane);
+                    PROF_END(4);
+                    if (p >= 64) continue;                     // the chain used the whole window
+                    if (bitpos(r) >= total) goto done;
+                }
+                e = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)p);   // LUT entry of the token the chain stopped on
+
+                // ---- that token, decoded wave-uniformly with every check of the reference
+                PROF_BEGIN();
+                const uint64_t b1 = bitpos(r);
+                uint64_t slug = peek64(r);
+                if ((e & 15) == 0) e = decode_long<0>((uint32_t)slug, s.tlit, s.sorted_lit, LBITS);
                 const uint32_t len = e & 15, kind = (e >> 8) & 3;
                 if (kind == K_LIT) {
-                    if (b0 + len > total) goto done;
+                    if (b1 + len > total) goto done;
                     if (o.pos >= o.cap) FAIL(SPNG_E_OUTPUT_CAPACITY, 0, 0);
-                    take(r, len);
+                    advance(s, r, src, n, lane, len);
                     if (lane == 0) s.ring[o.pos & (RING - 1)] = (uint8_t)(e >> 16);
-                    o.pos += 1;
+                    o.pos = uni64(o.pos + 1);
                 } else if (kind == K_EOB) {
-                    if (b0 + len > total) goto done;
-                    take(r, len);
+                    if (b1 + len > total) goto done;
+                    advance(s, r, src, n, lane, len);
                     break;
                 } else {
-                    Reader t = r;                              // commit only if the whole token fits
-                    take(t, len);
-                    const uint32_t cx = (e >> 4) & 15;
-                    const uint32_t count = (e >> 16) + take(t, cx);
-                    refill(s, t, src, n, lane);
-                    uint32_t d = s.dist[(uint32_t)t.buf & ((1 << DBITS) - 1)];
-                    if ((d & 15) == 0) d = decode_long(t, s.tdist, s.sorted_dist, DBITS);
-                    if (((d >> 8) & 3) == K_UNDEF) FAIL(SPNG_E_REFERENCE_UNDEFINED, 0, 0);
-                    take(t, d & 15);
-                    const uint32_t ox = (d >> 4) & 15;
-                    const uint32_t offset = (d >> 16) + take(t, ox);
-                    if (bitpos(t) > total) goto done;
+                    slug >>= len;
+                    const uint32_t ex = (e >> 4) & 15;
+                    const uint32_t count = (e >> 16) + ((uint32_t)slug & ((1u << ex) - 1));
+                    slug >>= ex;
+                    uint32_t dd = UNI(s.dist[(uint32_t)slug & ((1 << DBITS) - 1)]);
+                    if ((dd & 15) == 0) dd = decode_long<1>((uint32_t)slug, s.tdist, s.sorted_dist, DBITS);
+                    if (((dd >> 8) & 3) == K_UNDEF) FAIL(SPNG_E_REFERENCE_UNDEFINED, 0, 0);
+                    slug >>= dd & 15;
+                    const uint32_t dx = (dd >> 4) & 15;
+                    const uint32_t offset = (dd >> 16) + ((uint32_t)slug & ((1u << dx) - 1));
+                    const uint32_t bits = len + ex + (dd & 15) + dx;     // <= 48
+                    if (b1 + bits > total) goto done;
                     if (offset > o.pos) FAIL(SPNG_E_STRING_REFERENCE, 0, 0);
                     if (count && !offset) FAIL(SPNG_E_REFERENCE_UNDEFINED, 0, 0);
                     if (o.pos + count > o.cap) FAIL(SPNG_E_OUTPUT_CAPACITY, 0, 0);
-                    r = t;
-                    // InflatorOut.expand (InflatorOut.swift:124-139): forward copy, overlap replicates
-                    __syncthreads();
-                    if (offset <= RING - 258) {
-                        for (uint32_t i = lane; i < count; i += 64) {
-                            const uint32_t k = offset >= count ? i : i % offset;
-                            s.ring[(o.pos + i) & (RING - 1)] = s.ring[(o.pos - offset + k) & (RING - 1)];
-                        }
-                    } else {
-                        // source may already be overwritten in the ring; it was flushed long ago
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        for (uint32_t i = lane; i < count; i += 64)
-                            s.ring[(o.pos + i) & (RING - 1)] = o.dst[o.pos - offset + i];
-                    }
-                    __syncthreads();
-                    o.pos += count;
+                    advance(s, r, src, n, lane, bits);
+                    LDS_ORDER();
+                    copy_match(s, o, o.pos, count, offset, lane);
+                    LDS_ORDER();
+                    o.pos = uni64(o.pos + count);
                 }
+                PROF_END(5);
                 if (o.pos - o.flushed >= FLUSH) flush(s, o, o.pos & ~(uint64_t)15, lane);
             }
         } else {
@@ -470,19 +633,25 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
 
     // .checksum (InflatorBuffers.swift:112-130; Stream.swift:402-429)
     if (job.format != SPNG_FORMAT_IOS) {
-        refill(s, r, src, n, lane);
         const uint64_t boundary = (bitpos(r) + 7) & ~(uint64_t)7;
         if (boundary + 32 > total) goto done;
-        take(r, (uint32_t)(boundary - bitpos(r)));
+        TAKE((uint32_t)(boundary - bitpos(r)));
         uint32_t declared = 0;
-        for (int k = 0; k < 4; ++k) { refill(s, r, src, n, lane); declared = declared << 8 | take(r, 8); }
+        for (int k = 0; k < 4; ++k) declared = declared << 8 | TAKE(8);
         flush(s, o, o.pos, lane);
-        const uint32_t computed = o.s2 << 16 | o.s1;
+        const uint32_t S = UNI(wave_sum(o.accS % 65521)) % 65521, I = UNI(wave_sum(o.accI)) % 65521;
+        const uint32_t N = (uint32_t)(o.pos % 65521);
+        const uint32_t computed = ((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
         if (declared != computed) FAIL(SPNG_E_STREAM_CHECKSUM, declared, computed);
     }
     status = SPNG_DONE;
 done:
     flush(s, o, o.pos, lane);
+#ifdef SPNG_INFLATE_PROF
+    if (lane == 0 && blockIdx.x == 0)
+        printf("prof cycles/count: spec %llu/%llu chain %llu/%llu emit %llu/%llu advance %llu/%llu flush %llu/%llu slow %llu/%llu header %llu/%llu\n",
+               pt[0], pc[0], pt[1], pc[1], pt[2], pc[2], pt[3], pc[3], pt[4], pc[4], pt[5], pc[5], pt[6], pc[6]);
+#endif
     if (lane == 0) {
         spng_result &res = results[job.image];
         res.status = status; res.reserved = 0;
