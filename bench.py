@@ -32,13 +32,6 @@ MPIX = W * H / 1e6
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def shard(total: int, world: int, rank: int):
-    """Contiguous blocks of ceil(total/world) images per rank."""
-    per = -(-total // world)
-    lo = min(total, rank * per)
-    return lo, min(total, lo + per)
-
-
 def build_inputs(spng, session, unique: int, threads: int):
     """-> (list of original rasters as numpy, list of zlib streams).  Product path only: synthetic
     rasters -> GPU filter-select (spng_filter, the reference heuristic) -> zlib level 6."""
@@ -104,6 +97,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import swift_png_amd as spng
+    from swift_png_amd.distributed import gather_decoded, shard
     s = spng.load(local)
     cores = os.cpu_count() or 1
     images, rows, streams = build_inputs(spng, s, args.unique, min(cores, 32))
@@ -134,9 +128,7 @@ def main():
         s.decode_batch(descs, wait=False)
         if do_gather:
             # the only exchange step of the path: decoded rasters -> rank 0 over xGMI (RCCL)
-            per = -(-args.images // world)
-            send = d_out if n == per else torch.cat([d_out, d_out.new_zeros((per - n) * S)])
-            dist.gather(send, gathered, dst=0)
+            gather_decoded(d_out, S, args.images, world, rank, out=gathered)
 
     def fence():
         torch.cuda.synchronize()
