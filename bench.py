@@ -166,6 +166,15 @@ def main():
         unf_ms = prof["unfilter"][0] / max(1, prof["unfilter"][1])
         infl_bytes = total_c + n * U                 # algorithmic: read C, write U
         unf_bytes = n * (U + S)                      # algorithmic: read U, write S
+        # HBM traffic per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
+        # MI355X_MICROARCH.md prescribes; profiles/r01_pmc_traffic.json), scaled to this batch; null if absent
+        traffic = {"inflate": None, "unfilter": None}
+        try:
+            pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
+            for k in traffic:
+                traffic[k] = pmc["kernels"][k]["hbm_bytes_per_image"] * n
+        except (OSError, KeyError, ValueError):
+            pass
         dominant = "inflate" if infl_ms >= unf_ms else "unfilter"
         dom_bytes, dom_ms = (infl_bytes, infl_ms) if dominant == "inflate" else (unf_bytes, unf_ms)
         out = {
@@ -182,13 +191,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"{dominant}_kernel",
                          "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                         "traffic": None, "ms_per_launch": round(dom_ms, 3)},
+                         "traffic": traffic[dominant], "ms_per_launch": round(dom_ms, 3)},
             "kernels": {
                 "inflate": {"ms_per_launch": round(infl_ms, 3), "algorithmic_bytes": infl_bytes,
                             "gbps": round(infl_bytes / (infl_ms * 1e-3) / 1e9, 2)},
                 "unfilter": {"ms_per_launch": round(unf_ms, 3), "algorithmic_bytes": unf_bytes,
                              "gbps": round(unf_bytes / (unf_ms * 1e-3) / 1e9, 2),
-                             "frac_of_hbm_peak": round(unf_bytes / (unf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                             "frac_of_hbm_peak": round(unf_bytes / (unf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                             "traffic": traffic["unfilter"]},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
