@@ -532,18 +532,22 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
                 const uint64_t room = o.cap - o.pos;
                 const uint32_t maxout = UNI(room < WINOUT ? (uint32_t)room : (uint32_t)WINOUT);
                 // Taken scalar branches cost far more than the arithmetic here, so the walk is
-                // unrolled and branch-free: once a hop fails `good` stays false and nothing moves.
-                bool good = true;
+                // unrolled and branch-free.  A lane whose step is 0 is absorbing (p stops moving),
+                // the output budget is only checked afterwards (it almost never binds).
 #pragma unroll
                 for (int hop = 0; hop < 8; ++hop) {
                     const uint32_t q = p < 63 ? p : 63;
-                    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)q);
+                    uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)q);
                     const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)outlen, (int)q);
-                    good = good & (p < 64) & (st != 0) & (acc + ol <= maxout);
-                    offs = ((uint32_t)lane == q) & good ? acc : offs;
-                    chain |= good ? 1ull << q : 0ull;
-                    acc += good ? ol : 0u;
-                    p += good ? st : 0u;
+                    st = p < 64 ? st : 0u;
+                    offs = ((uint32_t)lane == q) & (st != 0) ? acc : offs;
+                    chain |= st ? 1ull << q : 0ull;
+                    acc += st ? ol : 0u;
+                    p += st;
+                }
+                bool good = p < 64 && __builtin_amdgcn_readlane((int)step, (int)(p < 63 ? p : 63)) != 0;
+                if (acc > maxout) {                            // out of room (or > WINOUT bytes): walk again, carefully
+                    p = 0; acc = 0; chain = 0; good = true;
                 }
                 while (good && p < 64) {                       // more than eight tokens in 64 bits: rare
                     const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)p);
