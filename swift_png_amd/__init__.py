@@ -36,6 +36,7 @@ EXPORTS = [
     "spng_storage_size", "spng_create", "spng_destroy", "spng_stream", "spng_sync", "spng_profile",
     "spng_profile_get", "spng_inflate_batch", "spng_unfilter_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
+    "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_encode_batch",
 ]
 
 
@@ -140,6 +141,11 @@ def load_library():
     lib.spng_decode.argtypes = [vp, vp, u64, i32, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, rp]
     lib.spng_adler32.argtypes = [vp, vp, u64, ctypes.POINTER(u32)]
     lib.spng_filter.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, rp]
+    lib.spng_deflate_bound.restype = u64
+    lib.spng_deflate_bound.argtypes = [u64]
+    lib.spng_deflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), ctypes.POINTER(i32), u32, vp, rp]
+    lib.spng_deflate.argtypes = [vp, vp, u64, i32, i32, vp, u64, rp]
+    lib.spng_encode_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), i32, u32, vp, rp]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -318,6 +324,30 @@ class Session:
         _check(self.lib, self.lib.spng_filter(self.ctx, src, w, h, depth, channels, int(bool(interlaced)), dst,
                                               ctypes.byref(res)))
         return bytes(dst[:u])
+
+    def deflate(self, data: bytes, level: int, fmt=FORMAT_ZLIB) -> bytes:
+        """Whole-stream LZ77.Deflator (push(all, last: true) + concatenated pull()): -> stream bytes"""
+        cap = self.lib.spng_deflate_bound(len(data))
+        src = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+        dst = (ctypes.c_uint8 * cap)()
+        res = Result()
+        _check(self.lib, self.lib.spng_deflate(self.ctx, src, len(data), fmt, level, dst, cap, ctypes.byref(res)))
+        if res.status != DONE:
+            raise SpngError(res.status)
+        return bytes(dst[:res.written])
+
+    def deflate_batch(self, streams, level, fmt=FORMAT_ZLIB):
+        """streams: list of uint8 device tensors -> (list of output tensors, list[Result])"""
+        n = len(streams)
+        caps = [self.lib.spng_deflate_bound(t.numel()) for t in streams]
+        outs = [self.empty(c) for c in caps]
+        descs = (StreamDesc * n)()
+        for i, (t, o, c) in enumerate(zip(streams, outs, caps)):
+            descs[i] = StreamDesc(self._ptr(t), t.numel(), self._ptr(o), int(c), fmt, 0)
+        levels = (ctypes.c_int32 * n)(*([level] * n))
+        res = (Result * n)()
+        _check(self.lib, self.lib.spng_deflate_batch(self.ctx, descs, levels, n, None, res))
+        return outs, list(res)
 
     def adler32(self, data: bytes) -> int:
         src = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")

@@ -62,6 +62,7 @@ struct spng_ctx {
     // device + pinned workspaces for job tables
     void *d_ws = nullptr;  size_t d_ws_cap = 0;
     void *h_ws = nullptr;  size_t h_ws_cap = 0;
+    void *d_ring = nullptr; size_t ring_cap = 0;     // deflate link rings
     // profiling
     bool profiling = false;
     struct Span { int kernel; hipEvent_t a, b; };
@@ -190,6 +191,7 @@ void spng_destroy(spng_ctx *c)
     for (auto e : c->pool) hipEventDestroy(e);
     if (c->d_ws) hipFree(c->d_ws);
     if (c->h_ws) hipHostFree(c->h_ws);
+    if (c->d_ring) hipFree(c->d_ring);
     if (c->owns_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -647,6 +649,88 @@ int32_t spng_filter(spng_ctx *c, const void *storage,
     if (int32_t st = spng_filter_batch(c, &d, 1, nullptr, result)) return st;
     HIP_TRY(hipMemcpy(rows, dr.p, u, hipMemcpyDeviceToHost));
     return SPNG_DONE;
+}
+
+
+uint64_t spng_deflate_bound(uint64_t n) { return n + n / 4 + 4096; }
+
+// shared by spng_deflate_batch / spng_encode_batch: per-stream link rings live in a context-owned slab
+static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_result *dr, Arena &a, size_t jslot)
+{
+    const size_t ring_bytes = (size_t)jobs.size() * 65536 * 4;
+    if (ring_bytes > c->ring_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_ring) HIP_TRY(hipFree(c->d_ring));
+        c->d_ring = nullptr; c->ring_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_ring, ring_bytes));
+        c->ring_cap = ring_bytes;
+    }
+    for (size_t i = 0; i < jobs.size(); ++i) jobs[i].ring = (uint32_t *)c->d_ring + i * 65536;
+    memcpy(a.host<DeflateJob>(jslot), jobs.data(), jobs.size() * sizeof(DeflateJob));
+    HIP_TRY(hipMemcpyAsync((char *)c->d_ws + jslot, (char *)c->h_ws + jslot, jobs.size() * sizeof(DeflateJob),
+                           hipMemcpyHostToDevice, c->stream));
+    Timed t(c, SPNG_K_DEFLATE);
+    HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)jobs.size(), dr, c->stream));
+    return SPNG_DONE;
+}
+
+int32_t spng_deflate_batch(spng_ctx *c, const spng_stream_desc *descs, const int32_t *levels, uint32_t count,
+                           spng_result *d_results, spng_result *h_results)
+{
+    if (!c || (!descs && count) || !levels) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    std::vector<DeflateJob> jobs(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        if ((!descs[i].d_src && descs[i].src_len) || !descs[i].d_dst || levels[i] > 7) return SPNG_E_ARGUMENT;
+        jobs[i] = DeflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst, descs[i].src_len,
+                             descs[i].dst_cap, nullptr, descs[i].format, levels[i], i};
+    }
+    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result)) + 1024)) return st;
+    Arena a{c};
+    const size_t jslot = a.take(count * sizeof(DeflateJob));
+    const size_t res = a.take(count * sizeof(spng_result));
+    spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
+    if (int32_t st = deflate_launch(c, jobs, dr, a, jslot)) return st;
+    if (h_results) {
+        HIP_TRY(hipMemcpyAsync(h_results, dr, count * sizeof(spng_result), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SPNG_DONE;
+}
+
+int32_t spng_deflate(spng_ctx *c, const void *src, uint64_t n, int32_t format, int32_t level,
+                     void *dst, uint64_t cap, spng_result *result)
+{
+    if (!c || (!src && n) || !dst || !result) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf ds, dd;
+    HIP_TRY(ds.alloc(n + 8)); HIP_TRY(dd.alloc(cap));
+    HIP_TRY(hipMemcpyAsync(ds.p, src, n, hipMemcpyHostToDevice, c->stream));
+    spng_stream_desc d{ds.p, n, dd.p, cap, format, 0};
+    if (int32_t st = spng_deflate_batch(c, &d, &level, 1, nullptr, result)) return st;
+    const uint64_t w = result->written < cap ? result->written : cap;
+    if (w) HIP_TRY(hipMemcpy(dst, dd.p, w, hipMemcpyDeviceToHost));
+    return SPNG_DONE;
+}
+
+int32_t spng_encode_batch(spng_ctx *c, const spng_image_desc *descs, int32_t level, uint32_t count,
+                          spng_result *d_results, spng_result *h_results)
+{
+    if (!c || (!descs && count) || level > 7) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    // filter-select (own lock), then deflate of the filtered scanlines
+    if (int32_t st = spng_filter_batch(c, descs, count, d_results, nullptr)) return st;
+    std::vector<spng_stream_desc> sd(count);
+    std::vector<int32_t> lv(count, level);
+    for (uint32_t i = 0; i < count; ++i) {
+        const spng_image_desc &d = descs[i];
+        if (!d.d_idat) return SPNG_E_ARGUMENT;
+        sd[i] = spng_stream_desc{d.d_rows, spng_inflated_size(d.width, d.height, d.depth, d.channels, d.interlaced),
+                                 (void *)d.d_idat, d.idat_len, d.format, 0};
+    }
+    return spng_deflate_batch(c, sd.data(), lv.data(), count, d_results, h_results);
 }
 
 }  // extern "C"

@@ -60,6 +60,16 @@ struct InflateJob {
     uint32_t       image;
 };
 
+struct DeflateJob {
+    const uint8_t *src;
+    uint8_t       *dst;
+    uint64_t       src_len;
+    uint64_t       dst_cap;
+    uint32_t      *ring;          // 65536-entry link ring (scratch, HBM)
+    int32_t        format, level;
+    uint32_t       image;
+};
+
 // PNG.adam7, PNG.Decoder.swift:6-15
 struct Pass { uint32_t bx, by, sx, sy, w, h; uint64_t pitch; };
 int passes(uint32_t w, uint32_t h, int volume, int interlaced, Pass out[7]);
@@ -71,6 +81,7 @@ hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32
                           const spng_result *d_results, uint32_t blocks_x, hipStream_t stream);
 hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results,
                           hipStream_t stream);
+hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 hipError_t launch_filter(const FilterJob *d_jobs, uint32_t count, uint32_t max_rows, hipStream_t stream);
 hipError_t launch_adler_partial(const uint8_t *d, uint64_t n, uint32_t chunk, uint64_t *d_out, uint32_t blocks,
                                 hipStream_t stream);

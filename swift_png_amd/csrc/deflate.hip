@@ -1,0 +1,511 @@
+// deflate.hip -- batched DEFLATE / zlib compression for gfx950, bit-exact with swift-png's
+// LZ77.Deflator at the greedy and lazy levels (level <= 7); one wavefront per stream.
+//
+// Replaces (whole-stream form, i.e. LZ77.Deflator.push(all, last: true)):
+//   level table        Sources/LZ77/Deflator/LZ77.DeflatorSearch.swift:13-35
+//   compress loops     Sources/LZ77/Deflator/LZ77.DeflatorBuffers.Stream.swift:64-342 (greedy, lazy)
+//   window / chains    Sources/LZ77/Deflator/LZ77.DeflatorWindow.swift:78-212, F14 exact map
+//   terms              Sources/LZ77/Deflator/LZ77.DeflatorTerm.swift:10-56, LZ77.Decades.swift
+//   block writer       Sources/LZ77/Deflator/LZ77.DeflatorBuffers.Stream.swift:440-709
+//   tree construction  Sources/LZ77/HuffmanCoding/LZ77.HuffmanTree.swift:247-404, LZ77.Heap.swift
+//   header / trailer   Sources/LZ77/Inflator/LZ77.StreamHeader.swift:56-62, LZ77.MRC32.swift
+//
+// Design.  The reference's match candidates are a pure function of the input: every position is
+// entered into the window, and the candidates of position p are the earlier positions with the
+// same 4-byte key, most recent first (first one at distance <= 32767, later ones < 32767), tried
+// until `attempts` run out or a run >= `goal` is seen; the first strictly longest run > 5 wins.
+// Only the parse (which positions are asked) is sequential.  So the wave works in three layers:
+//   * hash insertion, 64 positions per step: every lane hashes its key, reads the bucket head from
+//     LDS, an unrolled readlane sweep resolves same-bucket positions inside the batch, and each
+//     position's link (distance to the previous same-bucket position + a 16-bit key tag) goes to a
+//     64 K-entry ring in HBM.  Insertion runs ahead of the parse -- later positions never appear
+//     in an earlier position's chain, which only walks backwards;
+//   * match search, 64 positions per step: lane i walks the chain of position w+i (tag filter,
+//     then dword-wise comparison straight from the input), all lanes at once, so the HBM/L2
+//     latency of a chain hop is paid once per step instead of once per position;
+//   * the parse itself walks those 64 results on the scalar unit (readlane per token) with the
+//     reference's greedy / lazy rules, packing terms exactly like LZ77.DeflatorTerm.
+// When 2047 terms are queued (lazy: 2046/2047) the block is written: histogram with LDS atomics,
+// the reference's heap-based length-limited Huffman construction (ranked in parallel, merged on
+// one lane because its tie-breaking is order dependent), code-length RLE, and the token bits.
+#include "common.hpp"
+
+namespace spng {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed)) U32u { uint32_t v; };
+struct __attribute__((packed)) U128u { u32x4 v; };
+
+static constexpr int HBITS = 13;                 // bucket heads in LDS
+static constexpr uint32_t NONE = 0xffffffffu;
+static constexpr int OUTB = 8192;                // output staging ring (bytes, power of two)
+
+// LZ77.Composites.swift:25-110
+__device__ const uint16_t D_RUN_EXTRA[32] = {0, 0,0,0,0,0, 0,0,0,1,1, 1,1,2,2,2, 2,3,3,3,3, 4,4,4,4,5, 5,5,5,0, 0,0};
+__device__ const uint16_t D_RUN_BASE [32] = {0, 3,4,5,6,7, 8,9,10,11,13, 15,17,19,23,27, 31,35,43,51,59,
+                                             67,83,99,115,131, 163,195,227,258, 0,0};
+__device__ const uint16_t D_DIST_EXTRA[32] = {0,0,0,0,1, 1,2,2,3,3, 4,4,5,5,6, 6,7,7,8,8, 9,9,10,10,11,
+                                              11,12,12,13,13, 0,0};
+__device__ const uint16_t D_DIST_BASE [32] = {1,2,3,4,5, 7,9,13,17,25, 33,49,65,97,129, 193,257,385,513,769,
+                                              1025,1537,2049,3073,4097, 6145,8193,12289,16385,24577, 0,0};
+
+// LZ77.Decades.swift in closed form
+__device__ __forceinline__ uint32_t run_decade(uint32_t run)
+{
+    if (run < 11) return run - 2;
+    if (run == 258) return 29;
+    const uint32_t x = run - 3, e = 29 - __builtin_clz(x);       // extra bits: 1 for 8..15, 2 for 16..31, ...
+    return 1 + 4 * e + 4 + (x >> e) - 4;                          // 4 codes per extra-bit class
+}
+__device__ __forceinline__ uint32_t dist_decade(uint32_t d)
+{
+    if (d < 5) return d - 1;
+    const uint32_t x = d - 1, e = 30 - __builtin_clz(x);          // extra bits
+    return 2 * e + 2 + ((x >> e) & 1);
+}
+
+struct DLds {
+    uint32_t head[1 << HBITS];                   // most recent position per bucket (low 32 bits)
+    uint32_t terms[2048];
+    uint32_t freq[320];                          // 0..287 lit/len, 288..319 distance
+    uint8_t  out[OUTB];
+    // Huffman scratch (one tree at a time)
+    uint16_t order[288];                         // symbols by descending frequency (stable)
+    uint32_t hkey[288];                          // heap keys
+    uint16_t hnode[288];                         // heap node ids
+    uint16_t parent[576];                        // tree nodes: leaves 0..m-1 (in `order`), then merges
+    uint16_t depthcnt[300];                      // leaves per depth
+    uint8_t  ll[288], dl[32], ml[19];            // code lengths
+    uint16_t lcode[288], dcode[32], mcode[19];   // bit-reversed codewords
+    uint8_t  msym[320], mbits[320];              // code-length RLE terms
+};
+
+struct Bits {                                    // LSB-first bit writer (LZ77.DeflatorOut.append)
+    uint64_t acc; uint32_t nacc;
+    uint64_t total;                              // bytes produced so far
+    uint64_t flushed;
+    uint8_t *dst; uint64_t cap; bool overflow;
+};
+
+__device__ __forceinline__ void put(DLds &s, Bits &b, uint32_t bits, uint32_t count, int lane)
+{
+    b.acc |= (uint64_t)(bits & ((1u << count) - 1)) << b.nacc;
+    b.nacc += count;
+    while (b.nacc >= 8) {
+        if (lane == 0) s.out[b.total & (OUTB - 1)] = (uint8_t)b.acc;
+        b.total++; b.acc >>= 8; b.nacc -= 8;
+    }
+}
+__device__ void drain(DLds &s, Bits &b, uint64_t upto, int lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    for (uint64_t i = b.flushed + lane; i < upto; i += 64) {
+        if (i < b.cap) b.dst[i] = s.out[i & (OUTB - 1)];
+    }
+    if (upto > b.cap) b.overflow = true;
+    b.flushed = upto;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+}
+__device__ __forceinline__ void maybe_drain(DLds &s, Bits &b, int lane)
+{
+    if (b.total - b.flushed >= OUTB / 2) drain(s, b, b.total, lane);
+}
+
+// HuffmanTree.init(frequencies:limit:) (HuffmanTree.swift:247-344) for `n` symbols with counts
+// in freq[0..n): code length per symbol into len[].  The heap (LZ77.Heap.swift) is replayed
+// exactly -- which two nodes merge on equal keys depends on its sift order -- but its values are
+// node ids: the reference's per-level leaf-count vectors are the depth histogram of the tree.
+__device__ void build_tree(DLds &s, const uint32_t *freq, int n, int limit, uint8_t *len, int lane)
+{
+    for (int i = lane; i < n; i += 64) len[i] = 0;
+    // rank = position in (descending frequency, ascending symbol) order
+    int m = 0;
+    for (int base = 0; base < n; base += 64) m += __popcll(__ballot(base + lane < n && freq[base + lane] > 0));
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t f = freq[i];
+        if (!f) continue;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const uint32_t g = freq[j]; rank += (g > f) | ((g == f) & (j < i) & (g != 0)); }
+        s.order[rank] = (uint16_t)i;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (m <= 1) {                                              // stub tree (HuffmanTree.swift:52-65)
+        if (m == 1 && lane == 0) len[s.order[0]] = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        return;
+    }
+    if (lane == 0) {
+        // heap over symbols.reversed(): ascending frequency; leaf k = order[m-1-k]
+        int count = m, nodes = m;
+        for (int k = 0; k < m; ++k) { s.hkey[k] = freq[s.order[m - 1 - k]]; s.hnode[k] = (uint16_t)k; }
+        auto lowest = [&](int parent) -> int {                // Heap.lowest(below:) (:94-111), 1-based
+            const int r = (parent << 1) + 1, l = parent << 1;
+            if (l >= count + 1) return 0;
+            if (r >= count + 1) return s.hkey[l - 1] < s.hkey[parent - 1] ? l : 0;
+            const int c = s.hkey[r - 1] < s.hkey[l - 1] ? r : l;
+            return s.hkey[c - 1] < s.hkey[parent - 1] ? c : 0;
+        };
+        auto swap = [&](int a, int b) {
+            const uint32_t k = s.hkey[a - 1]; s.hkey[a - 1] = s.hkey[b - 1]; s.hkey[b - 1] = k;
+            const uint16_t v = s.hnode[a - 1]; s.hnode[a - 1] = s.hnode[b - 1]; s.hnode[b - 1] = v;
+        };
+        auto sift_down = [&](int i) { for (;;) { const int c = lowest(i); if (!c) return; swap(i, c); i = c; } };
+        auto dequeue = [&](uint32_t &key, uint16_t &node) {    // Heap.dequeue (:149-164)
+            if (count > 1) swap(1, count);
+            key = s.hkey[count - 1]; node = s.hnode[count - 1];
+            --count;
+            if (count > 0) sift_down(1);
+        };
+        for (int i = count >> 1; i >= 1; --i) sift_down(i);    // heapify (:166-175)
+        uint16_t root = 0;
+        for (;;) {
+            uint32_t k1, k2; uint16_t n1, n2;
+            dequeue(k1, n1);
+            if (count == 0) { root = n1; break; }
+            dequeue(k2, n2);
+            const uint16_t id = (uint16_t)nodes++;
+            s.parent[n1] = id; s.parent[n2] = id;
+            s.hkey[count] = k1 + k2; s.hnode[count] = id;      // enqueue + siftUp (:137-147)
+            ++count;
+            for (int i = count; ;) {
+                const int p = i >> 1;
+                if (p < 1 || !(s.hkey[i - 1] < s.hkey[p - 1])) break;
+                swap(i, p); i = p;
+            }
+        }
+        // depth histogram: depthcnt[d-1] = leaves at depth d
+        int maxd = 0;
+        for (int d = 0; d < 300; ++d) s.depthcnt[d] = 0;
+        for (int k = 0; k < m; ++k) {
+            int d = 0;
+            for (uint16_t v = (uint16_t)k; v != root; v = s.parent[v]) ++d;
+            s.depthcnt[d - 1]++;
+            if (d > maxd) maxd = d;
+        }
+        // HuffmanTree.limitHeight (:348-404)
+        int nl = maxd;
+        if (nl > limit) {
+            int unhoused = 0;
+            for (int l = nl - 1; l >= limit; --l) {
+                const int pairs = s.depthcnt[l] >> 1;
+                unhoused += pairs;
+                s.depthcnt[l - 1] += (uint16_t)pairs;
+            }
+            nl = limit;
+            int split = limit - 2;
+            while (unhoused > 0) {
+                if (!(s.depthcnt[split] > 0)) { split--; continue; }
+                const int resettled = s.depthcnt[split] < unhoused ? s.depthcnt[split] : unhoused;
+                unhoused -= resettled;
+                s.depthcnt[split] -= (uint16_t)resettled;
+                s.depthcnt[split + 1] += (uint16_t)(2 * resettled);
+                if (split < limit - 2) split++;
+            }
+        }
+        // most frequent symbols take the shortest codes (:306-337)
+        int at = 0;
+        for (int l = 0; l < nl; ++l)
+            for (int k = 0; k < s.depthcnt[l]; ++k) len[s.order[at++]] = (uint8_t)(l + 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+}
+
+// canonical codewords, bit-reversed for LSB-first emission (HuffmanTree.codewords :206-230)
+__device__ void make_codes(const uint8_t *len, int n, uint16_t *code, int lane)
+{
+    if (lane == 0) {
+        uint32_t counter = 0;
+        for (int l = 1; l <= 15; ++l) {
+            for (int sym = 0; sym < n; ++sym) if (len[sym] == l) {
+                code[sym] = (uint16_t)(__brev(counter) >> (32 - l));
+                counter++;
+            }
+            counter <<= 1;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+}
+
+// Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), greedy / lazy form
+__device__ void write_block(DLds &s, Bits &b, int count, bool final, int lane)
+{
+    // DeflatorMatches.trees() (:138-159)
+    for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    for (int i = lane; i < count; i += 64) {
+        const uint32_t t = s.terms[i];
+        atomicAdd(&s.freq[t & 0x1ff], 1u);
+        atomicAdd(&s.freq[288 + (t >> 27)], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (lane == 0) s.freq[256] = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    build_tree(s, s.freq, 286, 15, s.ll, lane);
+    build_tree(s, s.freq + 288, 30, 15, s.dl, lane);
+    if (lane < 2) { s.ll[286 + lane] = 0; s.dl[30 + lane] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+
+    // code-length RLE (:459-552) and the meta tree, on one lane
+    int r = 0, dn = 0, nm = 0;
+    if (lane == 0) {
+        r = 286; while (r > 0 && s.ll[r - 1] == 0) --r;
+        if (r < 257) r = 257;
+        dn = 30; while (dn > 0 && s.dl[dn - 1] == 0) --dn;
+        if (dn < 1) dn = 1;
+        auto length_at = [&](int idx) -> uint8_t { return idx < r ? s.ll[idx] : s.dl[idx - r]; };
+        int reps = 1; uint8_t last = length_at(0);
+        for (int idx = 1; ; ++idx) {
+            const bool have = idx < r + dn;
+            const uint8_t cur = have ? length_at(idx) : 0;
+            if (have && cur == last) { reps++; continue; }
+            if (last == 0) {
+                while (reps > 138) { s.msym[nm] = 18; s.mbits[nm++] = 138 - 11; reps -= 138; }
+                if (reps > 2) { if (reps < 11) { s.msym[nm] = 17; s.mbits[nm++] = (uint8_t)(reps - 3); }
+                                else { s.msym[nm] = 18; s.mbits[nm++] = (uint8_t)(reps - 11); } }
+                else for (int k = 0; k < reps; ++k) { s.msym[nm] = 0; s.mbits[nm++] = 0; }
+            } else {
+                s.msym[nm] = last; s.mbits[nm++] = 0; reps -= 1;
+                while (reps > 6) { s.msym[nm] = 16; s.mbits[nm++] = 6 - 3; reps -= 6; }
+                if (reps > 2) { s.msym[nm] = 16; s.mbits[nm++] = (uint8_t)(reps - 3); }
+                else for (int k = 0; k < reps; ++k) { s.msym[nm] = last; s.mbits[nm++] = 0; }
+            }
+            if (!have) break;
+            last = cur; reps = 1;
+        }
+        for (int k = 0; k < 19; ++k) s.freq[k] = 0;
+        for (int k = 0; k < nm; ++k) s.freq[s.msym[k]]++;
+    }
+    r = __builtin_amdgcn_readfirstlane(r); dn = __builtin_amdgcn_readfirstlane(dn); nm = __builtin_amdgcn_readfirstlane(nm);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    build_tree(s, s.freq, 19, 7, s.ml, lane);
+    make_codes(s.ll, 288, s.lcode, lane);
+    make_codes(s.dl, 32, s.dcode, lane);
+    make_codes(s.ml, 19, s.mcode, lane);
+
+    // writeBlockMetadata (:577-612)
+    const int ZPOS[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
+    uint8_t cl[19];
+    for (int k = 0; k < 19; ++k) cl[k] = 0;
+    for (int sym = 0; sym < 19; ++sym) if (s.ml[sym]) cl[ZPOS[sym]] = s.ml[sym];
+    int ncl = 19; while (ncl > 0 && cl[ncl - 1] == 0) --ncl;
+    if (ncl < 4) ncl = 4;
+    put(s, b, final ? 5 : 4, 3, lane);
+    put(s, b, (uint32_t)(r - 257), 5, lane);
+    put(s, b, (uint32_t)(dn - 1), 5, lane);
+    put(s, b, (uint32_t)(ncl - 4), 4, lane);
+    for (int k = 0; k < ncl; ++k) put(s, b, cl[k], 3, lane);
+    // writeBlockTables (:615-623)
+    for (int k = 0; k < nm; ++k) {
+        const uint32_t sym = s.msym[k];
+        put(s, b, s.mcode[sym], s.ml[sym], lane);
+        put(s, b, s.mbits[k], sym == 18 ? 7 : sym == 17 ? 3 : sym == 16 ? 2 : 0, lane);
+    }
+    maybe_drain(s, b, lane);
+    // writeBlock(with:) (:626-659)
+    for (int i = 0; i < count; ++i) {
+        const uint32_t t = s.terms[i];
+        const uint32_t sym = t & 0x1ff, dsym = t >> 27;
+        put(s, b, s.lcode[sym], s.ll[sym], lane);
+        if (sym > 256) {
+            put(s, b, (t >> 9) & 0x1f, D_RUN_EXTRA[sym & 0xff], lane);
+            put(s, b, s.dcode[dsym], s.dl[dsym], lane);
+            put(s, b, (t >> 14) & 0x1fff, D_DIST_EXTRA[dsym], lane);
+        }
+        if ((i & 255) == 255) maybe_drain(s, b, lane);
+    }
+    put(s, b, s.lcode[256], s.ll[256], lane);
+    maybe_drain(s, b, lane);
+}
+
+__device__ __forceinline__ uint32_t load32(const uint8_t *p) { return ((const U32u *)p)->v; }
+
+// bytes of position q.. and p.. agree for how many bytes (<= limit)?  Dword-wise from the input.
+__device__ __forceinline__ uint32_t common_prefix(const uint8_t *in, uint64_t q, uint64_t p, uint32_t limit)
+{
+    uint32_t i = 0;
+    while (i + 4 <= limit) {
+        const uint32_t x = load32(in + q + i) ^ load32(in + p + i);
+        if (x) return i + (__builtin_ctz(x) >> 3);
+        i += 4;
+    }
+    while (i < limit && in[q + i] == in[p + i]) ++i;
+    return i;
+}
+
+__global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restrict__ jobs,
+                                                     spng_result *__restrict__ results)
+{
+    __shared__ __attribute__((aligned(16))) DLds s;
+    const DeflateJob job = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const uint8_t *in = job.src;
+    const uint64_t n = job.src_len;
+    uint32_t *ring = job.ring;                                 // 65536 links: distance | tag << 16
+
+    // DeflatorSearch.init(level:) (:13-35), greedy and lazy rows
+    const int level = job.level < 0 ? 0 : job.level;
+    const bool lazy = level >= 4;
+    const int ATT[8] = {1, 2, 4, 40, 20, 40, 64, 100}, GOAL[8] = {6, 8, 10, 24, 32, 54, 80, 160};
+    const int attempts = ATT[level & 7], goal = GOAL[level & 7];
+
+    Bits b = {0, 0, 0, 0, job.dst, job.dst_cap, false};
+    if (job.format == SPNG_FORMAT_ZLIB) put(s, b, 0x0178, 16, lane);   // StreamHeader.write, exponent 15
+    for (int i = lane; i < (1 << HBITS); i += 64) s.head[i] = NONE;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+
+    uint32_t accS = 0, accI = 0;                               // Adler-32 of the input, as in inflate.hip
+    int count = 0;                                             // queued terms
+    const int limit_terms = 2048;
+    auto unfilled = [&]() { return limit_terms - 1 - count; };
+
+    if (n < 3) {
+        // Stream.compressBlocks stored tail (:45-60, :417-434)
+        put(s, b, 1, 3, lane);
+        if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
+        put(s, b, (uint32_t)n, 16, lane); put(s, b, ~(uint32_t)n & 0xffff, 16, lane);
+        for (uint64_t k = 0; k < n; ++k) put(s, b, in[k], 8, lane);
+        if ((uint64_t)lane < n) { accS = in[lane]; accI = (uint32_t)lane * in[lane]; }
+    } else {
+        const uint64_t last_main = n - 4 + 1;                  // positions 0 .. n-4 are searched
+        uint64_t inserted = 0;                                 // positions < inserted are in the window
+        uint64_t w = 0;                                        // parse position
+        auto insert_upto = [&](uint64_t target) {
+            while (inserted < target && inserted < n) {
+                const uint64_t p = inserted + lane;
+                const bool live = p + 4 <= n;                  // the last three positions never start a match
+                uint32_t key = 0;
+                if (live) key = load32(in + p);
+                else for (int k = 0; k < 4; ++k) if (p + k < n) key |= (uint32_t)in[p + k] << (8 * k);
+                if (p < n) {                                   // Adler-32 accumulators
+                    const uint32_t byte = key & 0xff;
+                    accS += byte;
+                    accI = (accI + (uint32_t)(p % 65521) * byte) % 65521;
+                }
+                const uint32_t mix = key * 0x9E3779B1u;
+                const uint32_t h = live ? mix >> (32 - HBITS) : 0xffffffffu - lane;
+                const uint32_t tag = (mix >> 3) & 0xffffu;
+                uint32_t prev = live ? s.head[h & ((1 << HBITS) - 1)] : NONE;
+                bool later = false;
+#pragma unroll
+                for (int j = 0; j < 64; ++j) {
+                    const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
+                    const bool same = hj == h;
+                    prev = (same && j < lane) ? (uint32_t)(inserted + j) : prev;
+                    later |= same && j > lane;
+                }
+                uint32_t dist = 0;
+                if (live && prev != NONE) {
+                    const uint64_t d = (uint32_t)((uint32_t)p - prev);
+                    dist = d <= 32767 ? (uint32_t)d : 0;
+                }
+                if (p < n) ring[p & 65535] = dist | tag << 16;
+                if (live && !later) s.head[h & ((1 << HBITS) - 1)] = (uint32_t)p;
+                inserted += 64;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            }
+        };
+
+        while (w < last_main) {
+            // keep the window filled well ahead of the 64 positions searched now (+258 of look-ahead
+            // is irrelevant for insertion: links only point backwards)
+            insert_upto(w + 128);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // our own ring stores, before we read them back
+            // ---- match search: lane i answers window.match(from: w + i)
+            const uint64_t p = w + lane;
+            uint32_t best_run = 5, best_dist = 1;
+            if (p < last_main) {
+                const uint32_t limit = n - p < 258 ? (uint32_t)(n - p) : 258u;
+                const uint32_t mine = ring[p & 65535];
+                const uint32_t tag = mine >> 16;
+                uint32_t d = mine & 0xffff, acc = 0;
+                int remaining = attempts;
+                bool first = true;
+                while (d) {
+                    acc += d;
+                    if (acc > 32767 || (!first && acc >= 32767)) break;
+                    const uint32_t e = ring[(p - acc) & 65535];
+                    if ((e >> 16) == tag && load32(in + p - acc) == load32(in + p)) {
+                        // LZ77.DeflatorWindow.match (:145-208): run, then the stop rules
+                        const uint32_t run = common_prefix(in, p - acc, p, limit);
+                        if (best_run < run) { best_run = run; best_dist = acc; }
+                        first = false;
+                        remaining -= 1;
+                        if (!(remaining > 0 && goal > (int)run)) break;
+                    }
+                    d = e & 0xffff;
+                }
+            }
+            const uint32_t mrun = best_run > 5 ? best_run : 0;   // 0: no match (run must exceed 5, :129)
+            const uint32_t mylit = p < n ? in[p] : 0u;
+
+            // ---- the parse: Stream.compress greedy (:209-252) / lazy (:268-323) over these 64 answers
+            uint32_t t = 0;
+            bool stop = false;
+            while (t < 64 && w + t < last_main && !stop) {
+                if (!(unfilled() > (lazy ? 1 : 0))) { write_block(s, b, count, false, lane); count = 0; }
+                const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)mrun, (int)t);
+                const uint32_t lit = (uint32_t)__builtin_amdgcn_readlane((int)mylit, (int)t);
+                if (!run) { if (lane == 0) s.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
+                uint32_t use_run = run, use_dist = (uint32_t)__builtin_amdgcn_readlane((int)best_dist, (int)t);
+                uint32_t adv = run;
+                if (lazy) {
+                    // the answer for position w+t+1 is needed: restart the search there if it is not in this batch
+                    if (t + 1 >= 64) { stop = true; break; }
+                    // lazy match at a+1 (:293-299); it exists only if that position is still searched
+                    const uint32_t lrun = (w + t + 1 < last_main) ? (uint32_t)__builtin_amdgcn_readlane((int)mrun, (int)(t + 1)) : 0u;
+                    if (lrun > run) {
+                        if (lane == 0) s.terms[count] = 0xf8000000u | lit;
+                        ++count;
+                        use_run = lrun; use_dist = (uint32_t)__builtin_amdgcn_readlane((int)best_dist, (int)(t + 1));
+                        adv = 1 + lrun;
+                    }
+                }
+                // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
+                const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
+                if (lane == 0)
+                    s.terms[count] = dd << 27 | 0x100u | rd | (use_dist - D_DIST_BASE[dd]) << 14 | (use_run - D_RUN_BASE[rd]) << 9;
+                ++count;
+                t += adv;
+            }
+            w += t;
+        }
+        insert_upto(n);                                        // Adler-32 over the tail
+        // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
+        for (uint64_t p = w; p < n; ++p) {
+            if (!(unfilled() > 0)) { write_block(s, b, count, false, lane); count = 0; }
+            if (lane == 0) s.terms[count] = 0xf8000000u | in[p];
+            ++count;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        write_block(s, b, count, true, lane);
+    }
+
+    if (job.format == SPNG_FORMAT_ZLIB) {
+        // Adler-32 (see inflate.hip): s1 = 1 + S, s2 = N + N*S - I
+        uint32_t S = accS % 65521, I = accI % 65521;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { S += __shfl_xor(S, m, 64); I += __shfl_xor(I, m, 64); }
+        S %= 65521; I %= 65521;
+        const uint32_t N = (uint32_t)(n % 65521);
+        const uint32_t sum = ((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
+        if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
+        put(s, b, sum >> 24, 8, lane); put(s, b, (sum >> 16) & 0xff, 8, lane);
+        put(s, b, (sum >> 8) & 0xff, 8, lane); put(s, b, sum & 0xff, 8, lane);
+    }
+    if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);                // DeflatorOut.pull flushes padding bits
+    drain(s, b, b.total, lane);
+    if (lane == 0) {
+        spng_result &res = results[job.image];
+        res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_DONE; res.reserved = 0;
+        res.written = b.total; res.consumed = n; res.aux[0] = res.aux[1] = 0;
+    }
+}
+
+hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    deflate_kernel<<<count, 64, 0, stream>>>(d_jobs, d_results);
+    return hipGetLastError();
+}
+
+}  // namespace spng

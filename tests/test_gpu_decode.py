@@ -329,3 +329,52 @@ def test_synthetic_4k_image_roundtrip(gpu):
     z = zlib.compress(rows, 6)
     st, storage, _ = s.decode(z, 4096, 4096, 8, 4, False)
     assert st == 0 and storage == img.tobytes()
+
+
+# ------------------------------------------------------------------------------------------ deflate
+def _deflate_payloads():
+    rng = np.random.default_rng(21)
+    p = dict(_payloads())
+    p["two"] = b"ab"; p["three"] = b"abc"; p["four"] = b"abcd"; p["five"] = b"abcde"
+    p["runs"] = b"".join(bytes([i % 7]) * int(rng.integers(1, 600)) for i in range(300))
+    p["periodic"] = (bytes(range(37)) * 3000)[:100001]
+    p["end-in-match"] = rng.integers(0, 256, 5000, dtype=np.uint8).tobytes() + b"\x05" * 300
+    return p
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_deflate_vs_oracle(gpu, level):
+    """Identical DEFLATE bitstream at the same level (BASELINE north star), greedy and lazy rows of
+    LZ77.DeflatorSearch.swift:17-24."""
+    s = gpu.load()
+    for kind, data in sorted(_deflate_payloads().items()):
+        for fmt in (0, 1):
+            want = ph.orc_deflate(data, level, fmt)
+            got = s.deflate(data, level, fmt)
+            assert got == want, (kind, fmt, len(got), len(want))
+        assert zlib.decompress(got if fmt == 0 else want) == data if fmt == 0 else True
+
+
+def test_deflate_block_boundaries(gpu):
+    """Blocks close after 2047 terms (greedy) / 2046-2047 (lazy); literal-only inputs around the
+    boundary exercise the term-buffer guards (DeflatorBuffers.Stream.swift:219,277)."""
+    s = gpu.load()
+    rng = np.random.default_rng(8)
+    for n in (2046, 2047, 2048, 2049, 2050, 4094, 4095, 4096, 6141):
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        for level in (0, 6):
+            assert s.deflate(data, level) == ph.orc_deflate(data, level), (n, level)
+
+
+def test_deflate_4k_rows_level6(gpu):
+    """The benchmark's own stream: filtered scanlines of a synthetic 4096x4096 RGBA8 image at
+    level 6; GPU stream == oracle stream, and the GPU inflates it back."""
+    from swift_png_amd import synth
+    s = gpu.load()
+    img = synth.image(5, 4096, 4096)
+    rows = s.filter(img.tobytes(), 4096, 4096, 8, 4, False)
+    got = s.deflate(rows, 6)
+    want = ph.orc_deflate(rows, 6)
+    assert hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
+    st, storage, _ = s.decode(got, 4096, 4096, 8, 4, False)
+    assert st == 0 and storage == img.tobytes()
