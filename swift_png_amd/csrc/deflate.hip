@@ -40,14 +40,12 @@ static constexpr int HBITS = 13;                 // bucket heads in LDS
 static constexpr uint32_t NONE = 0xffffffffu;
 static constexpr int OUTB = 8192;                // output staging ring (bytes, power of two)
 
-// LZ77.Composites.swift:25-110
-__device__ const uint16_t D_RUN_EXTRA[32] = {0, 0,0,0,0,0, 0,0,0,1,1, 1,1,2,2,2, 2,3,3,3,3, 4,4,4,4,5, 5,5,5,0, 0,0};
-__device__ const uint16_t D_RUN_BASE [32] = {0, 3,4,5,6,7, 8,9,10,11,13, 15,17,19,23,27, 31,35,43,51,59,
-                                             67,83,99,115,131, 163,195,227,258, 0,0};
-__device__ const uint16_t D_DIST_EXTRA[32] = {0,0,0,0,1, 1,2,2,3,3, 4,4,5,5,6, 6,7,7,8,8, 9,9,10,10,11,
-                                              11,12,12,13,13, 0,0};
-__device__ const uint16_t D_DIST_BASE [32] = {1,2,3,4,5, 7,9,13,17,25, 33,49,65,97,129, 193,257,385,513,769,
-                                              1025,1537,2049,3073,4097, 6145,8193,12289,16385,24577, 0,0};
+// LZ77.Composites.swift:25-110 in closed form (table loads from HBM would sit on the serial path):
+// number of extra bits of a run / distance decade, and the extra-bit value of a run / distance.
+__device__ __forceinline__ uint32_t run_extra_bits(uint32_t decade) { return decade < 9 || decade == 29 ? 0u : (decade - 5) >> 2; }
+__device__ __forceinline__ uint32_t dist_extra_bits(uint32_t decade) { return decade < 4 ? 0u : (decade >> 1) - 1; }
+__device__ __forceinline__ uint32_t run_extra_value(uint32_t run, uint32_t decade) { return (run - 3) & ((1u << run_extra_bits(decade)) - 1); }
+__device__ __forceinline__ uint32_t dist_extra_value(uint32_t d, uint32_t decade) { return (d - 1) & ((1u << dist_extra_bits(decade)) - 1); }
 
 // LZ77.Decades.swift in closed form
 __device__ __forceinline__ uint32_t run_decade(uint32_t run)
@@ -71,8 +69,7 @@ struct DLds {
     uint8_t  out[OUTB];
     // Huffman scratch (one tree at a time)
     uint16_t order[288];                         // symbols by descending frequency (stable)
-    uint32_t hkey[288];                          // heap keys
-    uint16_t hnode[288];                         // heap node ids
+    uint64_t heap[288];                          // heap entries: key << 32 | node id
     uint16_t parent[576];                        // tree nodes: leaves 0..m-1 (in `order`), then merges
     uint16_t depthcnt[300];                      // leaves per depth
     uint8_t  ll[288], dl[32], ml[19];            // code lengths
@@ -135,43 +132,51 @@ __device__ void build_tree(DLds &s, const uint32_t *freq, int n, int limit, uint
         return;
     }
     if (lane == 0) {
-        // heap over symbols.reversed(): ascending frequency; leaf k = order[m-1-k]
+        // heap over symbols.reversed(): ascending frequency; leaf k = order[m-1-k].  Entries are
+        // (key << 32 | node) so that one LDS access moves an element; the sifts carry the moving
+        // element in registers (same comparisons, same outcome as the reference's swap form).
+        uint64_t *hp = s.heap;                                 // 1-based: hp[i - 1]
         int count = m, nodes = m;
-        for (int k = 0; k < m; ++k) { s.hkey[k] = freq[s.order[m - 1 - k]]; s.hnode[k] = (uint16_t)k; }
-        auto lowest = [&](int parent) -> int {                // Heap.lowest(below:) (:94-111), 1-based
-            const int r = (parent << 1) + 1, l = parent << 1;
-            if (l >= count + 1) return 0;
-            if (r >= count + 1) return s.hkey[l - 1] < s.hkey[parent - 1] ? l : 0;
-            const int c = s.hkey[r - 1] < s.hkey[l - 1] ? r : l;
-            return s.hkey[c - 1] < s.hkey[parent - 1] ? c : 0;
+        for (int k = 0; k < m; ++k) hp[k] = (uint64_t)freq[s.order[m - 1 - k]] << 32 | (uint32_t)k;
+        auto sift_down = [&](int i, uint64_t moving) {         // Heap.siftDown / lowest(below:) (:94-135)
+            const uint32_t key = (uint32_t)(moving >> 32);
+            for (;;) {
+                const int l = i << 1, r = l + 1;
+                if (l > count) break;
+                const uint64_t el = hp[l - 1], er = r <= count ? hp[r - 1] : ~0ull;
+                const bool right = r <= count && (uint32_t)(er >> 32) < (uint32_t)(el >> 32);
+                const uint64_t ec = right ? er : el;
+                if (!((uint32_t)(ec >> 32) < key)) break;
+                hp[i - 1] = ec;
+                i = right ? r : l;
+            }
+            hp[i - 1] = moving;
         };
-        auto swap = [&](int a, int b) {
-            const uint32_t k = s.hkey[a - 1]; s.hkey[a - 1] = s.hkey[b - 1]; s.hkey[b - 1] = k;
-            const uint16_t v = s.hnode[a - 1]; s.hnode[a - 1] = s.hnode[b - 1]; s.hnode[b - 1] = v;
-        };
-        auto sift_down = [&](int i) { for (;;) { const int c = lowest(i); if (!c) return; swap(i, c); i = c; } };
-        auto dequeue = [&](uint32_t &key, uint16_t &node) {    // Heap.dequeue (:149-164)
-            if (count > 1) swap(1, count);
-            key = s.hkey[count - 1]; node = s.hnode[count - 1];
+        auto dequeue = [&]() -> uint64_t {                     // Heap.dequeue (:149-164)
+            const uint64_t top = hp[0];
+            const uint64_t moving = hp[count - 1];
             --count;
-            if (count > 0) sift_down(1);
+            if (count > 0) sift_down(1, moving);
+            return top;
         };
-        for (int i = count >> 1; i >= 1; --i) sift_down(i);    // heapify (:166-175)
+        for (int i = count >> 1; i >= 1; --i) sift_down(i, hp[i - 1]);   // heapify (:166-175)
         uint16_t root = 0;
         for (;;) {
-            uint32_t k1, k2; uint16_t n1, n2;
-            dequeue(k1, n1);
-            if (count == 0) { root = n1; break; }
-            dequeue(k2, n2);
+            const uint64_t e1 = dequeue();
+            if (count == 0) { root = (uint16_t)e1; break; }
+            const uint64_t e2 = dequeue();
             const uint16_t id = (uint16_t)nodes++;
-            s.parent[n1] = id; s.parent[n2] = id;
-            s.hkey[count] = k1 + k2; s.hnode[count] = id;      // enqueue + siftUp (:137-147)
-            ++count;
-            for (int i = count; ;) {
+            s.parent[(uint16_t)e1] = id; s.parent[(uint16_t)e2] = id;
+            const uint32_t key = (uint32_t)(e1 >> 32) + (uint32_t)(e2 >> 32);
+            int i = ++count;                                   // enqueue + siftUp (:137-147, :113-123)
+            for (;;) {
                 const int p = i >> 1;
-                if (p < 1 || !(s.hkey[i - 1] < s.hkey[p - 1])) break;
-                swap(i, p); i = p;
+                if (p < 1) break;
+                const uint64_t ep = hp[p - 1];
+                if (!(key < (uint32_t)(ep >> 32))) break;
+                hp[i - 1] = ep; i = p;
             }
+            hp[i - 1] = (uint64_t)key << 32 | id;
         }
         // depth histogram: depthcnt[d-1] = leaves at depth d
         int maxd = 0;
@@ -307,9 +312,9 @@ __device__ void write_block(DLds &s, Bits &b, int count, bool final, int lane)
         const uint32_t sym = t & 0x1ff, dsym = t >> 27;
         put(s, b, s.lcode[sym], s.ll[sym], lane);
         if (sym > 256) {
-            put(s, b, (t >> 9) & 0x1f, D_RUN_EXTRA[sym & 0xff], lane);
+            put(s, b, (t >> 9) & 0x1f, run_extra_bits(sym & 0xff), lane);
             put(s, b, s.dcode[dsym], s.dl[dsym], lane);
-            put(s, b, (t >> 14) & 0x1fff, D_DIST_EXTRA[dsym], lane);
+            put(s, b, (t >> 14) & 0x1fff, dist_extra_bits(dsym), lane);
         }
         if ((i & 255) == 255) maybe_drain(s, b, lane);
     }
@@ -332,6 +337,16 @@ __device__ __forceinline__ uint32_t common_prefix(const uint8_t *in, uint64_t q,
     return i;
 }
 
+#ifdef SPNG_DEFLATE_PROF
+#define DPROF_DECL uint64_t pt[6] = {0,0,0,0,0,0}, p_t0 = 0;
+#define DPROF_BEGIN() p_t0 = __builtin_readcyclecounter()
+#define DPROF_END(k) pt[k] += __builtin_readcyclecounter() - p_t0
+#else
+#define DPROF_DECL
+#define DPROF_BEGIN()
+#define DPROF_END(k)
+#endif
+
 __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restrict__ jobs,
                                                      spng_result *__restrict__ results)
 {
@@ -353,6 +368,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
     for (int i = lane; i < (1 << HBITS); i += 64) s.head[i] = NONE;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 
+    DPROF_DECL
     uint32_t accS = 0, accI = 0;                               // Adler-32 of the input, as in inflate.hip
     int count = 0;                                             // queued terms
     const int limit_terms = 2048;
@@ -408,8 +424,10 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         while (w < last_main) {
             // keep the window filled well ahead of the 64 positions searched now (+258 of look-ahead
             // is irrelevant for insertion: links only point backwards)
+            DPROF_BEGIN();
             insert_upto(w + 128);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // our own ring stores, before we read them back
+            DPROF_END(0); DPROF_BEGIN();
             // ---- match search: lane i answers window.match(from: w + i)
             const uint64_t p = w + lane;
             uint32_t best_run = 5, best_dist = 1;
@@ -437,12 +455,14 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
             }
             const uint32_t mrun = best_run > 5 ? best_run : 0;   // 0: no match (run must exceed 5, :129)
             const uint32_t mylit = p < n ? in[p] : 0u;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DPROF_END(1); DPROF_BEGIN();
 
             // ---- the parse: Stream.compress greedy (:209-252) / lazy (:268-323) over these 64 answers
             uint32_t t = 0;
             bool stop = false;
             while (t < 64 && w + t < last_main && !stop) {
-                if (!(unfilled() > (lazy ? 1 : 0))) { write_block(s, b, count, false, lane); count = 0; }
+                if (!(unfilled() > (lazy ? 1 : 0))) { DPROF_END(2); DPROF_BEGIN(); write_block(s, b, count, false, lane); count = 0; DPROF_END(3); DPROF_BEGIN(); }
                 const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)mrun, (int)t);
                 const uint32_t lit = (uint32_t)__builtin_amdgcn_readlane((int)mylit, (int)t);
                 if (!run) { if (lane == 0) s.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
@@ -463,11 +483,12 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                 // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
                 const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
                 if (lane == 0)
-                    s.terms[count] = dd << 27 | 0x100u | rd | (use_dist - D_DIST_BASE[dd]) << 14 | (use_run - D_RUN_BASE[rd]) << 9;
+                    s.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
                 ++count;
                 t += adv;
             }
             w += t;
+            DPROF_END(2);
         }
         insert_upto(n);                                        // Adler-32 over the tail
         // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
@@ -494,6 +515,9 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
     }
     if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);                // DeflatorOut.pull flushes padding bits
     drain(s, b, b.total, lane);
+#ifdef SPNG_DEFLATE_PROF
+    if (lane == 0 && blockIdx.x == 0) printf("deflate prof cycles: insert %llu search %llu parse %llu write_block %llu\n", pt[0], pt[1], pt[2], pt[3]);
+#endif
     if (lane == 0) {
         spng_result &res = results[job.image];
         res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_DONE; res.reserved = 0;
