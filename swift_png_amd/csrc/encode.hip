@@ -46,6 +46,136 @@ __device__ __forceinline__ uint32_t abs8(uint32_t v)   // |Int8(bitPattern:)|, P
     return (uint32_t)(s < 0 ? -s : s);
 }
 
+// ---- fast path: 8/16-bit non-interlaced rows whose pitch is a multiple of 16 ---------------------
+// 16 bytes per lane per step, two 16-byte loads (this row, row above); the left / upper-left
+// neighbours are the same bytes shifted by bpp, taken from the previous lane with DPP instead of a
+// second pair of loads.  All five residuals are formed with byte-SWAR arithmetic in registers
+// (v_lerp_u8 for Average, packed-i16 Paeth), scored with v_sad_u8; only the winner is recomputed
+// and stored.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+struct __attribute__((packed)) U128u { u32x4 v; };
+
+__device__ __forceinline__ uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ uint32_t sub8(uint32_t x, uint32_t p)              // per-byte x - p (mod 256)
+{
+    constexpr uint32_t Hb = 0x80808080u;
+    return ((x | Hb) - (p & ~Hb)) ^ ((x ^ ~p) & Hb);
+}
+__device__ __forceinline__ uint32_t sumabs8(uint32_t r, uint32_t acc)         // acc + sum |Int8(byte)|
+{
+    const uint32_t m = (r >> 7) & 0x01010101u, neg = (m << 8) - m;
+    return __builtin_amdgcn_sad_u8((r ^ neg) + m, 0u, acc);
+}
+__device__ __forceinline__ uint32_t paeth_pk16(uint32_t a, uint32_t b, uint32_t c)
+{
+    const s16x2 va = __builtin_bit_cast(s16x2, a), vb = __builtin_bit_cast(s16x2, b), vc = __builtin_bit_cast(s16x2, c);
+    const s16x2 d0 = vb - vc, d1 = va - vc, ds = d0 + d1;
+    const s16x2 pa = __builtin_elementwise_max(d0, -d0), pb = __builtin_elementwise_max(d1, -d1),
+                pc = __builtin_elementwise_max(ds, -ds);
+    const s16x2 fifteen = {15, 15};
+    const uint32_t nota = opaque(__builtin_bit_cast(uint32_t, ((pb - pa) | (pc - pa)) >> fifteen));
+    const uint32_t usec = opaque(__builtin_bit_cast(uint32_t, (pc - pb) >> fifteen));
+    const uint32_t bc = (c & usec) | (b & ~usec);
+    return (bc & nota) | (a & ~nota);
+}
+__device__ __forceinline__ uint32_t paeth8(uint32_t a, uint32_t b, uint32_t c)   // PNG.paeth on 4 bytes
+{
+    constexpr uint32_t M = 0x00ff00ffu;
+    const uint32_t lo = paeth_pk16(a & M, b & M, c & M);
+    const uint32_t hi = paeth_pk16((a >> 8) & M, (b >> 8) & M, (c >> 8) & M);
+    return lo | hi << 8;
+}
+__device__ __forceinline__ uint32_t lane_above(uint32_t mine, uint32_t first)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)mine, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+// the 16 bytes that start BPP bytes before `x`, given the 8 bytes (pz, pw) that precede x
+template <int BPP>
+__device__ __forceinline__ u32x4 shifted(u32x4 x, uint32_t pz, uint32_t pw)
+{
+    u32x4 r;
+    if constexpr (BPP == 4) { r.x = pw; r.y = x.x; r.z = x.y; r.w = x.z; }
+    else if constexpr (BPP == 8) { r.x = pz; r.y = pw; r.z = x.x; r.w = x.y; }
+    else if constexpr (BPP < 4) {
+        constexpr int sh = 4 - BPP;
+        r.x = __builtin_amdgcn_alignbyte(x.x, pw, sh); r.y = __builtin_amdgcn_alignbyte(x.y, x.x, sh);
+        r.z = __builtin_amdgcn_alignbyte(x.z, x.y, sh); r.w = __builtin_amdgcn_alignbyte(x.w, x.z, sh);
+    } else {                                                   // BPP == 6
+        r.x = __builtin_amdgcn_alignbyte(pw, pz, 2); r.y = __builtin_amdgcn_alignbyte(x.x, pw, 2);
+        r.z = __builtin_amdgcn_alignbyte(x.y, x.x, 2); r.w = __builtin_amdgcn_alignbyte(x.z, x.y, 2);
+    }
+    return r;
+}
+
+template <int BPP>
+__device__ void filter_row_fast(const uint8_t *cur, const uint8_t *up, uint32_t pitch, uint8_t *out, int lane)
+{
+    uint32_t sc[5] = {0, 0, 0, 0, 0};
+    const uint32_t steps = pitch / 1024 + (pitch % 1024 ? 1 : 0);
+    // carry of the last 8 bytes of the previous 1 KiB step (lane 63 -> lane 0)
+    uint32_t cz = 0, cw = 0, uz = 0, uw = 0;
+    for (uint32_t it = 0; it < steps; ++it) {
+        const uint32_t j = (it * 64 + lane) * 16;
+        const bool live = j < pitch;
+        u32x4 x = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (live) { x = ((const U128u *)(cur + j))->v; if (up) b = ((const U128u *)(up + j))->v; }
+        const uint32_t pz = lane_above(x.z, cz), pw = lane_above(x.w, cw);
+        const uint32_t qz = lane_above(b.z, uz), qw = lane_above(b.w, uw);
+        cz = (uint32_t)__builtin_amdgcn_readlane((int)x.z, 63); cw = (uint32_t)__builtin_amdgcn_readlane((int)x.w, 63);
+        uz = (uint32_t)__builtin_amdgcn_readlane((int)b.z, 63); uw = (uint32_t)__builtin_amdgcn_readlane((int)b.w, 63);
+        const u32x4 a = shifted<BPP>(x, pz, pw), c = shifted<BPP>(b, qz, qw);
+        if (live) {
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, as[4] = {a.x, a.y, a.z, a.w};
+            const uint32_t bs[4] = {b.x, b.y, b.z, b.w}, cs[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sc[0] = sumabs8(xs[k], sc[0]);
+                sc[1] = sumabs8(sub8(xs[k], as[k]), sc[1]);
+                sc[2] = sumabs8(sub8(xs[k], bs[k]), sc[2]);
+                sc[3] = sumabs8(sub8(xs[k], __builtin_amdgcn_lerp(as[k], bs[k], 0u)), sc[3]);
+                sc[4] = sumabs8(sub8(xs[k], paeth8(as[k], bs[k], cs[k])), sc[4]);
+            }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 5; ++f)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sc[f] += __shfl_xor(sc[f], m, 64);
+    uint32_t best = 0, minimum = sc[0];
+#pragma unroll
+    for (int f = 1; f < 5; ++f) if (sc[f] < minimum) { minimum = sc[f]; best = f; }   // first strict minimum
+    if (lane == 0) out[0] = (uint8_t)best;
+    cz = cw = uz = uw = 0;
+    for (uint32_t it = 0; it < steps; ++it) {
+        const uint32_t j = (it * 64 + lane) * 16;
+        const bool live = j < pitch;
+        u32x4 x = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (live) { x = ((const U128u *)(cur + j))->v; if (up) b = ((const U128u *)(up + j))->v; }
+        const uint32_t pz = lane_above(x.z, cz), pw = lane_above(x.w, cw);
+        const uint32_t qz = lane_above(b.z, uz), qw = lane_above(b.w, uw);
+        cz = (uint32_t)__builtin_amdgcn_readlane((int)x.z, 63); cw = (uint32_t)__builtin_amdgcn_readlane((int)x.w, 63);
+        uz = (uint32_t)__builtin_amdgcn_readlane((int)b.z, 63); uw = (uint32_t)__builtin_amdgcn_readlane((int)b.w, 63);
+        const u32x4 a = shifted<BPP>(x, pz, pw), c = shifted<BPP>(b, qz, qw);
+        if (live) {
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, as[4] = {a.x, a.y, a.z, a.w};
+            const uint32_t bs[4] = {b.x, b.y, b.z, b.w}, cs[4] = {c.x, c.y, c.z, c.w};
+            uint32_t r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t pred = 0;
+                if (best == 1) pred = as[k];
+                else if (best == 2) pred = bs[k];
+                else if (best == 3) pred = __builtin_amdgcn_lerp(as[k], bs[k], 0u);
+                else if (best == 4) pred = paeth8(as[k], bs[k], cs[k]);
+                r[k] = sub8(xs[k], pred);
+            }
+            u32x4 v; v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3];
+            ((U128u *)(out + 1 + j))->v = v;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void filter_kernel(const FilterJob *__restrict__ jobs)
 {
     const FilterJob job = jobs[blockIdx.y];
@@ -53,7 +183,22 @@ __global__ __launch_bounds__(256) void filter_kernel(const FilterJob *__restrict
     const uint32_t volume = job.depth * job.channels, bpp = (volume + 7) >> 3;
     const bool direct = volume >= 8 && job.sx == 1 && job.sy == 1 && job.bx == 0 && job.by == 0 &&
                         job.sub_w == job.width;
+    const bool fast = direct && (job.pitch & 15) == 0 && bpp != 5 && bpp != 7;
     for (uint32_t y = blockIdx.x * 4 + wave; y < job.sub_h; y += gridDim.x * 4) {
+        if (fast) {
+            const uint8_t *cur = job.storage + (uint64_t)y * job.pitch;
+            const uint8_t *up = y ? cur - job.pitch : nullptr;
+            uint8_t *out = job.rows + (uint64_t)y * job.row_stride;
+            switch (bpp) {
+            case 1: filter_row_fast<1>(cur, up, job.pitch, out, lane); break;
+            case 2: filter_row_fast<2>(cur, up, job.pitch, out, lane); break;
+            case 3: filter_row_fast<3>(cur, up, job.pitch, out, lane); break;
+            case 4: filter_row_fast<4>(cur, up, job.pitch, out, lane); break;
+            case 6: filter_row_fast<6>(cur, up, job.pitch, out, lane); break;
+            default: filter_row_fast<8>(cur, up, job.pitch, out, lane); break;
+            }
+            continue;
+        }
         uint32_t sc[5] = {0, 0, 0, 0, 0};
         for (uint32_t j = lane; j < job.pitch; j += 64) {
             const uint32_t x = raw_byte(job, y, j, direct, volume, bpp);
