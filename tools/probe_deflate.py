@@ -1,4 +1,5 @@
 """GPU probe: deflate level 6 throughput on the benchmark's filtered rows."""
+import sys; sys.path.insert(0, ".")
 import sys, time, zlib
 import numpy as np, torch
 import swift_png_amd as spng

@@ -1,4 +1,5 @@
 """GPU probe: filter-select kernel throughput on distinct 4K rasters."""
+import sys; sys.path.insert(0, ".")
 import sys, numpy as np, torch
 import swift_png_amd as spng
 from swift_png_amd import synth

@@ -1,7 +1,8 @@
 """First-contact GPU probe: timing of unfilter and inflate on a few 4K images."""
+import sys; sys.path.insert(0, ".")
 import sys, time, zlib, ctypes
 import numpy as np, torch
-sys.path.insert(0, "tests")
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import swift_png_amd as spng
 from swift_png_amd import synth
 

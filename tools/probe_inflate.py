@@ -1,4 +1,5 @@
 """GPU probe: inflate throughput per stream on the benchmark's 4K streams."""
+import sys; sys.path.insert(0, ".")
 import sys, time, zlib
 import numpy as np, torch
 import swift_png_amd as spng

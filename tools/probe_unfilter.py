@@ -1,4 +1,5 @@
 """GPU probe: unfilter throughput on distinct 4K inputs (real HBM traffic)."""
+import sys; sys.path.insert(0, ".")
 import sys, time, zlib
 import numpy as np, torch
 import swift_png_amd as spng
