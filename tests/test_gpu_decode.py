@@ -429,3 +429,71 @@ def test_config5_shape_rgba16_adam7_multi_idat(gpu):
     assert st == 0 and storage == img.tobytes()
     png = ph.Png(w, h, 16, 6, True, False, z)
     assert (ph.orc_decode(png)[1] == img.reshape(-1)).all()
+
+
+def test_inflate_fuzz_mutated_streams(gpu):
+    """Differential fuzz: valid streams with a few bytes flipped, truncated, or spliced.  The device
+    path and the oracle must agree on status, output bytes and error payload for every one of them
+    (malformed input is where the reference's accept/reject rules differ from zlib's)."""
+    s = gpu.load()
+    rng = np.random.default_rng(1234)
+    seeds = []
+    for level in (1, 6, 9):
+        n = int(rng.integers(200, 6000))
+        data = (rng.integers(0, 256, n, dtype=np.uint8) * (rng.random(n) < 0.5)).astype(np.uint8).tobytes()
+        seeds.append(zlib.compress(data, level))
+        co = zlib.compressobj(level, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+        seeds.append(co.compress(data) + co.flush())
+    seeds.append(zlib.compress(rng.integers(0, 256, 3000, dtype=np.uint8).tobytes(), 0))
+    cases = []
+    for z in seeds:
+        for _ in range(40):
+            m = bytearray(z)
+            for _ in range(int(rng.integers(1, 4))):
+                i = int(rng.integers(0, len(m)))
+                m[i] ^= 1 << int(rng.integers(0, 8))
+            if rng.random() < 0.3:
+                m = m[:int(rng.integers(0, len(m)))]
+            cases.append(bytes(m))
+    n = len(cases)
+    cap = 1 << 16
+    outs, res = s.inflate_batch([s.to_device(c) for c in cases], [cap] * n)
+    statuses = set()
+    for c, o, r in zip(cases, outs, res):
+        st, out, consumed, aux = ph.orc_inflate(c, 0, cap)
+        statuses.add(st)
+        assert r.status == st, (r.status, st, c[:16].hex())
+        assert r.written == len(out) and bytes(o[:r.written].cpu().numpy()) == out
+        assert (r.aux[0], r.aux[1]) == aux
+        if st == 0:
+            assert r.consumed == consumed
+    assert len(statuses) >= 5                                 # the fuzz really reaches the error paths
+
+
+def test_unfilter_fuzz_shapes(gpu):
+    """Random geometry sweep (every format, both interlacing modes, widths around the 64-unit tile
+    and 64-row band boundaries), one batched call, against the oracle."""
+    s = gpu.load()
+    rng = np.random.default_rng(99)
+    descs, keep, wants = [], [], []
+    for _ in range(60):
+        depth, ch = FORMATS[int(rng.integers(0, len(FORMATS)))]
+        il = bool(rng.integers(0, 2))
+        w = int(rng.choice([1, 2, 31, 63, 64, 65, 127, 128, 129, 200, int(rng.integers(1, 300))]))
+        h = int(rng.choice([1, 2, 63, 64, 65, 128, 129, int(rng.integers(1, 200))]))
+        u = gpu.inflated_size(w, h, depth, ch, il)
+        rows = rng.integers(0, 256, u, dtype=np.uint8)
+        off = 0
+        for pitch, ph_rows in _passes(w, h, depth * ch, il):
+            for _y in range(ph_rows):
+                rows[off] = rng.integers(0, 5)
+                off += pitch + 1
+        st, want = ph.orc_unfilter(rows.tobytes(), w, h, depth, ch, il)
+        assert st == 0
+        rt, stt = s.to_device(rows), s.empty(gpu.storage_size(w, h, depth, ch))
+        keep.append((rt, stt)); wants.append(want)
+        descs.append(s.image_desc(None, rt, stt, w, h, depth, ch, il, rows_cap=u))
+    res = s.unfilter_batch(descs)
+    for (rt, stt), want, r in zip(keep, wants, res):
+        assert r.status == 0
+        assert bytes(stt[:len(want)].cpu().numpy()) == want.tobytes()
