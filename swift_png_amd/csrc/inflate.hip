@@ -10,27 +10,33 @@
 // with the same accept/reject behaviour and error vocabulary (status codes in spng_mi355.h).
 //
 // Design.  A DEFLATE stream is one serial dependency chain (the bit position of token k+1 depends
-// on token k), so the unit of parallelism is the stream: one 64-lane wave per stream, 4 waves per
-// CU -> 1024 streams in flight on the chip.  Inside the wave the chain is attacked two ways:
-//   * speculative literal runs: every lane looks up the lit/len LUT (LDS) at bit offset
-//     position + lane, all 64 offsets at once; the true chain of symbol boundaries through those
-//     64 bits is then resolved on the scalar unit (v_readlane hop per symbol, ~10 cycles instead
-//     of an LDS round trip per symbol), the lanes on the chain form a ballot-style mask, and each
-//     of them stores its literal at (output position + popcount(mask below me)).  One LDS latency
-//     therefore buys every literal that fits in 64 bits (6-8 for PNG residuals);
-//   * the token on which a run stops (match, end of block, long code) is decoded wave-uniformly
-//     from the same LUT entry; its LZ77 copy is done by all 64 lanes as a second, parallel pass
-//     (overlapping runs replicate via i mod distance).
-// Tables are LDS resident: a 2^9-entry lit/len LUT and a 2^8-entry distance LUT whose 32-bit
+// on token k), so the unit of parallelism is the stream, and the work on one stream is split into
+// the two halves that do not depend on each other's latency: a workgroup of two wavefronts per
+// stream, four workgroups per CU -> 1024 streams (2048 waves) in flight on the chip.
+//   * wave 0, the DECODER, turns bits into LZ77 tokens.  Every lane looks up the lit/len LUT (LDS)
+//     at bit offset position + lane and decodes the whole token that would start there (extra
+//     bits, distance code, extra bits), all 64 offsets at once; the true chain of token boundaries
+//     through those 64 bits is then resolved on the scalar unit (a v_readlane hop per token), and
+//     the lanes on the chain append their tokens (4 bytes each, stream order by popcount of the
+//     chain mask below the lane) to a 256-entry token queue in LDS.  The token on which a chain
+//     stops (end of block, long code, anything unusual) is decoded wave-uniformly with every check
+//     of the reference.  The decoder never touches the output.
+//   * wave 1, the RESOLVER, owns the 32 KiB output window (LDS ring = the whole DEFLATE window).
+//     It takes up to 64 tokens at a time, prefix-sums their lengths across the wave, stores all
+//     literals in one LDS write, then replays the back-references in stream order as LDS->LDS
+//     copies (overlapping runs replicate via i mod distance), flushes the ring to HBM in aligned
+//     4 KiB pieces with 16 B/lane coalesced stores and folds Adler-32 into the flush (v_sad_u8 /
+//     v_dot4 weighted sums), so the inflated bytes are never re-read.  Position-dependent checks
+//     (reference before the start of the stream, output capacity) live here.
+// The queue is a single-producer single-consumer ring: tokens are published by a tail counter and
+// released by a head counter, both in LDS; errors keep stream order because the resolver drains
+// everything the decoder queued before it looks at the decoder's final status.
+// Tables are LDS resident: a 2^10-entry lit/len LUT and a 2^8-entry distance LUT whose 32-bit
 // entries already carry base value + extra-bit count, and a canonical first-code/count fallback
 // for the rare longer codes.  They are rebuilt cooperatively per block (ballot/popcount ranking,
 // lanes fill LUT replicas in parallel) -- swift-png's own encoder emits a dynamic block every
-// <= 2047 tokens, so this is hot.  Compressed input is staged through a 2 KiB LDS ring with
-// coalesced 16 B/lane loads and read through a 6-dword register window; output goes to a 32 KiB
-// LDS ring (the whole DEFLATE window), so back-references are LDS->LDS copies, and is flushed to
-// HBM in aligned 4 KiB pieces with 16 B/lane coalesced stores; only references that reach beyond
-// 32 KiB - run go through HBM (already flushed).  Adler-32 is folded into the flush (v_sad_u8 /
-// v_dot4 weighted sums + wave reduction), so the inflated bytes are never re-read.
+// <= 2047 tokens, so this is hot.  Compressed input is staged through a 512-byte LDS ring with
+// coalesced 16 B/lane loads and read through a 6-dword register window.
 #include "common.hpp"
 
 namespace spng {
@@ -39,11 +45,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) U128u { u32x4 v; };
 
 static constexpr int RING = 32768;           // output window in LDS (power of two)
-static constexpr int INR = 1024;             // input ring (two 512-byte halves)
+static constexpr int INR = 512;              // input ring (two 256-byte halves)
 static constexpr int HALF = INR / 2;
 static constexpr int FLUSH = 4096;           // flush granularity
-static constexpr int WINOUT = 1024;          // most bytes one speculative window may produce
-// Literals of a window are stored before its back-references are resolved, up to WINOUT bytes
+static constexpr int WINOUT = 1024;          // most bytes one batch of tokens may produce
+static constexpr int QN = 256;               // token queue entries (power of two)
+// Literals of a batch are stored before its back-references are resolved, up to WINOUT bytes
 // ahead of a reference; a source is still intact in the ring if it is not further back than this.
 static constexpr uint32_t LDS_REACH = RING - WINOUT - 258 - 16;
 static constexpr int LBITS = 10, DBITS = 8, MBITS = 7;
@@ -52,13 +59,20 @@ static constexpr int LBITS = 10, DBITS = 8, MBITS = 7;
 // the whole bit reader and the symbol-boundary chain run on the scalar unit.
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)UNI(v >> 32) << 32 | UNI((uint32_t)v); }
+// A wave-uniform condition, said so to the compiler: its divergence analysis is conservative at
+// control-flow joins, and one branch it takes for lane-dependent turns every loop around it into
+// exec-mask bookkeeping.
+#define UB(c) (UNI((c) ? 1u : 0u) != 0u)
 
 // LUT entry: [3:0] code length (0 = longer than the LUT index), [7:4] extra bits,
-// [9:8] kind, [31:16] literal / base run / base distance.
+// [9:8] kind, [10] literal / [11] back-reference half that the speculative decoder may take without
+// any further check (a real code with a non-zero base), [31:16] literal / base run / base distance.
 enum { K_LIT = 0, K_EOB = 1, K_MATCH = 2, K_UNDEF = 3 };
+static constexpr uint32_t F_LIT = 1u << 10, F_REF = 1u << 11;
 __device__ __forceinline__ uint32_t entry(uint32_t len, uint32_t extra, uint32_t kind, uint32_t value)
 {
-    return len | extra << 4 | kind << 8 | value << 16;
+    const uint32_t fast = len == 0 ? 0u : kind == K_LIT ? F_LIT : (kind == K_MATCH && value != 0) ? F_REF : 0u;
+    return len | extra << 4 | kind << 8 | fast | value << 16;
 }
 
 // LZ77.Composites.swift:25-66 (run decades; symbols 286/287 are zero padding rows) in closed form
@@ -90,9 +104,23 @@ struct Tree {                    // canonical description for codes longer than 
     uint16_t first[16], count[16], offset[16];
 };
 
-struct Lds {                       // 40,208 bytes: four streams per CU
+// Token: literal = byte; back-reference = 1<<31 | run << 16 | distance; bit 30 = "the next `low 16
+// bits` bytes must fit the output" (stored blocks check their whole length up front).
+static constexpr uint32_t T_MATCH = 0x80000000u, T_CHECK = 0x40000000u;
+
+struct Ctrl {
+    uint32_t tail, head;           // tokens published by the decoder / released by the resolver
+    uint32_t a_done, b_fail;
+    int32_t  status;               // decoder's final status; SPNG_DONE + check => compare Adler-32
+    uint32_t check, declared, pad;
+    uint64_t aux0, aux1, bits;
+};
+
+struct Lds {                       // 40,816 bytes: four streams per CU
     uint8_t  ring[RING];
-    uint8_t  in[INR];
+    uint32_t q[QN + 4];            // + a slot nobody reads, so that stores need no branch
+    Ctrl     c;
+    uint8_t  in[INR + 16];         // + mirror of the first 16 bytes
     uint32_t lit[1 << LBITS];      // the code-length-code LUT (2^MBITS entries) lives here while a
                                    // dynamic header is parsed, i.e. before this table is built
     uint32_t dist[1 << DBITS];
@@ -101,6 +129,10 @@ struct Lds {                       // 40,208 bytes: four streams per CU
     uint8_t  lens[464];            // 286 + 32 code lengths + worst-case RLE overshoot (138)
     Tree     tlit, tdist;
 };
+
+// Only one wave of the workgroup builds tables; LDS operations of one wave execute in order, so a
+// compiler + counter fence is all the synchronisation the cooperative phases need.
+#define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -138,10 +170,10 @@ __device__ bool build(const uint8_t *lens, int n, uint32_t *lut, int lbits, uint
             const unsigned long long m = __ballot(s < n && lens[s] == 1);
             if (m) sym = base + __ffsll((long long)m) - 1;
         }
-        for (int j = lane; j < size; j += 64)
+        for (int j = lane; j - lane < size; j += 64)         // size is a multiple of 64: uniform trip count
             lut[j] = (used && !(j & 1)) ? (KIND == 1 ? dist_entry(sym, 1) : litlen_entry(sym, 1))
                                         : entry(1, 0, K_UNDEF, 0);
-        __syncthreads();
+        WSYNC();
         return true;
     }
     int interior = 1;
@@ -161,8 +193,8 @@ __device__ bool build(const uint8_t *lens, int n, uint32_t *lut, int lbits, uint
         for (int l = 1; l < 16; ++l) if (lane == l) { f = first[l]; c = cnt[l]; o = off[l]; }
         tree->first[lane] = (uint16_t)f; tree->count[lane] = (uint16_t)c; tree->offset[lane] = (uint16_t)o;
     }
-    for (int j = lane; j < size; j += 64) lut[j] = 0;      // 0 = "longer than lbits"
-    __syncthreads();
+    for (int j = lane; j - lane < size; j += 64) lut[j] = 0;      // 0 = "longer than lbits"
+    WSYNC();
 
     uint32_t run[16];
 #pragma unroll
@@ -187,17 +219,17 @@ __device__ bool build(const uint8_t *lens, int n, uint32_t *lut, int lbits, uint
             }
         }
     }
-    __syncthreads();
+    WSYNC();
     return true;
 }
 
-// Bit reader: a window of six consecutive stream dwords held in (wave-uniform) registers.
+// Bit reader.  The compressed stream is staged through a small LDS ring; a position is just a bit
+// index, every fetch reads three consecutive dwords at that position straight from the ring (the
+// ring carries a 16-byte mirror of its head so that a fetch never has to wrap), and advancing is an
+// addition plus a countdown to the next staging point.
 struct Reader {
-    uint32_t w0, w1, w2, w3, n0;         // dwords wd .. wd+4, pinned to scalar registers
-    uint32_t n1;                         // dword wd+5 as it came back from LDS (pinned one shift later,
-                                         // so that its latency never sits on the critical path)
-    uint64_t wd;                         // dword index of w0
-    uint32_t bit;                        // position inside w0, 0..31
+    uint64_t pos;                        // absolute bit position (wave-uniform)
+    int32_t  left;                       // bits until the position enters the half staged last
 };
 
 // stage HALF bytes of the stream starting at `from` (multiple of HALF) into the input ring; bytes
@@ -213,59 +245,57 @@ __device__ void stage(Lds &s, const uint8_t *src, uint64_t n, uint64_t from, int
             for (int k = 0; k < 16; ++k) if (off + k < n) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
             v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
         }
-        *(u32x4 *)(s.in + ((from + lane * 16) & (INR - 1))) = v;
+        const uint32_t at = (uint32_t)(from + lane * 16) & (INR - 1);
+        *(u32x4 *)(s.in + at) = v;
+        if (at == 0) *(u32x4 *)(s.in + INR) = v;               // the mirror
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    WSYNC();
 }
-__device__ __forceinline__ uint32_t dword_at(const Lds &s, uint64_t d)
-{
-    return *(const uint32_t *)(s.in + ((d * 4) & (INR - 1)));
-}
-
 __device__ __forceinline__ void seek(Lds &s, Reader &r, const uint8_t *src, uint64_t n, uint64_t byte, int lane)
 {
     const uint64_t h = byte & ~(uint64_t)(HALF - 1);
     stage(s, src, n, h, lane);
     stage(s, src, n, h + HALF, lane);
-    r.wd = uni64(byte >> 2); r.bit = UNI(8 * (uint32_t)(byte & 3));
-    r.w0 = UNI(dword_at(s, r.wd));     r.w1 = UNI(dword_at(s, r.wd + 1)); r.w2 = UNI(dword_at(s, r.wd + 2));
-    r.w3 = UNI(dword_at(s, r.wd + 3)); r.n0 = UNI(dword_at(s, r.wd + 4)); r.n1 = dword_at(s, r.wd + 5);
-}
-__device__ __forceinline__ void shift(Lds &s, Reader &r, const uint8_t *src, uint64_t n, int lane)
-{
-    r.w0 = r.w1; r.w1 = r.w2; r.w2 = r.w3; r.w3 = r.n0; r.n0 = UNI(r.n1);
-    r.wd = uni64(r.wd + 1);
-    const uint64_t d = r.wd + 5;
-    if (((d * 4) & (HALF - 1)) == 0) stage(s, src, n, d * 4, lane);
-    r.n1 = dword_at(s, d);
+    r.pos = uni64(byte * 8);
+    r.left = (int32_t)UNI((uint32_t)(h + HALF - byte) * 8);
 }
 __device__ __forceinline__ void advance(Lds &s, Reader &r, const uint8_t *src, uint64_t n, int lane, uint32_t k)
 {
-    r.bit = UNI(r.bit + k);
-    while (r.bit >= 32) { shift(s, r, src, n, lane); r.bit = UNI(r.bit - 32); }
+    r.pos = uni64(r.pos + k);                                  // k < 8 * HALF
+    r.left = (int32_t)UNI((uint32_t)r.left - k);
+    if (r.left <= 0) {
+        stage(s, src, n, ((r.pos >> 3) & ~(uint64_t)(HALF - 1)) + HALF, lane);
+        r.left = (int32_t)UNI((uint32_t)r.left + 8 * HALF);
+    }
 }
-__device__ __forceinline__ uint32_t peek32(const Reader &r) { return __builtin_amdgcn_alignbit(r.w1, r.w0, r.bit); }
-__device__ __forceinline__ uint64_t peek64(const Reader &r)
+// 64 stream bits starting at bit position `bit` (low 32 bits of the absolute position suffice)
+__device__ __forceinline__ void fetch64(const Lds &s, uint32_t bit, uint32_t &lo, uint32_t &hi)
 {
-    return (uint64_t)__builtin_amdgcn_alignbit(r.w2, r.w1, r.bit) << 32 | __builtin_amdgcn_alignbit(r.w1, r.w0, r.bit);
+    const uint32_t *w = (const uint32_t *)(s.in + ((bit >> 3) & (INR - 4)));
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+    lo = __builtin_amdgcn_alignbit(d1, d0, bit);
+    hi = __builtin_amdgcn_alignbit(d2, d1, bit);
 }
-// 32 stream bits starting `rel` bits after the current position (bit + rel <= 127)
-__device__ __forceinline__ uint32_t peek32_at(const Reader &r, uint32_t rel)
+__device__ __forceinline__ uint32_t peek32(const Lds &s, const Reader &r)
 {
-    const uint32_t a = r.w0, b = r.w1, c = r.w2, d = r.w3, e = r.n0;   // by value: stays in registers
-    const uint32_t off = r.bit + rel, sel = off >> 5;
-    const uint32_t lo = sel == 0 ? a : (sel == 1 ? b : (sel == 2 ? c : d));
-    const uint32_t hi = sel == 0 ? b : (sel == 1 ? c : (sel == 2 ? d : e));
-    return __builtin_amdgcn_alignbit(hi, lo, off & 31);
+    uint32_t lo, hi;
+    fetch64(s, (uint32_t)r.pos, lo, hi);
+    return UNI(lo);
+}
+__device__ __forceinline__ uint64_t peek64(const Lds &s, const Reader &r)
+{
+    uint32_t lo, hi;
+    fetch64(s, (uint32_t)r.pos, lo, hi);
+    return (uint64_t)UNI(hi) << 32 | UNI(lo);
 }
 #define TAKE(k) take(s, r, src, n, lane, (k))
 __device__ __forceinline__ uint32_t take(Lds &s, Reader &r, const uint8_t *src, uint64_t n, int lane, uint32_t k)
 {
-    const uint32_t v = peek32(r) & ((1u << k) - 1);          // k <= 16
+    const uint32_t v = peek32(s, r) & ((1u << k) - 1);       // k <= 16
     advance(s, r, src, n, lane, k);
     return v;
 }
-__device__ __forceinline__ uint64_t bitpos(const Reader &r) { return r.wd * 32 + r.bit; }
+__device__ __forceinline__ uint64_t bitpos(const Reader &r) { return r.pos; }
 
 // canonical decode of a code longer than the LUT index (uniform); `bits` = next >= 15 stream bits
 template <int KIND>
@@ -293,7 +323,23 @@ struct Out {
     uint32_t base;                                             // flushed mod 65521 (uniform)
 };
 
+#ifdef SPNG_INFLATE_PROF
+#define PROFC(x) ((x) += 1)
+#define PROF_DECL uint64_t pt[8] = {0,0,0,0,0,0,0,0}, pc[8] = {0,0,0,0,0,0,0,0}, p_t1 = 0;
+#define PROF_BEGIN() p_t1 = __builtin_readcyclecounter()
+#define PROF_END(k) do { pt[k] += __builtin_readcyclecounter() - p_t1; pc[k] += 1; } while (0)
+#else
+#define PROFC(x)
+#define PROF_DECL
+#define PROF_BEGIN()
+#define PROF_END(k)
+#endif
+#define COMPILER_ORDER() asm volatile("" ::: "memory")
 #define LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+#define LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LDS_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+static constexpr uint32_t SPIN_LIMIT = 1u << 24;               // a lost partner traps instead of hanging the GPU
 
 // flush ring bytes [flushed, upto) to HBM and fold them into the lane's Adler-32 accumulators
 __device__ __attribute__((always_inline)) void flush(Lds &s, Out &o, uint64_t upto, int lane)
@@ -368,36 +414,181 @@ __device__ __forceinline__ void copy_match(Lds &s, const Out &o, uint64_t pos, u
     }
 }
 
-#ifdef SPNG_INFLATE_PROF
-#define PROF_DECL uint64_t pt[8] = {0,0,0,0,0,0,0,0}, pc[8] = {0,0,0,0,0,0,0,0}, p_t0 = 0;
-#define PROF_BEGIN() p_t0 = __builtin_readcyclecounter()
-#define PROF_END(k) do { pt[k] += __builtin_readcyclecounter() - p_t0; pc[k] += 1; } while (0)
-#else
-#define PROF_DECL
-#define PROF_BEGIN()
-#define PROF_END(k)
-#endif
-#define FAIL(code, a0, a1) do { status = (code); aux0 = (a0); aux1 = (a1); goto done; } while (0)
-
-__global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restrict__ jobs,
-                                                     spng_result *__restrict__ results)
+// ------------------------------------------------------------------------------------------------
+// wave 1: the resolver
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((always_inline)) void resolver(Lds &s, uint8_t *dst, uint64_t dst_cap, uint64_t src_len,
+                                                        spng_result *__restrict__ result, int lane)
 {
-    __shared__ __attribute__((aligned(16))) Lds s;
-    const InflateJob job = jobs[blockIdx.x];
-    const int lane = threadIdx.x;
-    const uint8_t *src = job.src;
-    const uint64_t n = job.src_len, total = n * 8;
-    const unsigned long long below = (1ull << lane) - 1;
+    Out o = { dst, dst_cap, 0, 0, 0, 0, 0 };
+    uint32_t head = 0, spins = 0;
+#ifdef SPNG_INFLATE_PROF
+    uint64_t p_empty = 0, p_batches = 0, p_t0 = __builtin_readcyclecounter();
+#endif
+    int32_t status = SPNG_NEED_MORE_INPUT;
+    uint64_t aux0 = 0, aux1 = 0, bits = 0;
+    bool failed = false;
+
+    for (;;) {
+        uint32_t tail = UNI(LDS_LOAD(&s.c.tail));
+        if (tail == head) {
+            if (UNI(LDS_LOAD(&s.c.a_done))) {
+                LDS_ACQUIRE();
+                tail = UNI(LDS_LOAD(&s.c.tail));
+                if (tail == head) break;
+            } else {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) __builtin_trap();
+                PROFC(p_empty);
+                continue;
+            }
+        }
+        spins = 0;
+        PROFC(p_batches);
+        COMPILER_ORDER();
+        uint32_t m = tail - head < 64 ? tail - head : 64;
+        const uint32_t t = s.q[(head + lane) & (QN - 1)];
+        const bool is_match = (t & T_MATCH) != 0, is_check = (t & (T_MATCH | T_CHECK)) == T_CHECK;
+        const uint32_t run = (t >> 16) & 0x1ff, dist = t & 0xffff;
+        const uint32_t len = (uint32_t)lane >= m ? 0u : is_match ? run : is_check ? 0u : 1u;
+        // inclusive prefix sum of the token lengths: row scan on DPP, rows stitched on the scalar unit
+        uint32_t incl = len;
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, false);
+        incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, false);
+        {
+            const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+            const uint32_t r1 = r0 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+            const uint32_t r2 = r1 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 47);
+            incl += lane < 16 ? 0u : lane < 32 ? r0 : lane < 48 ? r1 : r2;
+        }
+        // a batch may run at most WINOUT bytes ahead of the references it still has to resolve
+        const unsigned long long over = __ballot(incl > WINOUT);
+        if (over) m = (uint32_t)__ffsll((long long)over) - 1;  // >= 1: a single token is <= 258 bytes
+        const uint32_t offs = incl - len;
+        const uint64_t at = o.pos + offs;
+        const uint32_t need = is_match ? run : is_check ? dist : 1u;
+        const bool bad_ref = is_match && (uint64_t)dist > at;
+        const unsigned long long bad = __ballot((uint32_t)lane < m && (bad_ref || at + need > o.cap));
+        if (bad) {
+            // InflatorBuffers.Stream.swift:352-366: the reference is validated before the capacity
+            m = (uint32_t)__ffsll((long long)bad) - 1;
+            status = __builtin_amdgcn_readlane(bad_ref ? SPNG_E_STRING_REFERENCE : SPNG_E_OUTPUT_CAPACITY, (int)m);
+            failed = true;
+        }
+        head = UNI(head + m + (failed ? 1u : 0u));
+        COMPILER_ORDER();                                      // the token loads were issued: release their slots
+        LDS_STORE(&s.c.head, head);
+        const bool mine = (uint32_t)lane < m;
+        // literals first (no token ever reads a later token's bytes) ...
+        if (mine && !is_match && !is_check) s.ring[at & (RING - 1)] = (uint8_t)t;
+        LDS_ORDER();
+        // ... then the back-references, in stream order
+        unsigned long long mm = __ballot(mine && is_match && run != 0);
+        while (mm) {
+            const int l = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)run, l);
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)dist, l);
+            const uint64_t dstpos = o.pos + (uint32_t)__builtin_amdgcn_readlane((int)offs, l);
+            copy_match(s, o, dstpos, cnt, off, lane);
+            LDS_ORDER();
+        }
+        const uint32_t produced = (uint32_t)__builtin_amdgcn_readlane((int)offs, (int)(m < 63 ? m : 63));
+        o.pos = uni64(o.pos + (m < 64 ? produced : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63)));
+        if (failed) break;
+        if (o.pos - o.flushed >= FLUSH) flush(s, o, o.pos & ~(uint64_t)15, lane);
+    }
+
+    if (failed) {
+        if (lane == 0) LDS_STORE(&s.c.b_fail, 1u);             // the decoder stops at its next full queue
+    } else {
+        status = (int32_t)UNI(s.c.status);
+        aux0 = uni64(s.c.aux0); aux1 = uni64(s.c.aux1); bits = uni64(s.c.bits);
+        if (status == SPNG_DONE && UNI(s.c.check)) {
+            // .checksum (InflatorBuffers.swift:112-130; Stream.swift:402-429)
+            flush(s, o, o.pos, lane);
+            const uint32_t declared = UNI(s.c.declared);
+            const uint32_t S = UNI(wave_sum(o.accS % 65521)) % 65521, I = UNI(wave_sum(o.accI)) % 65521;
+            const uint32_t N = (uint32_t)(o.pos % 65521);
+            const uint32_t computed = ((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
+            if (declared != computed) { status = SPNG_E_STREAM_CHECKSUM; aux0 = declared; aux1 = computed; }
+        }
+    }
+    flush(s, o, o.pos, lane);
+#ifdef SPNG_INFLATE_PROF
+    if (lane == 0 && blockIdx.x == 0)
+        printf("resolver: %llu batches (%.1f tokens each), %llu empty polls, %llu cycles\n", p_batches,
+               (double)head / (double)p_batches, p_empty, __builtin_readcyclecounter() - p_t0);
+#endif
+    if (lane == 0) {
+        spng_result &res = *result;
+        res.status = status; res.reserved = 0;
+        res.written = o.pos;
+        res.consumed = (bits + 7) / 8 > src_len ? src_len : (bits + 7) / 8;
+        res.aux[0] = aux0; res.aux[1] = aux1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave 0: the decoder
+// ------------------------------------------------------------------------------------------------
+struct Queue {
+    uint32_t tail, head_seen;
+#ifdef SPNG_INFLATE_PROF
+    uint64_t p_full, p_push;
+#endif
+};
+
+// appends the tokens of the lanes in `who` (stream order = lane order); false = the resolver gave up
+__device__ __forceinline__ bool push(Lds &s, Queue &q, unsigned long long who, uint32_t tok, int lane)
+{
+    const uint32_t k = UNI((uint32_t)__popcll(who));
+    uint32_t spins = 0;
+    q.tail = UNI(q.tail); q.head_seen = UNI(q.head_seen);
+    while (q.tail + k - q.head_seen > QN) {
+        q.head_seen = UNI(LDS_LOAD(&s.c.head));
+        if (q.tail + k - q.head_seen <= QN) break;
+        if (UNI(LDS_LOAD(&s.c.b_fail))) return false;
+        PROFC(q.p_full);
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > SPIN_LIMIT) __builtin_trap();
+    }
+    // LDS executes one wave's operations in issue order, so publishing needs no wait: the compiler
+    // only has to keep head load -> token store -> tail store in this order
+    COMPILER_ORDER();
+    PROFC(q.p_push);
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(who >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)who, 0));
+    s.q[(who >> lane) & 1 ? (q.tail + rank) & (QN - 1) : QN] = tok;      // q[QN]: write-only slot for idle lanes
+    q.tail = UNI(q.tail + k);
+    COMPILER_ORDER();
+    // every lane stores the same value to the same address: one LDS operation, and no lane-dependent
+    // branch for the compiler to fold into the (wave-uniform) return paths
+    LDS_STORE(&s.c.tail, q.tail);
+    return true;
+}
+
+#define FAIL(code, a0, a1) do { status = (code); aux0 = (a0); aux1 = (a1); goto done; } while (0)
+#define PUSH(who, tok) do { if (!push(s, q, (who), (tok), lane)) return; } while (0)
+
+__device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *src, uint64_t n, int32_t format, int lane)
+{
+    const uint64_t total = n * 8;
 
     int32_t status = SPNG_NEED_MORE_INPUT;
     uint64_t aux0 = 0, aux1 = 0;
+    uint32_t check = 0, declared = 0;
+    Queue q = {};
     PROF_DECL
-    Out o = { job.dst, job.dst_cap, 0, 0, 0, 0, 0 };
+#ifdef SPNG_INFLATE_PROF
+    const uint64_t p_t0 = __builtin_readcyclecounter();
+#endif
     Reader r;
     seek(s, r, src, n, 0, lane);
 
     // .initial (InflatorBuffers.swift:92-104, StreamHeader.swift:16-54)
-    if (job.format != SPNG_FORMAT_IOS) {
+    if (format != SPNG_FORMAT_IOS) {
         if (16 > total) goto done;
         const uint32_t cm = TAKE(4);
         if (cm != 8) FAIL(SPNG_E_COMPRESSION_METHOD, cm, 0);
@@ -421,27 +612,26 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
             const uint32_t l = TAKE(16);
             const uint32_t m = TAKE(16);
             if (l != (~m & 0xffffu)) FAIL(SPNG_E_BLOCK_COUNT_PARITY, l, m);
-            // readBlock(upTo:) (:384-399): copies as many of the LEN bytes as the input holds
+            // readBlock(upTo:) (:384-399): copies as many of the LEN bytes as the input holds, after
+            // making sure all of them fit the output
             const uint64_t from = boundary / 8 + 4;
-            const uint64_t have = n - from < l ? n - from : l;
-            if (o.pos + have > o.cap) FAIL(SPNG_E_OUTPUT_CAPACITY, 0, 0);
-            for (uint64_t done_ = 0; done_ < have;) {
-                const uint64_t piece = have - done_ < 1024 ? have - done_ : 1024;
-                for (uint64_t i = lane; i < piece; i += 64) s.ring[(o.pos + i) & (RING - 1)] = src[from + done_ + i];
-                LDS_ORDER();
-                o.pos = uni64(o.pos + piece); done_ += piece;
-                if (o.pos - o.flushed >= FLUSH) flush(s, o, o.pos & ~(uint64_t)15, lane);
+            const uint32_t have = n - from < l ? (uint32_t)(n - from) : l;
+            PUSH(1ull, T_CHECK | have);
+            for (uint32_t done_ = 0; done_ < have; done_ += 64) {
+                const uint32_t piece = have - done_ < 64 ? have - done_ : 64;
+                const uint32_t b = (uint32_t)lane < piece ? src[from + done_ + lane] : 0u;
+                PUSH(piece == 64 ? ~0ull : (1ull << piece) - 1, b);
             }
-            if (have < l) { r.wd = (n + 3) >> 2; r.bit = 0; goto done; }
+            if (have < l) { r.pos = n * 8; goto done; }
             seek(s, r, src, n, from + l, lane);
         } else if (type == 1 || type == 2) {
             if (type == 1) {
                 // fixed trees, HuffmanTree.swift:24-47
                 for (int i = lane; i < 288; i += 64) s.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-                __syncthreads();
+                WSYNC();
                 build<0>(s.lens, 288, s.lit, LBITS, s.sorted_lit, &s.tlit, false, lane);
                 for (int i = lane; i < 32; i += 64) s.lens[i] = 5;
-                __syncthreads();
+                WSYNC();
                 build<1>(s.lens, 32, s.dist, DBITS, s.sorted_dist, &s.tdist, false, lane);
             } else {
                 if (bitpos(r) - 3 + 17 > total) goto done;
@@ -451,14 +641,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
                 if (bitpos(r) + 3 * (uint64_t)codelengths > total) goto done;
                 if (literals > 286) FAIL(SPNG_E_RUNLITERAL_COUNT, literals, 0);
                 // 19 code-length-code lengths in zig-zag order (:120-125)
-                uint64_t packed = 0;                           // 19 x 3 bits = 57 bits
-                for (uint32_t i = 0; i < codelengths; ++i) packed |= (uint64_t)TAKE(3) << (3 * i);
+                const uint64_t packed = peek64(s, r) & ((1ull << (3 * codelengths)) - 1);   // 19 x 3 bits = 57 bits
+                advance(s, r, src, n, lane, 3 * codelengths);
                 if (lane < 19) {
                     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
                     s.lens[order[lane]] = (uint32_t)lane < codelengths ? (uint8_t)((packed >> (3 * lane)) & 7) : 0;
                 }
-                __syncthreads();
-                if (!build<2>(s.lens, 19, s.lit, MBITS, s.sorted_lit, &s.tlit, false, lane))
+                WSYNC();
+                if (!UB(build<2>(s.lens, 19, s.lit, MBITS, s.sorted_lit, &s.tlit, false, lane)))
                     FAIL(SPNG_E_CODELENGTH_TABLE, 0, 0);
 
                 // .tables: readBlockTables (:144-263), sequential RLE decode of the code lengths
@@ -466,13 +656,13 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
                 uint32_t have = 0, last = 0;
                 while (have < want) {
                     if (bitpos(r) >= total) goto done;
-                    const uint32_t bits = peek32(r);
+                    const uint32_t bits = peek32(s, r);
                     const uint32_t e = UNI(s.lit[bits & ((1 << MBITS) - 1)]);
                     const uint32_t len = e & 15, sym = e >> 16;
                     if (bitpos(r) + len > total) goto done;
                     if (sym < 16) {
                         advance(s, r, src, n, lane, len);
-                        if (lane == 0) s.lens[have] = (uint8_t)sym;
+                        s.lens[have] = (uint8_t)sym;            // every lane, same byte: no lane-dependent branch
                         last = sym; have += 1;
                         continue;
                     }
@@ -485,121 +675,103 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
                     if (bitpos(r) + len + extra > total) goto done;
                     const uint32_t reps = base + ((bits >> len) & ((1u << extra) - 1));
                     advance(s, r, src, n, lane, len + extra);
-                    for (uint32_t i = lane; i < reps; i += 64) s.lens[have + i] = (uint8_t)element;
+                    // reps <= 138: three unconditional stores; what lands beyond have + reps is either
+                    // rewritten by the following symbols or never read (branch-free on purpose)
+#pragma unroll
+                    for (uint32_t j = 0; j < 3; ++j) {
+                        const uint32_t at = have + lane + 64 * j;
+                        s.lens[at < sizeof(s.lens) - 1 ? at : sizeof(s.lens) - 1] = (uint8_t)element;
+                    }
                     last = element; have += reps;
                 }
-                __syncthreads();
+                WSYNC();
                 if (have != want) FAIL(SPNG_E_CODELENGTH_SEQUENCE, 0, 0);
-                const bool okd = build<1>(s.lens + literals, (int)distances, s.dist, DBITS, s.sorted_dist,
-                                          &s.tdist, true, lane);
-                const bool okl = build<0>(s.lens, (int)literals, s.lit, LBITS, s.sorted_lit, &s.tlit,
-                                          false, lane);
+                const bool okd = UB(build<1>(s.lens + literals, (int)distances, s.dist, DBITS, s.sorted_dist,
+                                             &s.tdist, true, lane));
+                const bool okl = UB(build<0>(s.lens, (int)literals, s.lit, LBITS, s.sorted_lit, &s.tlit,
+                                             false, lane));
                 if (!okl || !okd) FAIL(SPNG_E_HUFFMAN_TABLE, 0, 0);
             }
 
             PROF_END(6);
             // .compressed: readBlock(with:) (:266-381)
             for (;;) {
-                const uint64_t b0 = bitpos(r);
+                const uint64_t b0 = uni64(bitpos(r));
                 if (b0 >= total) goto done;
+                PROF_BEGIN();
                 // ---- speculative window: lane i decodes the whole token that would start at bit
                 //      b0 + i (lit/len LUT, extra bits, distance LUT, extra bits)
-                PROF_BEGIN();
-                const uint32_t lo = peek32_at(r, (uint32_t)lane), hi = peek32_at(r, (uint32_t)lane + 32);
+                uint32_t lo, hi;
+                fetch64(s, (uint32_t)b0 + (uint32_t)lane, lo, hi);
                 uint32_t e = s.lit[lo & ((1 << LBITS) - 1)];
-                const uint32_t len1 = e & 15, kind1 = (e >> 8) & 3, cx = (e >> 4) & 15;
+                const uint32_t len1 = e & 15, cx = (e >> 4) & 15;
                 const uint32_t run = (e >> 16) + ((lo >> len1) & ((1u << cx) - 1));
                 const uint32_t p2 = len1 + cx;                                   // <= 14
                 const uint32_t dbits = (uint32_t)(((uint64_t)hi << 32 | lo) >> p2);
                 const uint32_t d = s.dist[dbits & ((1 << DBITS) - 1)];
                 const uint32_t dl = d & 15, ox = (d >> 4) & 15;
                 const uint32_t dist = (d >> 16) + ((dbits >> dl) & ((1u << ox) - 1));
-                const bool is_lit = kind1 == K_LIT && len1 != 0;
                 // anything unusual (long codes, undefined codes, zero runs/offsets, end of block,
                 // tokens running past the input) ends the chain and is decoded the slow way
-                const bool is_match = kind1 == K_MATCH && len1 != 0 && dl != 0 && ((d >> 8) & 3) == K_MATCH &&
-                                      run != 0 && dist != 0;
+                const bool is_lit = (e & F_LIT) != 0;
+                const bool is_match = (e & d & F_REF) != 0;
                 const uint32_t tlen = is_lit ? len1 : p2 + dl + ox;              // <= 48
-                const bool ok = (is_lit || is_match) && b0 + lane + tlen <= total;
+                const uint64_t rem64 = total - b0;
+                const uint32_t rem = UNI(rem64 > 0xffffffffull ? 0xffffffffu : (uint32_t)rem64);
+                const bool ok = (is_lit || is_match) && (uint32_t)lane + tlen <= rem;
                 const uint32_t step = ok ? tlen : 0;
-                const uint32_t outlen = is_lit ? 1u : run;
+                const uint32_t tok = is_lit ? e >> 16 : T_MATCH | run << 16 | dist;
+                // successor on the chain; a lane that ends the chain (step 0) or leaves the window
+                // points at itself, so the walk below needs no conditions at all
+                const uint32_t nxt = (step != 0 && (uint32_t)lane + step < 64) ? (uint32_t)lane + step : (uint32_t)lane;
 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PROF_END(0); PROF_BEGIN();
-                // ---- resolve the true chain of token boundaries through the window (scalar unit)
-                uint32_t p = 0, acc = 0, offs = 0;
+                // ---- resolve the true chain of token boundaries through the window (scalar unit):
+                //      one v_readlane + one s_bitset per token
+                uint32_t p = 0;
                 unsigned long long chain = 0;
-                const uint64_t room = o.cap - o.pos;
-                const uint32_t maxout = UNI(room < WINOUT ? (uint32_t)room : (uint32_t)WINOUT);
-                // Taken scalar branches cost far more than the arithmetic here, so the walk is
-                // unrolled and branch-free.  A lane whose step is 0 is absorbing (p stops moving),
-                // the output budget is only checked afterwards (it almost never binds).
 #pragma unroll
-                for (int hop = 0; hop < 8; ++hop) {
-                    const uint32_t q = p < 63 ? p : 63;
-                    uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)q);
-                    const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)outlen, (int)q);
-                    st = p < 64 ? st : 0u;
-                    offs = ((uint32_t)lane == q) & (st != 0) ? acc : offs;
-                    chain |= st ? 1ull << q : 0ull;
-                    acc += st ? ol : 0u;
-                    p += st;
+                for (int hop = 0; hop < 10; ++hop) {
+                    asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p));
+                    p = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)p);
                 }
-                bool good = p < 64 && __builtin_amdgcn_readlane((int)step, (int)(p < 63 ? p : 63)) != 0;
-                if (acc > maxout) {                            // out of room (or > WINOUT bytes): walk again, carefully
-                    p = 0; acc = 0; chain = 0; good = true;
+                for (;;) {                                     // more than ten tokens in 64 bits: rare
+                    const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)p);
+                    if (np == p) break;
+                    asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p));
+                    p = np;
                 }
-                while (good && p < 64) {                       // more than eight tokens in 64 bits: rare
+                {
+                    // p is the lane the walk came to rest on: either the token that crosses the end
+                    // of the window (on the chain) or the first one the fast path cannot take
                     const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)p);
-                    if (!st) break;
-                    const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)outlen, (int)p);
-                    if (acc + ol > maxout) break;
-                    offs = (uint32_t)lane == p ? acc : offs;
-                    chain |= 1ull << p;
-                    acc += ol; p += st;
+                    chain = st ? chain | 1ull << p : chain & ~(1ull << p);
+                    p += st;
                 }
                 PROF_END(1);
                 if (chain) {
                     PROF_BEGIN();
-                    const bool mine = (chain >> lane) & 1;
-                    // literals first (no token ever reads a later token's bytes) ...
-                    if (mine && is_lit) s.ring[(o.pos + offs) & (RING - 1)] = (uint8_t)(e >> 16);
-                    LDS_ORDER();
-                    // ... then the back-references, in stream order
-                    unsigned long long mm = __ballot(mine && !is_lit);
-                    while (mm) {
-                        const int l = __ffsll((long long)mm) - 1;
-                        mm &= mm - 1;
-                        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)run, l);
-                        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)dist, l);
-                        const uint64_t at = o.pos + (uint32_t)__builtin_amdgcn_readlane((int)offs, l);
-                        if (off > at) { o.pos = uni64(at); FAIL(SPNG_E_STRING_REFERENCE, 0, 0); }
-                        copy_match(s, o, at, cnt, off, lane);
-                        LDS_ORDER();
-                    }
-                    o.pos = uni64(o.pos + acc);
+                    PUSH(chain, tok);
                     PROF_END(2); PROF_BEGIN();
                     advance(s, r, src, n, lane, p);
-                    PROF_END(3); PROF_BEGIN();
-                    if (o.pos - o.flushed >= FLUSH) flush(s, o, o.pos & ~(uint64_t)15, lane);
-                    PROF_END(4);
+                    PROF_END(3);
                     if (p >= 64) continue;                     // the chain used the whole window
                     if (bitpos(r) >= total) goto done;
                 }
                 e = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)p);   // LUT entry of the token the chain stopped on
 
-                // ---- that token, decoded wave-uniformly with every check of the reference
+                // ---- that token, decoded wave-uniformly with every check of the reference that
+                //      does not need the output position (those are the resolver's)
                 PROF_BEGIN();
                 const uint64_t b1 = bitpos(r);
-                uint64_t slug = peek64(r);
+                uint64_t slug = peek64(s, r);
                 if ((e & 15) == 0) e = decode_long<0>((uint32_t)slug, s.tlit, s.sorted_lit, LBITS);
                 const uint32_t len = e & 15, kind = (e >> 8) & 3;
                 if (kind == K_LIT) {
                     if (b1 + len > total) goto done;
-                    if (o.pos >= o.cap) FAIL(SPNG_E_OUTPUT_CAPACITY, 0, 0);
                     advance(s, r, src, n, lane, len);
-                    if (lane == 0) s.ring[o.pos & (RING - 1)] = (uint8_t)(e >> 16);
-                    o.pos = uni64(o.pos + 1);
+                    PUSH(1ull, e >> 16);
                 } else if (kind == K_EOB) {
                     if (b1 + len > total) goto done;
                     advance(s, r, src, n, lane, len);
@@ -617,17 +789,13 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
                     const uint32_t offset = (dd >> 16) + ((uint32_t)slug & ((1u << dx) - 1));
                     const uint32_t bits = len + ex + (dd & 15) + dx;     // <= 48
                     if (b1 + bits > total) goto done;
-                    if (offset > o.pos) FAIL(SPNG_E_STRING_REFERENCE, 0, 0);
+                    // offset > position is the resolver's check and comes first in the reference;
+                    // it cannot fire for offset 0, so this one may be raised here
                     if (count && !offset) FAIL(SPNG_E_REFERENCE_UNDEFINED, 0, 0);
-                    if (o.pos + count > o.cap) FAIL(SPNG_E_OUTPUT_CAPACITY, 0, 0);
                     advance(s, r, src, n, lane, bits);
-                    LDS_ORDER();
-                    copy_match(s, o, o.pos, count, offset, lane);
-                    LDS_ORDER();
-                    o.pos = uni64(o.pos + count);
+                    PUSH(1ull, T_MATCH | count << 16 | offset);
                 }
                 PROF_END(5);
-                if (o.pos - o.flushed >= FLUSH) flush(s, o, o.pos & ~(uint64_t)15, lane);
             }
         } else {
             FAIL(SPNG_E_BLOCK_TYPE, type, 0);
@@ -635,41 +803,54 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *__restric
         if (bfinal) break;
     }
 
-    // .checksum (InflatorBuffers.swift:112-130; Stream.swift:402-429)
-    if (job.format != SPNG_FORMAT_IOS) {
+    // .checksum (InflatorBuffers.swift:112-130; Stream.swift:402-429): compared by the resolver
+    if (format != SPNG_FORMAT_IOS) {
         const uint64_t boundary = (bitpos(r) + 7) & ~(uint64_t)7;
         if (boundary + 32 > total) goto done;
         TAKE((uint32_t)(boundary - bitpos(r)));
-        uint32_t declared = 0;
         for (int k = 0; k < 4; ++k) declared = declared << 8 | TAKE(8);
-        flush(s, o, o.pos, lane);
-        const uint32_t S = UNI(wave_sum(o.accS % 65521)) % 65521, I = UNI(wave_sum(o.accI)) % 65521;
-        const uint32_t N = (uint32_t)(o.pos % 65521);
-        const uint32_t computed = ((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
-        if (declared != computed) FAIL(SPNG_E_STREAM_CHECKSUM, declared, computed);
+        check = 1;
     }
     status = SPNG_DONE;
 done:
-    flush(s, o, o.pos, lane);
 #ifdef SPNG_INFLATE_PROF
     if (lane == 0 && blockIdx.x == 0)
-        printf("prof cycles/count: spec %llu/%llu chain %llu/%llu emit %llu/%llu advance %llu/%llu flush %llu/%llu slow %llu/%llu header %llu/%llu\n",
-               pt[0], pc[0], pt[1], pc[1], pt[2], pc[2], pt[3], pc[3], pt[4], pc[4], pt[5], pc[5], pt[6], pc[6]);
+        printf("decoder: %llu pushes (%.2f tokens each), %llu full polls, %llu cycles\n"
+               "  cycles/count: spec %llu/%llu chain %llu/%llu push %llu/%llu advance %llu/%llu slow %llu/%llu header %llu/%llu\n",
+               q.p_push, (double)q.tail / (double)q.p_push, q.p_full, __builtin_readcyclecounter() - p_t0,
+               pt[0], pc[0], pt[1], pc[1], pt[2], pc[2], pt[3], pc[3], pt[5], pc[5], pt[6], pc[6]);
 #endif
     if (lane == 0) {
-        spng_result &res = results[job.image];
-        res.status = status; res.reserved = 0;
-        res.written = o.pos;
-        const uint64_t bp = bitpos(r);
-        res.consumed = (bp + 7) / 8 > n ? n : (bp + 7) / 8;
-        res.aux[0] = aux0; res.aux[1] = aux1;
+        s.c.status = status; s.c.check = check; s.c.declared = declared;
+        s.c.aux0 = aux0; s.c.aux1 = aux1; s.c.bits = bitpos(r);
     }
+    LDS_ORDER();
+    if (lane == 0) LDS_STORE(&s.c.a_done, 1u);
+}
+
+__global__ __launch_bounds__(128) void inflate_kernel(const InflateJob *__restrict__ jobs,
+                                                      spng_result *__restrict__ results)
+{
+    __shared__ __attribute__((aligned(16))) Lds s;
+    // job fields are wave-uniform: pin them to scalar registers so that everything derived from
+    // them (positions, loop conditions) stays on the scalar unit
+    const InflateJob *job = jobs + blockIdx.x;
+    const uint8_t *src = (const uint8_t *)uni64((uint64_t)job->src);
+    uint8_t *dst = (uint8_t *)uni64((uint64_t)job->dst);
+    const uint64_t src_len = uni64(job->src_len), dst_cap = uni64(job->dst_cap);
+    const int32_t format = (int32_t)UNI(job->format);
+    const uint32_t image = UNI(job->image);
+    if (threadIdx.x == 0) { s.c.tail = 0; s.c.head = 0; s.c.a_done = 0; s.c.b_fail = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    if (UNI(threadIdx.x >> 6) == 0) decoder(s, src, src_len, format, lane);
+    else                            resolver(s, dst, dst_cap, src_len, results + image, lane);
 }
 
 hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream)
 {
     if (!count) return hipSuccess;
-    inflate_kernel<<<count, 64, 0, stream>>>(d_jobs, d_results);
+    inflate_kernel<<<count, 128, 0, stream>>>(d_jobs, d_results);
     return hipGetLastError();
 }
 
