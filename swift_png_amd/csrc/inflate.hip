@@ -297,19 +297,20 @@ __device__ __forceinline__ uint32_t take(Lds &s, Reader &r, const uint8_t *src, 
 }
 __device__ __forceinline__ uint64_t bitpos(const Reader &r) { return r.pos; }
 
-// canonical decode of a code longer than the LUT index (uniform); `bits` = next >= 15 stream bits
+// canonical decode of a code longer than the LUT index; `bits` = next >= 15 stream bits (uniform).
+// Lane l tries code length l, the shortest hit wins.
 template <int KIND>
-__device__ __forceinline__ uint32_t decode_long(uint32_t bits, const Tree &t, const uint16_t *sorted, int lbits)
+__device__ __forceinline__ uint32_t decode_long(uint32_t bits, const Tree &t, const uint16_t *sorted, int lbits, int lane)
 {
     const uint32_t v = __brev(bits) >> 17;                     // next 15 bits, MSB first
-    for (int l = lbits + 1; l < 16; ++l) {
-        const uint32_t d = (v >> (15 - l)) - UNI(t.first[l]);
-        if (d < UNI(t.count[l])) {
-            const uint32_t sym = UNI(sorted[UNI(t.offset[l]) + d]);
-            return KIND == 0 ? litlen_entry(sym, l) : dist_entry(sym, l);
-        }
-    }
-    return entry(15, 0, K_UNDEF, 0);                           // unreachable for complete codes
+    const uint32_t l = (uint32_t)lane & 15;
+    const uint32_t d = (v >> (15 - l)) - t.first[l];
+    const unsigned long long hit = __ballot(lane < 16 && (int)l > lbits && d < t.count[l]);
+    if (!hit) return entry(15, 0, K_UNDEF, 0);                 // unreachable for complete codes
+    const int len = __ffsll((long long)hit) - 1;
+    const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)(t.offset[l] + d), len);
+    const uint32_t sym = UNI(sorted[at]);
+    return KIND == 0 ? litlen_entry(sym, (uint32_t)len) : dist_entry(sym, (uint32_t)len);
 }
 
 struct Out {
@@ -541,19 +542,22 @@ struct Queue {
 #endif
 };
 
-// appends the tokens of the lanes in `who` (stream order = lane order); false = the resolver gave up
-__device__ __forceinline__ bool push(Lds &s, Queue &q, unsigned long long who, uint32_t tok, int lane)
+// appends the tokens of the lanes in `who` (stream order = lane order).  Single exit on purpose: a
+// return from inside the wait loop makes the compiler guard everything after it.  If the resolver
+// has given up (it has already written the result) the queue is treated as empty and the decoder
+// simply runs to the end of the stream; nobody reads what it queues.
+__device__ __forceinline__ void push(Lds &s, Queue &q, unsigned long long who, uint32_t tok, int lane)
 {
-    const uint32_t k = UNI((uint32_t)__popcll(who));
-    uint32_t spins = 0;
-    q.tail = UNI(q.tail); q.head_seen = UNI(q.head_seen);
-    while (q.tail + k - q.head_seen > QN) {
-        q.head_seen = UNI(LDS_LOAD(&s.c.head));
-        if (q.tail + k - q.head_seen <= QN) break;
-        if (UNI(LDS_LOAD(&s.c.b_fail))) return false;
-        PROFC(q.p_full);
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > SPIN_LIMIT) __builtin_trap();
+    const uint32_t k = (uint32_t)__popcll(who);
+    if (__builtin_expect(q.tail + k - q.head_seen > QN, 0)) {
+        for (uint32_t spins = 0;; ++spins) {
+            q.head_seen = UNI(LDS_LOAD(&s.c.head));
+            if (q.tail + k - q.head_seen <= QN) break;
+            if (UNI(LDS_LOAD(&s.c.b_fail))) { q.head_seen = q.tail; break; }
+            PROFC(q.p_full);
+            __builtin_amdgcn_s_sleep(1);
+            if (spins > SPIN_LIMIT) __builtin_trap();
+        }
     }
     // LDS executes one wave's operations in issue order, so publishing needs no wait: the compiler
     // only has to keep head load -> token store -> tail store in this order
@@ -564,13 +568,12 @@ __device__ __forceinline__ bool push(Lds &s, Queue &q, unsigned long long who, u
     q.tail = UNI(q.tail + k);
     COMPILER_ORDER();
     // every lane stores the same value to the same address: one LDS operation, and no lane-dependent
-    // branch for the compiler to fold into the (wave-uniform) return paths
+    // branch for the compiler to fold into wave-uniform control flow
     LDS_STORE(&s.c.tail, q.tail);
-    return true;
 }
 
 #define FAIL(code, a0, a1) do { status = (code); aux0 = (a0); aux1 = (a1); goto done; } while (0)
-#define PUSH(who, tok) do { if (!push(s, q, (who), (tok), lane)) return; } while (0)
+#define PUSH(who, tok) push(s, q, (who), (tok), lane)
 
 __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *src, uint64_t n, int32_t format, int lane)
 {
@@ -727,28 +730,48 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *sr
 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 PROF_END(0); PROF_BEGIN();
-                // ---- resolve the true chain of token boundaries through the window (scalar unit):
-                //      one v_readlane + one s_bitset per token
-                uint32_t p = 0;
-                unsigned long long chain = 0;
-#pragma unroll
-                for (int hop = 0; hop < 10; ++hop) {
-                    asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p));
-                    p = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)p);
-                }
-                for (;;) {                                     // more than ten tokens in 64 bits: rare
-                    const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)p);
-                    if (np == p) break;
-                    asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p));
-                    p = np;
-                }
+                // ---- resolve the true chain of token boundaries through the window.
+                // A hop (VALU writes an SGPR, the next v_readlane uses it as its lane select) costs
+                // ~50 cycles of pure latency, so the walk goes two tokens at a time over the squared
+                // successor map (one ds_bpermute), picking up the odd positions with independent
+                // reads that overlap the next hop.  Written out in assembly because the scheduler
+                // otherwise interleaves SALU work between the hops, which makes every one of them
+                // wait for the vector pipeline to drain (s_nop 2 + the odd read = the 4 wait states
+                // of the lane-select hazard).
+                const uint32_t nxt2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxt << 2), (int)nxt);
+                const unsigned long long live = __ballot(step != 0);   // lanes the fast path can take
+                uint32_t p, t7;
+                unsigned long long chain;
                 {
-                    // p is the lane the walk came to rest on: either the token that crosses the end
-                    // of the window (on the chain) or the first one the fast path cannot take
-                    const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)p);
-                    chain = st ? chain | 1ull << p : chain & ~(1ull << p);
-                    p += st;
+                    uint32_t t1, t2, t3, t4, t5, t6;
+                    asm volatile(
+                        "v_readlane_b32 %3, %10, 0\n\tv_readlane_b32 %2, %9, 0\n\ts_nop 2\n\t"
+                        "v_readlane_b32 %5, %10, %3\n\tv_readlane_b32 %4, %9, %3\n\ts_nop 2\n\t"
+                        "v_readlane_b32 %7, %10, %5\n\tv_readlane_b32 %6, %9, %5\n\ts_nop 2\n\t"
+                        "v_readlane_b32 %1, %10, %7\n\tv_readlane_b32 %8, %9, %7\n\t"
+                        "s_mov_b64 %0, 1\n\t"
+                        "s_bitset1_b64 %0, %2\n\ts_bitset1_b64 %0, %3\n\ts_bitset1_b64 %0, %4\n\t"
+                        "s_bitset1_b64 %0, %5\n\ts_bitset1_b64 %0, %6\n\ts_bitset1_b64 %0, %7\n\t"
+                        "s_bitset1_b64 %0, %8"
+                        : "=&s"(chain), "=&s"(p), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5),
+                          "=&s"(t6), "=&s"(t7)
+                        : "v"(nxt), "v"(nxt2));
                 }
+                if (__builtin_expect(p != t7, 0)) {            // not at rest after eight tokens: rare
+                    for (;;) {
+                        const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)p);
+                        if (np == p) break;
+                        asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p));
+                        p = np;
+                    }
+                }
+                // p is the lane the walk came to rest on: either the token that crosses the end of
+                // the window (on the chain) or the first one the fast path cannot take.  Its length
+                // is only needed for the advance, after the tokens are queued.
+                const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)p);
+                chain = (chain & ~(1ull << p)) | (live & 1ull << p);
+                const uint32_t rest = p;
+                p += st;
                 PROF_END(1);
                 if (chain) {
                     PROF_BEGIN();
@@ -759,14 +782,14 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *sr
                     if (p >= 64) continue;                     // the chain used the whole window
                     if (bitpos(r) >= total) goto done;
                 }
-                e = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)p);   // LUT entry of the token the chain stopped on
+                e = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)rest);   // LUT entry of the token the chain stopped on
 
                 // ---- that token, decoded wave-uniformly with every check of the reference that
                 //      does not need the output position (those are the resolver's)
                 PROF_BEGIN();
                 const uint64_t b1 = bitpos(r);
                 uint64_t slug = peek64(s, r);
-                if ((e & 15) == 0) e = decode_long<0>((uint32_t)slug, s.tlit, s.sorted_lit, LBITS);
+                if ((e & 15) == 0) e = decode_long<0>((uint32_t)slug, s.tlit, s.sorted_lit, LBITS, lane);
                 const uint32_t len = e & 15, kind = (e >> 8) & 3;
                 if (kind == K_LIT) {
                     if (b1 + len > total) goto done;
@@ -782,7 +805,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *sr
                     const uint32_t count = (e >> 16) + ((uint32_t)slug & ((1u << ex) - 1));
                     slug >>= ex;
                     uint32_t dd = UNI(s.dist[(uint32_t)slug & ((1 << DBITS) - 1)]);
-                    if ((dd & 15) == 0) dd = decode_long<1>((uint32_t)slug, s.tdist, s.sorted_dist, DBITS);
+                    if ((dd & 15) == 0) dd = decode_long<1>((uint32_t)slug, s.tdist, s.sorted_dist, DBITS, lane);
                     if (((dd >> 8) & 3) == K_UNDEF) FAIL(SPNG_E_REFERENCE_UNDEFINED, 0, 0);
                     slug >>= dd & 15;
                     const uint32_t dx = (dd >> 4) & 15;
