@@ -116,7 +116,7 @@ struct Ctrl {
     uint64_t aux0, aux1, bits;
 };
 
-struct Lds {                       // 40,816 bytes: four streams per CU
+struct Lds {                       // 40,944 bytes: four streams per CU
     uint8_t  ring[RING];
     uint32_t q[QN + 4];            // + a slot nobody reads, so that stores need no branch
     Ctrl     c;
@@ -128,11 +128,13 @@ struct Lds {                       // 40,816 bytes: four streams per CU
     uint16_t sorted_dist[32];
     uint8_t  lens[464];            // 286 + 32 code lengths + worst-case RLE overshoot (138)
     Tree     tlit, tdist;
+    uint32_t hist[16], run[16];    // table construction: symbols per code length, ranked so far
 };
 
 // Only one wave of the workgroup builds tables; LDS operations of one wave execute in order, so a
 // compiler + counter fence is all the synchronisation the cooperative phases need.
 #define WSYNC() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup", "local")
+#define COMPILER_ORDER() asm volatile("" ::: "memory")
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -141,33 +143,48 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// inclusive prefix sum inside each row of 16 lanes (DPP row_shr 1, 2, 4, 8; lanes without a source add 0)
+__device__ __forceinline__ uint32_t row_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    return v;
+}
+
 // Builds LUT + canonical fallback for `n` code lengths (lens[], LDS).  KIND: 0 lit/len, 1 distance,
 // 2 code-length code.  Returns false when the code is not complete (HuffmanTree.size, :80-108).
 // `normalizing` restates validate(symbols:normalizing:) (:112-135): 0 or 1 used symbol of length 1
 // gives a stub whose unused half the reference leaves uninitialised (K_UNDEF here).
+//
+// Everything per code length lives in lane l of a vector register (or in 16-entry LDS arrays), never
+// in 16-element wave-uniform arrays: those end up in scalar registers and crowd the decoder's
+// loop-carried state out into spill slots.
 template <int KIND>
-__device__ bool build(const uint8_t *lens, int n, uint32_t *lut, int lbits, uint16_t *sorted, Tree *tree,
-                      bool normalizing, int lane)
+__device__ __attribute__((always_inline)) bool build(Lds &s, const uint8_t *lens, int n, uint32_t *lut, int lbits,
+                                                     uint16_t *sorted, Tree *tree, bool normalizing, int lane)
 {
-    uint32_t cnt[16];
-#pragma unroll
-    for (int l = 0; l < 16; ++l) cnt[l] = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int s = base + lane;
-        const uint32_t my = s < n ? lens[s] : 0;
-#pragma unroll
-        for (int l = 1; l < 16; ++l) cnt[l] += __popcll(__ballot(my == (uint32_t)l));
-    }
-    uint32_t used = 0;
-#pragma unroll
-    for (int l = 1; l < 16; ++l) used += cnt[l];
     const int size = 1 << lbits;
-    if (normalizing && (used == 0 || (used == 1 && cnt[1] == 1))) {
+    // ---- histogram of the code lengths (LDS atomics), lane l <- count of length l
+    if (lane < 16) { s.hist[lane] = 0; s.run[lane] = 0; }
+    WSYNC();
+    uint32_t used = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int sym = base + lane;
+        const uint32_t my = sym < n ? lens[sym] : 0;
+        __hip_atomic_fetch_add(&s.hist[my], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // hist[0] is ignored
+        used += (uint32_t)__popcll(__ballot(my != 0));
+    }
+    WSYNC();
+    const uint32_t c = (lane >= 1 && lane < 16) ? s.hist[lane] : 0u;
+    const uint32_t cnt1 = (uint32_t)__builtin_amdgcn_readlane((int)c, 1);
+    if (normalizing && (used == 0 || (used == 1 && cnt1 == 1))) {
         // stub tree (HuffmanTree.swift:52-65)
         uint32_t sym = 0;
         for (int base = 0; base < n; base += 64) {
-            const int s = base + lane;
-            const unsigned long long m = __ballot(s < n && lens[s] == 1);
+            const int at = base + lane;
+            const unsigned long long m = __ballot(at < n && lens[at] == 1);
             if (m) sym = base + __ffsll((long long)m) - 1;
         }
         for (int j = lane; j - lane < size; j += 64)         // size is a multiple of 64: uniform trip count
@@ -176,50 +193,46 @@ __device__ bool build(const uint8_t *lens, int n, uint32_t *lut, int lbits, uint
         WSYNC();
         return true;
     }
-    int interior = 1;
-#pragma unroll
-    for (int l = 1; l < 16; ++l) interior = 2 * interior - (int)cnt[l];
-    if (interior != 0) return false;
+    // complete <=> Kraft sum is exactly 1: sum of count[l] << (15 - l) == 1 << 15 (the interior-node
+    // recurrence of the reference, interior = 2 * interior - count[l], is linear in the counts)
+    const uint32_t scaled = c << (15 - (lane & 15));           // c is 0 outside lanes 1..15
+    if (UNI(wave_sum(scaled)) != 32768u) return false;
 
-    uint32_t first[16], off[16];
-    {
-        uint32_t code = 0, o = 0;
-#pragma unroll
-        for (int l = 1; l < 16; ++l) { first[l] = code; off[l] = o; code = (code + cnt[l]) << 1; o += cnt[l]; }
-    }
-    if (lane < 16 && lane > 0) {
-        uint32_t f = 0, c = 0, o = 0;
-#pragma unroll
-        for (int l = 1; l < 16; ++l) if (lane == l) { f = first[l]; c = cnt[l]; o = off[l]; }
-        tree->first[lane] = (uint16_t)f; tree->count[lane] = (uint16_t)c; tree->offset[lane] = (uint16_t)o;
+    // canonical first code and first sorted slot of each length: exclusive prefix sums over lanes 0..15
+    const uint32_t off = row_scan(c) - c;
+    const uint32_t first = (row_scan(scaled) - scaled) >> (15 - (lane & 15));
+    if (lane >= 1 && lane < 16) {
+        tree->first[lane] = (uint16_t)first; tree->count[lane] = (uint16_t)c; tree->offset[lane] = (uint16_t)off;
     }
     for (int j = lane; j - lane < size; j += 64) lut[j] = 0;      // 0 = "longer than lbits"
     WSYNC();
 
-    uint32_t run[16];
-#pragma unroll
-    for (int l = 0; l < 16; ++l) run[l] = 0;
-    const unsigned long long below = (1ull << lane) - 1;
+    // ---- canonical codes: rank of a symbol among the symbols of its length, in symbol order
     for (int base = 0; base < n; base += 64) {
-        const int s = base + lane;
-        const uint32_t my = s < n ? lens[s] : 0;
-        uint32_t rank = 0, f = 0, o = 0;
+        const int sym = base + lane;
+        const uint32_t my = sym < n ? lens[sym] : 0;
+        // lanes of this batch with the same length as mine: radix match over the 4 bits of a length
+        unsigned long long same = ~0ull;
 #pragma unroll
-        for (int l = 1; l < 16; ++l) {
-            const unsigned long long m = __ballot(my == (uint32_t)l);
-            if (my == (uint32_t)l) { rank = run[l] + __popcll(m & below); f = first[l]; o = off[l]; }
-            run[l] += __popcll(m);
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long bk = __ballot((my >> k) & 1);
+            same &= (my >> k) & 1 ? bk : ~bk;
         }
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)same, 0));
+        const uint32_t rank = s.run[my] + before;             // + those of earlier batches
+        const uint32_t f = tree->first[my], o = tree->offset[my];
+        COMPILER_ORDER();
+        if (before == 0) s.run[my] += (uint32_t)__popcll(same);      // one lane per length updates the tally
         if (my) {
-            const uint32_t e = KIND == 0 ? litlen_entry(s, my) : KIND == 1 ? dist_entry(s, my) : meta_entry(s, my);
-            sorted[o + rank] = (uint16_t)s;
+            const uint32_t e = KIND == 0 ? litlen_entry(sym, my) : KIND == 1 ? dist_entry(sym, my) : meta_entry(sym, my);
+            sorted[o + rank] = (uint16_t)sym;
             if ((int)my <= lbits) {
                 const uint32_t rev = __brev(f + rank) >> (32 - my);
                 for (int j = rev; j < size; j += 1 << my) lut[j] = e;
             }
         }
+        WSYNC();
     }
-    WSYNC();
     return true;
 }
 
@@ -297,20 +310,18 @@ __device__ __forceinline__ uint32_t take(Lds &s, Reader &r, const uint8_t *src, 
 }
 __device__ __forceinline__ uint64_t bitpos(const Reader &r) { return r.pos; }
 
-// canonical decode of a code longer than the LUT index; `bits` = next >= 15 stream bits (uniform).
-// Lane l tries code length l, the shortest hit wins.
 template <int KIND>
 __device__ __forceinline__ uint32_t decode_long(uint32_t bits, const Tree &t, const uint16_t *sorted, int lbits, int lane)
 {
     const uint32_t v = __brev(bits) >> 17;                     // next 15 bits, MSB first
-    const uint32_t l = (uint32_t)lane & 15;
-    const uint32_t d = (v >> (15 - l)) - t.first[l];
-    const unsigned long long hit = __ballot(lane < 16 && (int)l > lbits && d < t.count[l]);
-    if (!hit) return entry(15, 0, K_UNDEF, 0);                 // unreachable for complete codes
-    const int len = __ffsll((long long)hit) - 1;
-    const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)(t.offset[l] + d), len);
-    const uint32_t sym = UNI(sorted[at]);
-    return KIND == 0 ? litlen_entry(sym, (uint32_t)len) : dist_entry(sym, (uint32_t)len);
+    for (int l = lbits + 1; l < 16; ++l) {
+        const uint32_t d = (v >> (15 - l)) - UNI(t.first[l]);
+        if (d < UNI(t.count[l])) {
+            const uint32_t sym = UNI(sorted[UNI(t.offset[l]) + d]);
+            return KIND == 0 ? litlen_entry(sym, l) : dist_entry(sym, l);
+        }
+    }
+    return entry(15, 0, K_UNDEF, 0);                           // unreachable for complete codes
 }
 
 struct Out {
@@ -335,7 +346,6 @@ struct Out {
 #define PROF_BEGIN()
 #define PROF_END(k)
 #endif
-#define COMPILER_ORDER() asm volatile("" ::: "memory")
 #define LDS_ORDER() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 #define LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
 #define LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -632,10 +642,10 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *sr
                 // fixed trees, HuffmanTree.swift:24-47
                 for (int i = lane; i < 288; i += 64) s.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
                 WSYNC();
-                build<0>(s.lens, 288, s.lit, LBITS, s.sorted_lit, &s.tlit, false, lane);
+                build<0>(s, s.lens, 288, s.lit, LBITS, s.sorted_lit, &s.tlit, false, lane);
                 for (int i = lane; i < 32; i += 64) s.lens[i] = 5;
                 WSYNC();
-                build<1>(s.lens, 32, s.dist, DBITS, s.sorted_dist, &s.tdist, false, lane);
+                build<1>(s, s.lens, 32, s.dist, DBITS, s.sorted_dist, &s.tdist, false, lane);
             } else {
                 if (bitpos(r) - 3 + 17 > total) goto done;
                 const uint32_t literals = 257 + TAKE(5);
@@ -651,7 +661,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *sr
                     s.lens[order[lane]] = (uint32_t)lane < codelengths ? (uint8_t)((packed >> (3 * lane)) & 7) : 0;
                 }
                 WSYNC();
-                if (!UB(build<2>(s.lens, 19, s.lit, MBITS, s.sorted_lit, &s.tlit, false, lane)))
+                if (!UB(build<2>(s, s.lens, 19, s.lit, MBITS, s.sorted_lit, &s.tlit, false, lane)))
                     FAIL(SPNG_E_CODELENGTH_TABLE, 0, 0);
 
                 // .tables: readBlockTables (:144-263), sequential RLE decode of the code lengths
@@ -689,9 +699,9 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *sr
                 }
                 WSYNC();
                 if (have != want) FAIL(SPNG_E_CODELENGTH_SEQUENCE, 0, 0);
-                const bool okd = UB(build<1>(s.lens + literals, (int)distances, s.dist, DBITS, s.sorted_dist,
+                const bool okd = UB(build<1>(s, s.lens + literals, (int)distances, s.dist, DBITS, s.sorted_dist,
                                              &s.tdist, true, lane));
-                const bool okl = UB(build<0>(s.lens, (int)literals, s.lit, LBITS, s.sorted_lit, &s.tlit,
+                const bool okl = UB(build<0>(s, s.lens, (int)literals, s.lit, LBITS, s.sorted_lit, &s.tlit,
                                              false, lane));
                 if (!okl || !okd) FAIL(SPNG_E_HUFFMAN_TABLE, 0, 0);
             }
