@@ -50,6 +50,10 @@ static constexpr int HALF = INR / 2;
 static constexpr int FLUSH = 4096;           // flush granularity
 static constexpr int WINOUT = 1024;          // most bytes one batch of tokens may produce
 static constexpr int QN = 256;               // token queue entries (power of two)
+#ifndef SPNG_BATCH_MIN
+#define SPNG_BATCH_MIN 16
+#endif
+static constexpr uint32_t BATCH_MIN = SPNG_BATCH_MIN;    // the resolver waits for this many tokens (or the end)
 // Literals of a batch are stored before its back-references are resolved, up to WINOUT bytes
 // ahead of a reference; a source is still intact in the ring if it is not further back than this.
 static constexpr uint32_t LDS_REACH = RING - WINOUT - 258 - 16;
@@ -441,14 +445,19 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, uint8_t *dst, ui
     bool failed = false;
 
     for (;;) {
+        // Take tokens in large batches: the fixed cost of a batch is paid once, and a resolver that
+        // polls an almost empty queue only steals issue slots and LDS cycles from the decoder.
         uint32_t tail = UNI(LDS_LOAD(&s.c.tail));
-        if (tail == head) {
+        if (tail - head < BATCH_MIN) {
             if (UNI(LDS_LOAD(&s.c.a_done))) {
                 LDS_ACQUIRE();
                 tail = UNI(LDS_LOAD(&s.c.tail));
                 if (tail == head) break;
             } else {
-                __builtin_amdgcn_s_sleep(1);
+#ifndef SPNG_B_SLEEP
+#define SPNG_B_SLEEP 4
+#endif
+                __builtin_amdgcn_s_sleep(SPNG_B_SLEEP);
                 if (++spins > SPIN_LIMIT) __builtin_trap();
                 PROFC(p_empty);
                 continue;
@@ -493,8 +502,10 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, uint8_t *dst, ui
         LDS_STORE(&s.c.head, head);
         const bool mine = (uint32_t)lane < m;
         // literals first (no token ever reads a later token's bytes) ...
+        // (LDS executes one wave's operations in issue order: a later read sees an earlier write
+        //  without any wait, so the compiler only has to keep the order)
         if (mine && !is_match && !is_check) s.ring[at & (RING - 1)] = (uint8_t)t;
-        LDS_ORDER();
+        COMPILER_ORDER();
         // ... then the back-references, in stream order
         unsigned long long mm = __ballot(mine && is_match && run != 0);
         while (mm) {
@@ -504,7 +515,7 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, uint8_t *dst, ui
             const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)dist, l);
             const uint64_t dstpos = o.pos + (uint32_t)__builtin_amdgcn_readlane((int)offs, l);
             copy_match(s, o, dstpos, cnt, off, lane);
-            LDS_ORDER();
+            COMPILER_ORDER();
         }
         const uint32_t produced = (uint32_t)__builtin_amdgcn_readlane((int)offs, (int)(m < 63 ? m : 63));
         o.pos = uni64(o.pos + (m < 64 ? produced : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63)));
@@ -588,6 +599,9 @@ __device__ __forceinline__ void push(Lds &s, Queue &q, unsigned long long who, u
 __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *src, uint64_t n, int32_t format, int lane)
 {
     const uint64_t total = n * 8;
+#ifndef SPNG_NO_PRIO
+    __builtin_amdgcn_s_setprio(3);           // the decoder is the critical path of its workgroup
+#endif
 
     int32_t status = SPNG_NEED_MORE_INPUT;
     uint64_t aux0 = 0, aux1 = 0;
