@@ -43,13 +43,19 @@ namespace spng {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) U128u { u32x4 v; };
+// The stream and output pointers are rebuilt from scalar registers; typed as global memory they
+// compile to global_load/global_store (a generic pointer would cost flat instructions, which also
+// tie up the LDS counter).
+typedef uint8_t __attribute__((address_space(1))) gbyte;
+typedef U128u __attribute__((address_space(1))) gU128u;
 
 static constexpr int RING = 32768;           // output window in LDS (power of two)
 static constexpr int INR = 512;              // input ring (two 256-byte halves)
 static constexpr int HALF = INR / 2;
 static constexpr int FLUSH = 4096;           // flush granularity
 static constexpr int WINOUT = 1024;          // most bytes one batch of tokens may produce
-static constexpr int QN = 256;               // token queue entries (power of two)
+static constexpr int QN = 128;               // token queue entries (power of two)
+static constexpr int WD = 4;                 // decoded windows in flight between scout and walker (power of two)
 #ifndef SPNG_BATCH_MIN
 #define SPNG_BATCH_MIN 16
 #endif
@@ -108,19 +114,34 @@ struct Tree {                    // canonical description for codes longer than 
     uint16_t first[16], count[16], offset[16];
 };
 
-// Token: literal = byte; back-reference = 1<<31 | run << 16 | distance; bit 30 = "the next `low 16
-// bits` bytes must fit the output" (stored blocks check their whole length up front).
-static constexpr uint32_t T_MATCH = 0x80000000u, T_CHECK = 0x40000000u;
+// Tokens, as the scout writes them (one per bit position) and as they travel through the queue:
+//   literal          byte << 8
+//   back-reference   1 << 7 | (run - 3) << 8 | (distance - 1) << 16                (15-bit distance)
+// with the token's length in bits (scout -> walker only; 0 = not for the fast path) in bits [5:0].
+// Tokens the walker decodes itself may be degenerate (run 0, checks the reference leaves to the
+// output side) and use the wide forms:
+//   back-reference   1 << 31 | run << 16 | distance
+//   capacity check   3 << 30 | bytes        ("the next `bytes` bytes must fit the output": stored
+//                                             blocks check their whole length up front)
+static constexpr uint32_t T_MATCH = 0x80000000u, T_CHECK = 0xc0000000u, T_REF = 0x80u;
 
 struct Ctrl {
-    uint32_t tail, head;           // tokens published by the decoder / released by the resolver
+    uint32_t tail, head;           // tokens published by the walker / released by the resolver
     uint32_t a_done, b_fail;
-    int32_t  status;               // decoder's final status; SPNG_DONE + check => compare Adler-32
+    int32_t  status;               // walker's final status; SPNG_DONE + check => compare Adler-32
     uint32_t check, declared, pad;
     uint64_t aux0, aux1, bits;
+    // scout <-> walker
+    uint32_t w_gen, w_stop, w_idle, w_quit;   // start order (generation), stop order, acknowledgement, exit
+    uint32_t w_prod, w_cons;                  // windows of this generation produced / consumed
+    uint64_t w_org;                           // first bit of window 0 of this generation
 };
 
-struct Lds {                       // 40,944 bytes: four streams per CU
+// What the scout hands to the walker for one 64-bit window: per lane the token that would start at
+// that bit.
+struct WinRec { uint32_t tok[64]; };
+
+struct Lds {                       // 40,928 bytes: four streams per CU
     uint8_t  ring[RING];
     uint32_t q[QN + 4];            // + a slot nobody reads, so that stores need no branch
     Ctrl     c;
@@ -130,9 +151,14 @@ struct Lds {                       // 40,944 bytes: four streams per CU
     uint32_t dist[1 << DBITS];
     uint16_t sorted_lit[288];      // symbols in canonical order, for codes longer than the LUT index
     uint16_t sorted_dist[32];
-    uint8_t  lens[464];            // 286 + 32 code lengths + worst-case RLE overshoot (138)
     Tree     tlit, tdist;
-    uint32_t hist[16], run[16];    // table construction: symbols per code length, ranked so far
+    union {
+        WinRec win[WD];            // compressed data: scout -> walker
+        struct {                   // block header (the scout is idle): table construction scratch
+            uint8_t  lens[464];    // 286 + 32 code lengths + worst-case RLE overshoot (138)
+            uint32_t hist[16], run[16];    // symbols per code length, ranked so far
+        };
+    };
 };
 
 // Only one wave of the workgroup builds tables; LDS operations of one wave execute in order, so a
@@ -251,12 +277,12 @@ struct Reader {
 
 // stage HALF bytes of the stream starting at `from` (multiple of HALF) into the input ring; bytes
 // past the end read as zero (the reference pads 48 zero bits, LZ77.InflatorIn.swift:130-133)
-__device__ void stage(Lds &s, const uint8_t *src, uint64_t n, uint64_t from, int lane)
+__device__ void stage(Lds &s, const gbyte *src, uint64_t n, uint64_t from, int lane)
 {
     if (lane < HALF / 16) {
         const uint64_t off = from + (uint64_t)lane * 16;
         u32x4 v = {0, 0, 0, 0};
-        if (off + 16 <= n) v = ((const U128u *)(src + off))->v;
+        if (off + 16 <= n) v = ((const gU128u *)(src + off))->v;
         else if (off < n) {
             uint32_t w[4] = {0, 0, 0, 0};
             for (int k = 0; k < 16; ++k) if (off + k < n) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
@@ -268,7 +294,7 @@ __device__ void stage(Lds &s, const uint8_t *src, uint64_t n, uint64_t from, int
     }
     WSYNC();
 }
-__device__ __forceinline__ void seek(Lds &s, Reader &r, const uint8_t *src, uint64_t n, uint64_t byte, int lane)
+__device__ __forceinline__ void seek(Lds &s, Reader &r, const gbyte *src, uint64_t n, uint64_t byte, int lane)
 {
     const uint64_t h = byte & ~(uint64_t)(HALF - 1);
     stage(s, src, n, h, lane);
@@ -276,7 +302,16 @@ __device__ __forceinline__ void seek(Lds &s, Reader &r, const uint8_t *src, uint
     r.pos = uni64(byte * 8);
     r.left = (int32_t)UNI((uint32_t)(h + HALF - byte) * 8);
 }
-__device__ __forceinline__ void advance(Lds &s, Reader &r, const uint8_t *src, uint64_t n, int lane, uint32_t k)
+// reposition at an arbitrary bit (the walker taking the input ring back from the scout)
+__device__ __forceinline__ void seek_bits(Lds &s, Reader &r, const gbyte *src, uint64_t n, uint64_t bit, int lane)
+{
+    const uint64_t h = (bit >> 3) & ~(uint64_t)(HALF - 1);
+    stage(s, src, n, h, lane);
+    stage(s, src, n, h + HALF, lane);
+    r.pos = uni64(bit);
+    r.left = (int32_t)UNI((uint32_t)((h + HALF) * 8 - bit));
+}
+__device__ __forceinline__ void advance(Lds &s, Reader &r, const gbyte *src, uint64_t n, int lane, uint32_t k)
 {
     r.pos = uni64(r.pos + k);                                  // k < 8 * HALF
     r.left = (int32_t)UNI((uint32_t)r.left - k);
@@ -306,7 +341,7 @@ __device__ __forceinline__ uint64_t peek64(const Lds &s, const Reader &r)
     return (uint64_t)UNI(hi) << 32 | UNI(lo);
 }
 #define TAKE(k) take(s, r, src, n, lane, (k))
-__device__ __forceinline__ uint32_t take(Lds &s, Reader &r, const uint8_t *src, uint64_t n, int lane, uint32_t k)
+__device__ __forceinline__ uint32_t take(Lds &s, Reader &r, const gbyte *src, uint64_t n, int lane, uint32_t k)
 {
     const uint32_t v = peek32(s, r) & ((1u << k) - 1);       // k <= 16
     advance(s, r, src, n, lane, k);
@@ -329,7 +364,7 @@ __device__ __forceinline__ uint32_t decode_long(uint32_t bits, const Tree &t, co
 }
 
 struct Out {
-    uint8_t *dst; uint64_t cap;
+    gbyte *dst; uint64_t cap;
     uint64_t pos, flushed;
     // Adler-32 (MRC32.swift:26-50) in a form that needs no cross-lane traffic until the very end:
     // with S = sum b_i and I = sum i*b_i over the whole stream of N bytes,
@@ -355,6 +390,9 @@ struct Out {
 #define LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define LDS_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 static constexpr uint32_t SPIN_LIMIT = 1u << 24;               // a lost partner traps instead of hanging the GPU
+// (the trap as an opaque instruction: as a block terminator it would be one more loop exit for the
+//  compiler to thread guard flags around)
+#define SPIN_ABORT() asm volatile("s_trap 2")
 
 // flush ring bytes [flushed, upto) to HBM and fold them into the lane's Adler-32 accumulators
 __device__ __attribute__((always_inline)) void flush(Lds &s, Out &o, uint64_t upto, int lane)
@@ -368,7 +406,7 @@ __device__ __attribute__((always_inline)) void flush(Lds &s, Out &o, uint64_t up
             uint32_t w[4] = {v.x, v.y, v.z, v.w};
             const uint32_t valid = n - off >= 16 ? 16 : n - off;
             if (valid == 16) {
-                ((U128u *)(o.dst + o.flushed + off))->v = v;
+                ((gU128u *)(o.dst + o.flushed + off))->v = v;
             } else {
                 for (uint32_t k = 0; k < valid; ++k) o.dst[o.flushed + off + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
                 for (uint32_t k = valid; k < 16; ++k) w[k >> 2] &= ~(0xffu << (8 * (k & 3)));
@@ -432,7 +470,7 @@ __device__ __forceinline__ void copy_match(Lds &s, const Out &o, uint64_t pos, u
 // ------------------------------------------------------------------------------------------------
 // wave 1: the resolver
 // ------------------------------------------------------------------------------------------------
-__device__ __attribute__((always_inline)) void resolver(Lds &s, uint8_t *dst, uint64_t dst_cap, uint64_t src_len,
+__device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint64_t dst_cap, uint64_t src_len,
                                                         spng_result *__restrict__ result, int lane)
 {
     Out o = { dst, dst_cap, 0, 0, 0, 0, 0 };
@@ -458,7 +496,7 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, uint8_t *dst, ui
 #define SPNG_B_SLEEP 4
 #endif
                 __builtin_amdgcn_s_sleep(SPNG_B_SLEEP);
-                if (++spins > SPIN_LIMIT) __builtin_trap();
+                if (++spins > SPIN_LIMIT) SPIN_ABORT();
                 PROFC(p_empty);
                 continue;
             }
@@ -468,8 +506,10 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, uint8_t *dst, ui
         COMPILER_ORDER();
         uint32_t m = tail - head < 64 ? tail - head : 64;
         const uint32_t t = s.q[(head + lane) & (QN - 1)];
-        const bool is_match = (t & T_MATCH) != 0, is_check = (t & (T_MATCH | T_CHECK)) == T_CHECK;
-        const uint32_t run = (t >> 16) & 0x1ff, dist = t & 0xffff;
+        const bool wide = (t & T_MATCH) != 0, is_check = (t & T_CHECK) == T_CHECK;
+        const bool is_match = wide ? !is_check : (t & T_REF) != 0;
+        const uint32_t run = wide ? (t >> 16) & 0x1ff : ((t >> 8) & 0xff) + 3;
+        const uint32_t dist = wide || is_check ? t & 0xffff : (t >> 16) + 1;
         const uint32_t len = (uint32_t)lane >= m ? 0u : is_match ? run : is_check ? 0u : 1u;
         // inclusive prefix sum of the token lengths: row scan on DPP, rows stitched on the scalar unit
         uint32_t incl = len;
@@ -501,21 +541,35 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, uint8_t *dst, ui
         COMPILER_ORDER();                                      // the token loads were issued: release their slots
         LDS_STORE(&s.c.head, head);
         const bool mine = (uint32_t)lane < m;
+        // ring offsets need only the low bits of the position
+        const uint32_t dsto = ((uint32_t)o.pos + offs) & (RING - 1);
         // literals first (no token ever reads a later token's bytes) ...
         // (LDS executes one wave's operations in issue order: a later read sees an earlier write
         //  without any wait, so the compiler only has to keep the order)
-        if (mine && !is_match && !is_check) s.ring[at & (RING - 1)] = (uint8_t)t;
+        if (mine && !is_match && !is_check) s.ring[dsto] = (uint8_t)(t >> 8);
         COMPILER_ORDER();
-        // ... then the back-references, in stream order
-        unsigned long long mm = __ballot(mine && is_match && run != 0);
+        // ... then the back-references, in stream order.  The common kind (one pass of the wave, no
+        // overlap, source still in the ring) is a byte read + byte write per lane; everything it
+        // needs was computed per lane above, so a reference costs two v_readlane.
+        const bool refs = mine && is_match && run != 0;
+        const uint32_t srco = (dsto - dist) & (RING - 1);
+        const uint32_t both = dsto | run << 16;
+        unsigned long long mm = __ballot(refs);
+        const unsigned long long plain = __ballot(refs && run <= 64 && dist >= run && dist <= LDS_REACH);
         while (mm) {
             const int l = __ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)run, l);
-            const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)dist, l);
-            const uint64_t dstpos = o.pos + (uint32_t)__builtin_amdgcn_readlane((int)offs, l);
-            copy_match(s, o, dstpos, cnt, off, lane);
+            const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)both, l);
+            const uint32_t from = (uint32_t)__builtin_amdgcn_readlane((int)srco, l);
+            const uint32_t to = pk & 0xffff, cnt = pk >> 16;
+            if ((plain >> l) & 1) {
+                if ((uint32_t)lane < cnt) s.ring[(to + lane) & (RING - 1)] = s.ring[(from + lane) & (RING - 1)];
+            } else {
+                const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)dist, l);
+                const uint64_t dstpos = o.pos + (uint32_t)__builtin_amdgcn_readlane((int)offs, l);
+                copy_match(s, o, dstpos, cnt, off, lane);
+            }
             COMPILER_ORDER();
+            mm &= mm - 1;
         }
         const uint32_t produced = (uint32_t)__builtin_amdgcn_readlane((int)offs, (int)(m < 63 ? m : 63));
         o.pos = uni64(o.pos + (m < 64 ? produced : (uint32_t)__builtin_amdgcn_readlane((int)incl, 63)));
@@ -554,7 +608,177 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, uint8_t *dst, ui
 }
 
 // ------------------------------------------------------------------------------------------------
-// wave 0: the decoder
+// wave 2: the scout
+// ------------------------------------------------------------------------------------------------
+// The scout's software pipeline: three 64-bit windows are in flight, one between each pair of
+// stages.  A stage reads the record its predecessor wrote in the previous iteration and overwrites
+// the record its successor has just finished with -- the records stay put, so no value is ever
+// copied while the load that produces it is still in flight.
+struct WinF { uint32_t d0, d1, d2; };                    // fetch ->:  three stream dwords at the lane's bit
+struct WinL { uint32_t lo, hi, e; };                     // litlen ->: the lane's next 64 bits, lit/len LUT entry
+struct WinD { uint32_t e, run, p2, dbits, d; };          // dist ->:   + run length, bits so far, distance LUT entry
+
+__device__ __forceinline__ void win_fetch(const Lds &s, WinF &f, uint32_t bit)
+{
+    const uint32_t *in = (const uint32_t *)(s.in + ((bit >> 3) & (INR - 4)));
+    f.d0 = in[0]; f.d1 = in[1]; f.d2 = in[2];
+}
+__device__ __forceinline__ void win_litlen(const Lds &s, const WinF &f, WinL &l, uint32_t bit)
+{
+    l.lo = __builtin_amdgcn_alignbit(f.d1, f.d0, bit);
+    l.hi = __builtin_amdgcn_alignbit(f.d2, f.d1, bit);
+    l.e = s.lit[l.lo & ((1 << LBITS) - 1)];
+}
+__device__ __forceinline__ void win_dist(const Lds &s, const WinL &l, WinD &d)
+{
+    const uint32_t len1 = l.e & 15, cx = (l.e >> 4) & 15;
+    d.e = l.e;
+    d.run = (l.e >> 16) + ((l.lo >> len1) & ((1u << cx) - 1));
+    d.p2 = len1 + cx;                                                // <= 14
+    d.dbits = (uint32_t)(((uint64_t)l.hi << 32 | l.lo) >> d.p2);
+    d.d = s.dist[d.dbits & ((1 << DBITS) - 1)];
+}
+// `rem` = stream bits from the first bit of the window to the end of the input (clamped)
+__device__ __forceinline__ uint32_t win_finish(const WinD &d, uint32_t rem, int lane)
+{
+    const uint32_t dl = d.d & 15, ox = (d.d >> 4) & 15;
+    const uint32_t dist = (d.d >> 16) + ((d.dbits >> dl) & ((1u << ox) - 1));
+    // anything unusual (long codes, undefined codes, zero runs/offsets, end of block, tokens
+    // running past the input) ends the chain and is decoded the slow way by the walker
+    const bool is_lit = (d.e & F_LIT) != 0;
+    const bool is_match = (d.e & d.d & F_REF) != 0;
+    const uint32_t tlen = is_lit ? d.e & 15 : d.p2 + dl + ox;         // <= 48
+    const bool ok = (is_lit || is_match) && (uint32_t)lane + tlen <= rem;
+    const uint32_t step = ok ? tlen : 0;
+    return step | (is_lit ? d.e >> 16 << 8 : T_REF | (d.run - 3) << 8 | (dist - 1) << 16);
+}
+__device__ __forceinline__ uint32_t window_rem(uint64_t total, uint64_t at)
+{
+    const uint64_t rem = total > at ? total - at : 0;
+    return UNI(rem > 0xffffffffull ? 0xffffffffu : (uint32_t)rem);
+}
+
+static constexpr int QUARTER = INR / 4;      // the scout stages the input ring in quarters
+
+// stage QUARTER bytes of the stream starting at `from` (multiple of QUARTER); see stage()
+__device__ void stage_quarter(Lds &s, const gbyte *src, uint64_t n, uint64_t from, int lane)
+{
+    if (lane < QUARTER / 16) {
+        const uint64_t off = from + (uint64_t)lane * 16;
+        u32x4 v = {0, 0, 0, 0};
+        if (off + 16 <= n) v = ((const gU128u *)(src + off))->v;
+        else if (off < n) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; ++k) if (off + k < n) w[k >> 2] |= (uint32_t)src[off + k] << (8 * (k & 3));
+            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        }
+        const uint32_t at = (uint32_t)(from + lane * 16) & (INR - 1);
+        *(u32x4 *)(s.in + at) = v;
+        if (at == 0) *(u32x4 *)(s.in + INR) = v;               // the mirror
+    }
+    WSYNC();
+}
+
+// Decodes, for every bit position of the compressed data of the current block, the token that would
+// start there -- window after window, ahead of the walker and without knowing where the real token
+// boundaries fall.  Started by the walker once a block's tables stand (generation counter + first
+// bit), stopped by it at the end of the block; what it decodes past the end of a block is never
+// looked at.  While it runs it owns the input ring: the quarter behind the newest window stays, so
+// the walker's slow path still finds the bytes around its own (older) position.
+__device__ __attribute__((always_inline)) void scout(Lds &s, const gbyte *src, uint64_t n, int lane)
+{
+    const uint64_t total = n * 8;
+    uint32_t gen = 0, quit = 0, idle_spins = 0;
+#ifdef SPNG_INFLATE_PROF
+    uint64_t sp_wait = 0, sp_stage = 0, sp_work = 0, sp_n = 0, sp_t = 0, sp_polls = 0;
+#define SPROF_T() (sp_t = __builtin_readcyclecounter())
+#define SPROF_ADD(x) ((x) += __builtin_readcyclecounter() - sp_t)
+#else
+#define SPROF_T()
+#define SPROF_ADD(x)
+#endif
+    while (!quit) {
+        const uint32_t g = UNI(LDS_LOAD(&s.c.w_gen));
+        quit = UNI(LDS_LOAD(&s.c.w_quit));
+        if (g == gen || quit) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++idle_spins > SPIN_LIMIT) SPIN_ABORT();
+            continue;
+        }
+        idle_spins = 0;
+        gen = g;
+        COMPILER_ORDER();
+        uint64_t wpos = uni64(s.c.w_org);                       // first bit of the window to finish next
+        // the ring around the first window: the quarter before, its own, two ahead
+        {
+            const uint64_t q0 = (wpos >> 3) & ~(uint64_t)(QUARTER - 1);
+            if (q0 >= QUARTER) stage_quarter(s, src, n, q0 - QUARTER, lane);
+            stage_quarter(s, src, n, q0, lane);
+            stage_quarter(s, src, n, q0 + QUARTER, lane);
+            stage_quarter(s, src, n, q0 + 2 * QUARTER, lane);
+        }
+        // bits until the newest window (three ahead of wpos) starts in the next quarter
+        int32_t left = (int32_t)UNI((uint32_t)(8 * QUARTER) - (uint32_t)((wpos + 192) & (8 * QUARTER - 1)));
+        if (((wpos + 192) >> 3 & ~(uint64_t)(QUARTER - 1)) != ((wpos >> 3) & ~(uint64_t)(QUARTER - 1)))
+            stage_quarter(s, src, n, (((wpos + 192) >> 3) & ~(uint64_t)(QUARTER - 1)) + 2 * QUARTER, lane);
+#define SBIT(k) ((uint32_t)wpos + 64u * (k) + (uint32_t)lane)
+        WinF F; WinL L; WinD D;                                // windows k+2, k+1, k
+        {
+            WinF f0, f1; WinL l0;
+            win_fetch(s, f0, SBIT(0)); win_fetch(s, f1, SBIT(1)); win_fetch(s, F, SBIT(2));
+            win_litlen(s, f0, l0, SBIT(0)); win_litlen(s, f1, L, SBIT(1));
+            win_dist(s, l0, D);
+        }
+        uint32_t k = 0, cons_seen = 0, stop = 0;
+        while (!stop) {
+            // a free slot (and the stop order, which can only matter when the walker has stopped taking)
+            if (__builtin_expect(k - cons_seen >= WD, 0)) {
+                SPROF_T();
+                for (uint32_t spins = 0; !stop; ++spins) {
+                    PROFC(sp_polls);
+                    cons_seen = UNI(LDS_LOAD(&s.c.w_cons));
+                    if (k - cons_seen < WD) break;
+                    stop = (UNI(LDS_LOAD(&s.c.w_stop)) == gen) | UNI(LDS_LOAD(&s.c.w_quit));
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins > SPIN_LIMIT) SPIN_ABORT();
+                }
+                SPROF_ADD(sp_wait);
+            }
+            if (!stop) {
+                SPROF_T();
+                PROFC(sp_n);
+                s.win[k & (WD - 1)].tok[lane] = win_finish(D, window_rem(total, wpos), lane);
+                k += 1;
+                COMPILER_ORDER();                              // LDS executes in issue order: no wait needed
+                LDS_STORE(&s.c.w_prod, k);
+                // every window behind moves one stage forward
+                wpos = uni64(wpos + 64);
+                left = (int32_t)UNI((uint32_t)left - 64u);
+                SPROF_ADD(sp_work);
+                if (left <= 0) {
+                    SPROF_T();
+                    stage_quarter(s, src, n, (((wpos + 192) >> 3) & ~(uint64_t)(QUARTER - 1)) + 2 * QUARTER, lane);
+                    left = (int32_t)UNI((uint32_t)left + 8u * QUARTER);
+                    SPROF_ADD(sp_stage);
+                }
+                SPROF_T();
+                win_dist(s, L, D);
+                win_litlen(s, F, L, SBIT(1));
+                win_fetch(s, F, SBIT(2));
+                SPROF_ADD(sp_work);
+            }
+        }
+#undef SBIT
+        if (!UNI(LDS_LOAD(&s.c.w_quit))) LDS_STORE(&s.c.w_idle, gen);
+    }
+#ifdef SPNG_INFLATE_PROF
+    if (lane == 0 && blockIdx.x == 0)
+        printf("scout: %llu windows, work %llu, slot wait %llu (%llu polls), staging %llu cycles\n", sp_n, sp_work, sp_wait, sp_polls, sp_stage);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave 0: the walker
 // ------------------------------------------------------------------------------------------------
 struct Queue {
     uint32_t tail, head_seen;
@@ -577,7 +801,7 @@ __device__ __forceinline__ void push(Lds &s, Queue &q, unsigned long long who, u
             if (UNI(LDS_LOAD(&s.c.b_fail))) { q.head_seen = q.tail; break; }
             PROFC(q.p_full);
             __builtin_amdgcn_s_sleep(1);
-            if (spins > SPIN_LIMIT) __builtin_trap();
+            if (spins > SPIN_LIMIT) SPIN_ABORT();
         }
     }
     // LDS executes one wave's operations in issue order, so publishing needs no wait: the compiler
@@ -596,7 +820,7 @@ __device__ __forceinline__ void push(Lds &s, Queue &q, unsigned long long who, u
 #define FAIL(code, a0, a1) do { status = (code); aux0 = (a0); aux1 = (a1); goto done; } while (0)
 #define PUSH(who, tok) push(s, q, (who), (tok), lane)
 
-__device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *src, uint64_t n, int32_t format, int lane)
+__device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src, uint64_t n, int32_t format, int lane)
 {
     const uint64_t total = n * 8;
 #ifndef SPNG_NO_PRIO
@@ -605,7 +829,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *sr
 
     int32_t status = SPNG_NEED_MORE_INPUT;
     uint64_t aux0 = 0, aux1 = 0;
-    uint32_t check = 0, declared = 0;
+    uint32_t check = 0, declared = 0, wgen = 0;
     Queue q = {};
     PROF_DECL
 #ifdef SPNG_INFLATE_PROF
@@ -647,7 +871,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *sr
             for (uint32_t done_ = 0; done_ < have; done_ += 64) {
                 const uint32_t piece = have - done_ < 64 ? have - done_ : 64;
                 const uint32_t b = (uint32_t)lane < piece ? src[from + done_ + lane] : 0u;
-                PUSH(piece == 64 ? ~0ull : (1ull << piece) - 1, b);
+                PUSH(piece == 64 ? ~0ull : (1ull << piece) - 1, b << 8);
             }
             if (have < l) { r.pos = n * 8; goto done; }
             seek(s, r, src, n, from + l, lane);
@@ -722,127 +946,156 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const uint8_t *sr
 
             PROF_END(6);
             // .compressed: readBlock(with:) (:266-381)
-            for (;;) {
-                const uint64_t b0 = uni64(bitpos(r));
-                if (b0 >= total) goto done;
-                PROF_BEGIN();
-                // ---- speculative window: lane i decodes the whole token that would start at bit
-                //      b0 + i (lit/len LUT, extra bits, distance LUT, extra bits)
-                uint32_t lo, hi;
-                fetch64(s, (uint32_t)b0 + (uint32_t)lane, lo, hi);
-                uint32_t e = s.lit[lo & ((1 << LBITS) - 1)];
-                const uint32_t len1 = e & 15, cx = (e >> 4) & 15;
-                const uint32_t run = (e >> 16) + ((lo >> len1) & ((1u << cx) - 1));
-                const uint32_t p2 = len1 + cx;                                   // <= 14
-                const uint32_t dbits = (uint32_t)(((uint64_t)hi << 32 | lo) >> p2);
-                const uint32_t d = s.dist[dbits & ((1 << DBITS) - 1)];
-                const uint32_t dl = d & 15, ox = (d >> 4) & 15;
-                const uint32_t dist = (d >> 16) + ((dbits >> dl) & ((1u << ox) - 1));
-                // anything unusual (long codes, undefined codes, zero runs/offsets, end of block,
-                // tokens running past the input) ends the chain and is decoded the slow way
-                const bool is_lit = (e & F_LIT) != 0;
-                const bool is_match = (e & d & F_REF) != 0;
-                const uint32_t tlen = is_lit ? len1 : p2 + dl + ox;              // <= 48
-                const uint64_t rem64 = total - b0;
-                const uint32_t rem = UNI(rem64 > 0xffffffffull ? 0xffffffffu : (uint32_t)rem64);
-                const bool ok = (is_lit || is_match) && (uint32_t)lane + tlen <= rem;
-                const uint32_t step = ok ? tlen : 0;
-                const uint32_t tok = is_lit ? e >> 16 : T_MATCH | run << 16 | dist;
-                // successor on the chain; a lane that ends the chain (step 0) or leaves the window
-                // points at itself, so the walk below needs no conditions at all
-                const uint32_t nxt = (step != 0 && (uint32_t)lane + step < 64) ? (uint32_t)lane + step : (uint32_t)lane;
-
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                PROF_END(0); PROF_BEGIN();
-                // ---- resolve the true chain of token boundaries through the window.
-                // A hop (VALU writes an SGPR, the next v_readlane uses it as its lane select) costs
-                // ~50 cycles of pure latency, so the walk goes two tokens at a time over the squared
-                // successor map (one ds_bpermute), picking up the odd positions with independent
-                // reads that overlap the next hop.  Written out in assembly because the scheduler
-                // otherwise interleaves SALU work between the hops, which makes every one of them
-                // wait for the vector pipeline to drain (s_nop 2 + the odd read = the 4 wait states
-                // of the lane-select hazard).
-                const uint32_t nxt2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxt << 2), (int)nxt);
-                const unsigned long long live = __ballot(step != 0);   // lanes the fast path can take
-                uint32_t p, t7;
-                unsigned long long chain;
-                {
-                    uint32_t t1, t2, t3, t4, t5, t6;
-                    asm volatile(
-                        "v_readlane_b32 %3, %10, 0\n\tv_readlane_b32 %2, %9, 0\n\ts_nop 2\n\t"
-                        "v_readlane_b32 %5, %10, %3\n\tv_readlane_b32 %4, %9, %3\n\ts_nop 2\n\t"
-                        "v_readlane_b32 %7, %10, %5\n\tv_readlane_b32 %6, %9, %5\n\ts_nop 2\n\t"
-                        "v_readlane_b32 %1, %10, %7\n\tv_readlane_b32 %8, %9, %7\n\t"
-                        "s_mov_b64 %0, 1\n\t"
-                        "s_bitset1_b64 %0, %2\n\ts_bitset1_b64 %0, %3\n\ts_bitset1_b64 %0, %4\n\t"
-                        "s_bitset1_b64 %0, %5\n\ts_bitset1_b64 %0, %6\n\ts_bitset1_b64 %0, %7\n\t"
-                        "s_bitset1_b64 %0, %8"
-                        : "=&s"(chain), "=&s"(p), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5),
-                          "=&s"(t6), "=&s"(t7)
-                        : "v"(nxt), "v"(nxt2));
-                }
-                if (__builtin_expect(p != t7, 0)) {            // not at rest after eight tokens: rare
-                    for (;;) {
-                        const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)p);
-                        if (np == p) break;
-                        asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p));
-                        p = np;
+            //
+            // The block is cut into 64-bit windows aligned to the first bit of its compressed data.
+            // The scout decodes, for every lane of every window, the token that would start at that
+            // bit; the walker only has to find the true chain of token boundaries through each
+            // window and queue the tokens on it.
+            {
+                const uint64_t org = r.pos;
+                wgen += 1;
+                LDS_STORE(&s.c.w_prod, 0u); LDS_STORE(&s.c.w_cons, 0u);   // (every lane, same value: no branch)
+                s.c.w_org = org;
+                COMPILER_ORDER();
+                LDS_STORE(&s.c.w_gen, wgen);                   // the start order
+                // One exit (`stop`), every branch wave-uniform, no breaks out of nested loops or gotos:
+                // anything fancier makes the compiler thread guard flags through every path.
+                // One loop, one exit (`stop`), one walk per iteration; every branch wave-uniform.
+                uint32_t k = 0, prod_seen = 0, ent = 0, stop = 0;   // stop: 1 = end of block, 2 = leave for `done`
+                uint32_t step = 0, nxt = 0, nxt2 = 0, tok = 0;
+                unsigned long long live = 0;
+                bool fresh = true;                             // the next walk starts a new window
+                for (;;) {
+                    if (fresh) {
+                        PROF_BEGIN();
+                        if (__builtin_expect(prod_seen <= k, 0)) {
+                            for (uint32_t spins = 0;; ++spins) {
+                                prod_seen = UNI(LDS_LOAD(&s.c.w_prod));
+                                if (prod_seen > k) break;
+                                PROFC(q.p_full);
+                                __builtin_amdgcn_s_sleep(1);
+                                if (spins > SPIN_LIMIT) SPIN_ABORT();
+                            }
+                        }
+                        COMPILER_ORDER();
+                        tok = s.win[k & (WD - 1)].tok[lane];
+                        step = tok & 63;
+                        // successor on the chain; a lane that ends the chain (step 0) or leaves the
+                        // window points at itself, so the walk needs no conditions at all
+                        nxt = (step != 0 && (uint32_t)lane + step < 64) ? (uint32_t)lane + step : (uint32_t)lane;
+                        nxt2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(nxt << 2), (int)nxt);
+                        live = __ballot(step != 0);            // lanes the fast path can take
+                        PROF_END(0);
+                    }
+                    const uint64_t wpos = org + ((uint64_t)k << 6);
+                    {
+                        PROF_BEGIN();
+                        // ---- resolve the true chain of token boundaries through the window.
+                        // A hop (VALU writes an SGPR, the next v_readlane uses it as its lane select)
+                        // costs ~50 cycles of pure latency, so the walk goes two tokens at a time over
+                        // the squared successor map, picking up the odd positions with independent
+                        // reads that overlap the next hop.  Written out in assembly because the
+                        // scheduler otherwise interleaves SALU work between the hops, which makes
+                        // every one of them wait for the vector pipeline to drain (s_nop 2 + the odd
+                        // read = the 4 wait states of the lane-select hazard).
+                        uint32_t p, t7;
+                        unsigned long long chain;
+                        {
+                            uint32_t t1, t2, t3, t4, t5, t6;
+                            asm volatile(
+                                "v_readlane_b32 %3, %10, %11\n\tv_readlane_b32 %2, %9, %11\n\ts_nop 2\n\t"
+                                "v_readlane_b32 %5, %10, %3\n\tv_readlane_b32 %4, %9, %3\n\ts_nop 2\n\t"
+                                "v_readlane_b32 %7, %10, %5\n\tv_readlane_b32 %6, %9, %5\n\ts_nop 2\n\t"
+                                "v_readlane_b32 %1, %10, %7\n\tv_readlane_b32 %8, %9, %7\n\t"
+                                "s_mov_b64 %0, 0\n\ts_bitset1_b64 %0, %11\n\t"
+                                "s_bitset1_b64 %0, %2\n\ts_bitset1_b64 %0, %3\n\ts_bitset1_b64 %0, %4\n\t"
+                                "s_bitset1_b64 %0, %5\n\ts_bitset1_b64 %0, %6\n\ts_bitset1_b64 %0, %7\n\t"
+                                "s_bitset1_b64 %0, %8"
+                                : "=&s"(chain), "=&s"(p), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5),
+                                  "=&s"(t6), "=&s"(t7)
+                                : "v"(nxt), "v"(nxt2), "s"(ent));
+                        }
+                        if (__builtin_expect(p != t7, 0)) {    // not at rest after eight tokens: rare
+                            for (;;) {
+                                const uint32_t np = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)p);
+                                if (np == p) break;
+                                asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p));
+                                p = np;
+                            }
+                        }
+                        // p is the lane the walk came to rest on: either the token that crosses into
+                        // the next window (on the chain) or the first one the fast path cannot take
+                        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)p);
+                        chain = (chain & ~(1ull << p)) | (live & 1ull << p);
+                        PROF_END(1);
+                        if (chain) {
+                            PROF_BEGIN();
+                            PUSH(chain, tok);
+                            PROF_END(2);
+                        }
+                        uint32_t used = st;
+                        if (__builtin_expect(st == 0, 0)) {
+                            // ---- the token at lane p, decoded wave-uniformly with every check of
+                            //      the reference that does not need the output position (those are
+                            //      the resolver's)
+                            PROF_BEGIN();
+                            const uint64_t b1 = wpos + p;
+                            uint32_t slo, shi;
+                            fetch64(s, (uint32_t)b1, slo, shi);
+                            uint64_t slug = (uint64_t)UNI(shi) << 32 | UNI(slo);
+                            if (b1 >= total) {
+                                stop = 2;
+                            } else {
+                                uint32_t e = UNI(s.lit[(uint32_t)slug & ((1 << LBITS) - 1)]);
+                                if ((e & 15) == 0) e = decode_long<0>((uint32_t)slug, s.tlit, s.sorted_lit, LBITS, lane);
+                                const uint32_t len = e & 15, kind = (e >> 8) & 3;
+                                if (kind == K_LIT) {
+                                    if (b1 + len > total) stop = 2;
+                                    else { PUSH(1ull, e >> 16 << 8); used = len; }
+                                } else if (kind == K_EOB) {
+                                    if (b1 + len > total) stop = 2;
+                                    else { used = len; stop = 1; }
+                                } else {
+                                    slug >>= len;
+                                    const uint32_t ex = (e >> 4) & 15;
+                                    const uint32_t count = (e >> 16) + ((uint32_t)slug & ((1u << ex) - 1));
+                                    slug >>= ex;
+                                    uint32_t dd = UNI(s.dist[(uint32_t)slug & ((1 << DBITS) - 1)]);
+                                    if ((dd & 15) == 0) dd = decode_long<1>((uint32_t)slug, s.tdist, s.sorted_dist, DBITS, lane);
+                                    slug >>= dd & 15;
+                                    const uint32_t dx = (dd >> 4) & 15;
+                                    const uint32_t offset = (dd >> 16) + ((uint32_t)slug & ((1u << dx) - 1));
+                                    const uint32_t bits = len + ex + (dd & 15) + dx;   // <= 48
+                                    // offset > position is the resolver's check and comes first in
+                                    // the reference; it cannot fire for offset 0, so the undefined-
+                                    // reference case may be raised here
+                                    if (((dd >> 8) & 3) == K_UNDEF) { status = SPNG_E_REFERENCE_UNDEFINED; stop = 2; }
+                                    else if (b1 + bits > total) stop = 2;
+                                    else if (count && !offset) { status = SPNG_E_REFERENCE_UNDEFINED; stop = 2; }
+                                    else { PUSH(1ull, T_MATCH | count << 16 | offset); used = bits; }
+                                }
+                            }
+                            PROF_END(5);
+                        }
+                        ent = p + used;
+                    }
+                    if (stop) break;
+                    fresh = ent >= 64;
+                    if (fresh) {
+                        ent -= 64;
+                        k += 1;
+                        COMPILER_ORDER();                      // the record's loads were issued: release its slot
+                        LDS_STORE(&s.c.w_cons, k);
                     }
                 }
-                // p is the lane the walk came to rest on: either the token that crosses the end of
-                // the window (on the chain) or the first one the fast path cannot take.  Its length
-                // is only needed for the advance, after the tokens are queued.
-                const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)p);
-                chain = (chain & ~(1ull << p)) | (live & 1ull << p);
-                const uint32_t rest = p;
-                p += st;
-                PROF_END(1);
-                if (chain) {
-                    PROF_BEGIN();
-                    PUSH(chain, tok);
-                    PROF_END(2); PROF_BEGIN();
-                    advance(s, r, src, n, lane, p);
-                    PROF_END(3);
-                    if (p >= 64) continue;                     // the chain used the whole window
-                    if (bitpos(r) >= total) goto done;
+                // stop the scout and take the input ring (and the table scratch it overlays) back
+                LDS_STORE(&s.c.w_stop, wgen);
+                for (uint32_t spins = 0; UNI(LDS_LOAD(&s.c.w_idle)) != wgen; ++spins) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (spins > SPIN_LIMIT) SPIN_ABORT();
                 }
-                e = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)rest);   // LUT entry of the token the chain stopped on
-
-                // ---- that token, decoded wave-uniformly with every check of the reference that
-                //      does not need the output position (those are the resolver's)
-                PROF_BEGIN();
-                const uint64_t b1 = bitpos(r);
-                uint64_t slug = peek64(s, r);
-                if ((e & 15) == 0) e = decode_long<0>((uint32_t)slug, s.tlit, s.sorted_lit, LBITS, lane);
-                const uint32_t len = e & 15, kind = (e >> 8) & 3;
-                if (kind == K_LIT) {
-                    if (b1 + len > total) goto done;
-                    advance(s, r, src, n, lane, len);
-                    PUSH(1ull, e >> 16);
-                } else if (kind == K_EOB) {
-                    if (b1 + len > total) goto done;
-                    advance(s, r, src, n, lane, len);
-                    break;
-                } else {
-                    slug >>= len;
-                    const uint32_t ex = (e >> 4) & 15;
-                    const uint32_t count = (e >> 16) + ((uint32_t)slug & ((1u << ex) - 1));
-                    slug >>= ex;
-                    uint32_t dd = UNI(s.dist[(uint32_t)slug & ((1 << DBITS) - 1)]);
-                    if ((dd & 15) == 0) dd = decode_long<1>((uint32_t)slug, s.tdist, s.sorted_dist, DBITS, lane);
-                    if (((dd >> 8) & 3) == K_UNDEF) FAIL(SPNG_E_REFERENCE_UNDEFINED, 0, 0);
-                    slug >>= dd & 15;
-                    const uint32_t dx = (dd >> 4) & 15;
-                    const uint32_t offset = (dd >> 16) + ((uint32_t)slug & ((1u << dx) - 1));
-                    const uint32_t bits = len + ex + (dd & 15) + dx;     // <= 48
-                    if (b1 + bits > total) goto done;
-                    // offset > position is the resolver's check and comes first in the reference;
-                    // it cannot fire for offset 0, so this one may be raised here
-                    if (count && !offset) FAIL(SPNG_E_REFERENCE_UNDEFINED, 0, 0);
-                    advance(s, r, src, n, lane, bits);
-                    PUSH(1ull, T_MATCH | count << 16 | offset);
-                }
-                PROF_END(5);
+                seek_bits(s, r, src, n, org + ((uint64_t)k << 6) + ent, lane);
+                if (stop == 2) goto done;
             }
         } else {
             FAIL(SPNG_E_BLOCK_TYPE, type, 0);
@@ -873,31 +1126,37 @@ done:
     }
     LDS_ORDER();
     if (lane == 0) LDS_STORE(&s.c.a_done, 1u);
+    LDS_STORE(&s.c.w_quit, 1u);                                // the scout is idle by now; let it go
 }
 
-__global__ __launch_bounds__(128) void inflate_kernel(const InflateJob *__restrict__ jobs,
+__global__ __launch_bounds__(192) void inflate_kernel(const InflateJob *__restrict__ jobs,
                                                       spng_result *__restrict__ results)
 {
     __shared__ __attribute__((aligned(16))) Lds s;
     // job fields are wave-uniform: pin them to scalar registers so that everything derived from
     // them (positions, loop conditions) stays on the scalar unit
     const InflateJob *job = jobs + blockIdx.x;
-    const uint8_t *src = (const uint8_t *)uni64((uint64_t)job->src);
-    uint8_t *dst = (uint8_t *)uni64((uint64_t)job->dst);
+    const gbyte *src = (const gbyte *)uni64((uint64_t)job->src);
+    gbyte *dst = (gbyte *)uni64((uint64_t)job->dst);
     const uint64_t src_len = uni64(job->src_len), dst_cap = uni64(job->dst_cap);
     const int32_t format = (int32_t)UNI(job->format);
     const uint32_t image = UNI(job->image);
-    if (threadIdx.x == 0) { s.c.tail = 0; s.c.head = 0; s.c.a_done = 0; s.c.b_fail = 0; }
+    if (threadIdx.x == 0) {
+        s.c.tail = 0; s.c.head = 0; s.c.a_done = 0; s.c.b_fail = 0;
+        s.c.w_gen = 0; s.c.w_stop = 0; s.c.w_idle = 0; s.c.w_quit = 0; s.c.w_prod = 0; s.c.w_cons = 0;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    if (UNI(threadIdx.x >> 6) == 0) decoder(s, src, src_len, format, lane);
-    else                            resolver(s, dst, dst_cap, src_len, results + image, lane);
+    const uint32_t role = UNI(threadIdx.x >> 6);
+    if (role == 0)      decoder(s, src, src_len, format, lane);
+    else if (role == 1) resolver(s, dst, dst_cap, src_len, results + image, lane);
+    else                scout(s, src, src_len, lane);
 }
 
 hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream)
 {
     if (!count) return hipSuccess;
-    inflate_kernel<<<count, 128, 0, stream>>>(d_jobs, d_results);
+    inflate_kernel<<<count, 192, 0, stream>>>(d_jobs, d_results);
     return hipGetLastError();
 }
 
