@@ -54,10 +54,10 @@ static constexpr int INR = 512;              // input ring (two 256-byte halves)
 static constexpr int HALF = INR / 2;
 static constexpr int FLUSH = 4096;           // flush granularity
 static constexpr int WINOUT = 1024;          // most bytes one batch of tokens may produce
-static constexpr int QN = 128;               // token queue entries (power of two)
+static constexpr int QN = 128;               // token queue entries (power of two; a window yields <= 64 tokens)
 static constexpr int WD = 4;                 // decoded windows in flight between scout and walker (power of two)
 #ifndef SPNG_BATCH_MIN
-#define SPNG_BATCH_MIN 16
+#define SPNG_BATCH_MIN 32
 #endif
 static constexpr uint32_t BATCH_MIN = SPNG_BATCH_MIN;    // the resolver waits for this many tokens (or the end)
 // Literals of a batch are stored before its back-references are resolved, up to WINOUT bytes
@@ -128,6 +128,7 @@ static constexpr uint32_t T_MATCH = 0x80000000u, T_CHECK = 0xc0000000u, T_REF = 
 struct Ctrl {
     uint32_t tail, head;           // tokens published by the walker / released by the resolver
     uint32_t a_done, b_fail;
+    uint32_t a_wait, pad1;         // the walker is blocked on a full queue: take whatever is there
     int32_t  status;               // walker's final status; SPNG_DONE + check => compare Adler-32
     uint32_t check, declared, pad;
     uint64_t aux0, aux1, bits;
@@ -390,9 +391,10 @@ struct Out {
 #define LDS_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define LDS_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 static constexpr uint32_t SPIN_LIMIT = 1u << 24;               // a lost partner traps instead of hanging the GPU
-// (the trap as an opaque instruction: as a block terminator it would be one more loop exit for the
-//  compiler to thread guard flags around)
-#define SPIN_ABORT() asm volatile("s_trap 2")
+// (ending the wave with an opaque instruction: a trap would be a block terminator, i.e. one more
+//  loop exit for the compiler to thread guard flags around.  The partner waves run into their own
+//  limits, the kernel ends, and the caller finds a result that was never written.)
+#define SPIN_ABORT() asm volatile("s_endpgm")
 
 // flush ring bytes [flushed, upto) to HBM and fold them into the lane's Adler-32 accumulators
 __device__ __attribute__((always_inline)) void flush(Lds &s, Out &o, uint64_t upto, int lane)
@@ -473,6 +475,10 @@ __device__ __forceinline__ void copy_match(Lds &s, const Out &o, uint64_t pos, u
 __device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint64_t dst_cap, uint64_t src_len,
                                                         spng_result *__restrict__ result, int lane)
 {
+#ifndef SPNG_B_PRIO
+#define SPNG_B_PRIO 2
+#endif
+    __builtin_amdgcn_s_setprio(SPNG_B_PRIO);               // walker 3 > resolver 2 > scout 0 (the scout has slack)
     Out o = { dst, dst_cap, 0, 0, 0, 0, 0 };
     uint32_t head = 0, spins = 0;
 #ifdef SPNG_INFLATE_PROF
@@ -486,7 +492,7 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint
         // Take tokens in large batches: the fixed cost of a batch is paid once, and a resolver that
         // polls an almost empty queue only steals issue slots and LDS cycles from the decoder.
         uint32_t tail = UNI(LDS_LOAD(&s.c.tail));
-        if (tail - head < BATCH_MIN) {
+        if (tail - head < BATCH_MIN && !(tail != head && UNI(LDS_LOAD(&s.c.a_wait)))) {
             if (UNI(LDS_LOAD(&s.c.a_done))) {
                 LDS_ACQUIRE();
                 tail = UNI(LDS_LOAD(&s.c.tail));
@@ -795,13 +801,18 @@ __device__ __forceinline__ void push(Lds &s, Queue &q, unsigned long long who, u
 {
     const uint32_t k = (uint32_t)__popcll(who);
     if (__builtin_expect(q.tail + k - q.head_seen > QN, 0)) {
-        for (uint32_t spins = 0;; ++spins) {
-            q.head_seen = UNI(LDS_LOAD(&s.c.head));
-            if (q.tail + k - q.head_seen <= QN) break;
-            if (UNI(LDS_LOAD(&s.c.b_fail))) { q.head_seen = q.tail; break; }
-            PROFC(q.p_full);
-            __builtin_amdgcn_s_sleep(1);
-            if (spins > SPIN_LIMIT) SPIN_ABORT();
+        q.head_seen = UNI(LDS_LOAD(&s.c.head));
+        if (q.tail + k - q.head_seen > QN) {
+            LDS_STORE(&s.c.a_wait, 1u);                        // (the resolver may be waiting for a fuller batch)
+            for (uint32_t spins = 0;; ++spins) {
+                q.head_seen = UNI(LDS_LOAD(&s.c.head));
+                if (q.tail + k - q.head_seen <= QN) break;
+                if (UNI(LDS_LOAD(&s.c.b_fail))) { q.head_seen = q.tail; break; }
+                PROFC(q.p_full);
+                __builtin_amdgcn_s_sleep(1);
+                if (spins > SPIN_LIMIT) SPIN_ABORT();
+            }
+            LDS_STORE(&s.c.a_wait, 0u);
         }
     }
     // LDS executes one wave's operations in issue order, so publishing needs no wait: the compiler
@@ -1142,7 +1153,7 @@ __global__ __launch_bounds__(192) void inflate_kernel(const InflateJob *__restri
     const int32_t format = (int32_t)UNI(job->format);
     const uint32_t image = UNI(job->image);
     if (threadIdx.x == 0) {
-        s.c.tail = 0; s.c.head = 0; s.c.a_done = 0; s.c.b_fail = 0;
+        s.c.tail = 0; s.c.head = 0; s.c.a_done = 0; s.c.b_fail = 0; s.c.a_wait = 0;
         s.c.w_gen = 0; s.c.w_stop = 0; s.c.w_idle = 0; s.c.w_quit = 0; s.c.w_prod = 0; s.c.w_cons = 0;
     }
     __syncthreads();

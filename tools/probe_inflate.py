@@ -18,7 +18,10 @@ flat = bytes(U)
 cases["zeros-l6"] = zlib.compress(flat, 6)
 truth = {"synth-l6": rows, "synth-l1": rows, "noise-l6": noise, "zeros-l6": flat}
 out = torch.empty(N * (U + 4096), dtype=torch.uint8, device=s.tdev)
+import os
+only = os.environ.get("PROBE_CASES")
 for name, z in cases.items():
+    if only and name not in only.split(","): continue
     dz = s.to_device(z)
     sd = (spng.StreamDesc * N)(*[spng.StreamDesc(dz.data_ptr(), dz.numel(), out.data_ptr() + i * (U + 4096), U + 4096, 0, 0) for i in range(N)])
     res = (spng.Result * N)()
