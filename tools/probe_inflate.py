@@ -22,12 +22,15 @@ import os
 only = os.environ.get("PROBE_CASES")
 for name, z in cases.items():
     if only and name not in only.split(","): continue
-    dz = s.to_device(z)
-    sd = (spng.StreamDesc * N)(*[spng.StreamDesc(dz.data_ptr(), dz.numel(), out.data_ptr() + i * (U + 4096), U + 4096, 0, 0) for i in range(N)])
+    K = int(os.environ.get("PROBE_DISTINCT", "1"))      # copies at distinct addresses: no sharing in L2
+    dzs = [s.to_device(z) for _ in range(K)]
+    sd = (spng.StreamDesc * N)(*[spng.StreamDesc(dzs[i % K].data_ptr(), dzs[i % K].numel(), out.data_ptr() + i * (U + 4096), U + 4096, 0, 0) for i in range(N)])
     res = (spng.Result * N)()
     s.lib.spng_inflate_batch(s.ctx, sd, N, None, res)
-    s.profile(True)
-    s.lib.spng_inflate_batch(s.ctx, sd, N, None, res)
-    ms, n = s.profile_get(spng.K_INFLATE); s.profile(False)
+    for _ in range(int(os.environ.get("PROBE_REPS", "1"))):
+        s.profile(True)
+        s.lib.spng_inflate_batch(s.ctx, sd, N, None, res)
+        ms, n = s.profile_get(spng.K_INFLATE); s.profile(False)
+        if os.environ.get("PROBE_REPS"): print(f"  launch: {ms/n:.1f} ms")
     ok = bytes(out[(N - 1) * (U + 4096):(N - 1) * (U + 4096) + U].cpu().numpy()) == truth[name]
     print(f"inflate {name} N={N}: ratio {U/len(z):.2f} kernel {ms/n:.1f} ms status {res[0].status} ok={ok} -> per-stream {U/(ms/n*1e-3)/1e6:.1f} MB/s out, batch {N*U/(ms/n*1e-3)/1e9:.2f} GB/s")
