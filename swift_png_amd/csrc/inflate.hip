@@ -1140,7 +1140,7 @@ done:
     LDS_STORE(&s.c.w_quit, 1u);                                // the scout is idle by now; let it go
 }
 
-__global__ __launch_bounds__(192) void inflate_kernel(const InflateJob *__restrict__ jobs,
+__global__ __launch_bounds__(256) void inflate_kernel(const InflateJob *__restrict__ jobs,
                                                       spng_result *__restrict__ results)
 {
     __shared__ __attribute__((aligned(16))) Lds s;
@@ -1161,13 +1161,17 @@ __global__ __launch_bounds__(192) void inflate_kernel(const InflateJob *__restri
     const uint32_t role = UNI(threadIdx.x >> 6);
     if (role == 0)      decoder(s, src, src_len, format, lane);
     else if (role == 1) resolver(s, dst, dst_cap, src_len, results + image, lane);
-    else                scout(s, src, src_len, lane);
+    else if (role == 2) scout(s, src, src_len, lane);
+    // (wave 3 has nothing to do.  It is there because the dispatcher places 256-thread workgroups
+    //  evenly -- exactly four per CU, all 1024 streams of a batch resident at once -- and 192-thread
+    //  ones not: with three waves a few dozen workgroups of every launch were left queued behind
+    //  full shader engines until other streams had finished, which doubled the time of the batch.)
 }
 
 hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream)
 {
     if (!count) return hipSuccess;
-    inflate_kernel<<<count, 192, 0, stream>>>(d_jobs, d_results);
+    inflate_kernel<<<count, 256, 0, stream>>>(d_jobs, d_results);
     return hipGetLastError();
 }
 
