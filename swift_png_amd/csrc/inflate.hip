@@ -1,4 +1,5 @@
-// inflate.hip -- batched zlib / raw-DEFLATE inflate for gfx950: one wavefront per stream.
+// inflate.hip -- batched zlib / raw-DEFLATE inflate for gfx950: one workgroup (three working
+// wavefronts) per stream.
 //
 // Replaces LZ77.Inflator over whole streams:
 //   state machine      Sources/LZ77/Inflator/LZ77.InflatorBuffers.swift:25-137
@@ -10,33 +11,45 @@
 // with the same accept/reject behaviour and error vocabulary (status codes in spng_mi355.h).
 //
 // Design.  A DEFLATE stream is one serial dependency chain (the bit position of token k+1 depends
-// on token k), so the unit of parallelism is the stream, and the work on one stream is split into
-// the two halves that do not depend on each other's latency: a workgroup of two wavefronts per
-// stream, four workgroups per CU -> 1024 streams (2048 waves) in flight on the chip.
-//   * wave 0, the DECODER, turns bits into LZ77 tokens.  Every lane looks up the lit/len LUT (LDS)
-//     at bit offset position + lane and decodes the whole token that would start there (extra
-//     bits, distance code, extra bits), all 64 offsets at once; the true chain of token boundaries
-//     through those 64 bits is then resolved on the scalar unit (a v_readlane hop per token), and
-//     the lanes on the chain append their tokens (4 bytes each, stream order by popcount of the
-//     chain mask below the lane) to a 256-entry token queue in LDS.  The token on which a chain
-//     stops (end of block, long code, anything unusual) is decoded wave-uniformly with every check
-//     of the reference.  The decoder never touches the output.
-//   * wave 1, the RESOLVER, owns the 32 KiB output window (LDS ring = the whole DEFLATE window).
-//     It takes up to 64 tokens at a time, prefix-sums their lengths across the wave, stores all
-//     literals in one LDS write, then replays the back-references in stream order as LDS->LDS
-//     copies (overlapping runs replicate via i mod distance), flushes the ring to HBM in aligned
-//     4 KiB pieces with 16 B/lane coalesced stores and folds Adler-32 into the flush (v_sad_u8 /
-//     v_dot4 weighted sums), so the inflated bytes are never re-read.  Position-dependent checks
+// on token k), so the unit of parallelism is the stream: one workgroup per stream, four workgroups
+// per CU (the 32 KiB window of each lives in LDS) -> 1024 streams in flight on the chip.  A lone
+// wavefront issues roughly one dependent instruction every 7-8 cycles, so what bounds a stream is
+// the length of the instruction sequence per token on its critical path; the work is therefore cut
+// into three stages that run as three wavefronts on three SIMDs, coupled by small LDS rings:
+//   * wave 2, the SCOUT, cuts the compressed data of a block into 64-bit windows aligned to its
+//     first bit and decodes, for every lane of every window, the whole token that would start at
+//     that bit (lit/len LUT, extra bits, distance LUT, extra bits) -- independent of where the real
+//     token boundaries fall, hence ahead of everything else and in a software pipeline in which
+//     every LDS result is used one iteration after its load was issued.  One 32-bit token per bit
+//     position goes into a ring of WD window records.
+//   * wave 0, the WALKER, finds the true chain of token boundaries through each window: the lanes'
+//     token lengths define a successor map, and the walk over it runs on v_readlane, two tokens per
+//     hop over the squared map (a hop is ~50 cycles of pure latency).  The lanes on the chain
+//     append their tokens (stream order = popcount of the chain mask below the lane) to a token
+//     queue.  The token on which a chain stops (end of block, long code, anything unusual) is
+//     decoded wave-uniformly with every check of the reference.  Block headers, table construction
+//     and stored blocks are the walker's too; the scout is started per block once the tables stand.
+//   * wave 1, the RESOLVER, owns the output window (LDS ring = the whole DEFLATE window).  It takes
+//     up to 64 tokens at a time, prefix-sums their lengths across the wave, stores all literals in
+//     one LDS write, then replays the back-references in stream order as LDS->LDS copies
+//     (overlapping runs replicate via i mod distance), flushes the ring to HBM in aligned 4 KiB
+//     pieces with 16 B/lane coalesced stores and folds Adler-32 into the flush (v_sad_u8 / v_dot4
+//     weighted sums), so the inflated bytes are never re-read.  Position-dependent checks
 //     (reference before the start of the stream, output capacity) live here.
-// The queue is a single-producer single-consumer ring: tokens are published by a tail counter and
-// released by a head counter, both in LDS; errors keep stream order because the resolver drains
-// everything the decoder queued before it looks at the decoder's final status.
+//   * wave 3 does nothing (see the kernel: 256-thread workgroups are placed evenly, 192 are not).
+// Both rings are single-producer single-consumer: a counter publishes, a counter releases, LDS
+// executes one wave's operations in issue order so neither side ever waits for a store to land.
+// Errors keep stream order because the resolver drains everything that was queued before it looks
+// at the walker's final status.  All control flow on the hot paths is wave-uniform and the spin
+// loops have no trap exits: either makes the compiler thread exec masks and guard flags through
+// every loop, which costs more than the work itself.
 // Tables are LDS resident: a 2^10-entry lit/len LUT and a 2^8-entry distance LUT whose 32-bit
 // entries already carry base value + extra-bit count, and a canonical first-code/count fallback
-// for the rare longer codes.  They are rebuilt cooperatively per block (ballot/popcount ranking,
-// lanes fill LUT replicas in parallel) -- swift-png's own encoder emits a dynamic block every
-// <= 2047 tokens, so this is hot.  Compressed input is staged through a 512-byte LDS ring with
-// coalesced 16 B/lane loads and read through a 6-dword register window.
+// for the rare longer codes.  They are rebuilt per block by the whole wave (LDS histogram, DPP
+// prefix sums, radix-match ranking; nothing per code length lives in scalar registers) --
+// swift-png's own encoder emits a dynamic block every <= 2047 tokens, so this is hot.  Compressed
+// input is staged through a 512-byte LDS ring with coalesced 16 B/lane loads; a position is a bit
+// index and every fetch reads three dwords straight from the ring.
 #include "common.hpp"
 
 namespace spng {
