@@ -35,6 +35,14 @@ namespace spng {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) U32u { uint32_t v; };
 struct __attribute__((packed)) U128u { u32x4 v; };
+// Input, output and the link ring are global memory, and say so in their types (a generic pointer
+// costs flat instructions, which also tie up the LDS counter).
+typedef uint8_t __attribute__((address_space(1))) gbyte;
+typedef uint32_t __attribute__((address_space(1))) gword;
+typedef U32u __attribute__((address_space(1))) gU32u;
+// wave-uniform values, said so to the compiler (see inflate.hip)
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)UNI(v >> 32) << 32 | UNI((uint32_t)v); }
 
 static constexpr int HBITS = 13;                 // bucket heads in LDS
 static constexpr uint32_t NONE = 0xffffffffu;
@@ -63,7 +71,7 @@ __device__ __forceinline__ uint32_t dist_decade(uint32_t d)
 }
 
 struct DLds {
-    uint32_t head[1 << HBITS];                   // most recent position per bucket (low 32 bits)
+    uint32_t head[(1 << HBITS) + 1];             // most recent position per bucket (low 32 bits); + a slot nobody reads
     uint32_t terms[2048];
     uint32_t freq[320];                          // 0..287 lit/len, 288..319 distance
     uint8_t  out[OUTB];
@@ -75,13 +83,17 @@ struct DLds {
     uint8_t  ll[288], dl[32], ml[19];            // code lengths
     uint16_t lcode[288], dcode[32], mcode[19];   // bit-reversed codewords
     uint8_t  msym[320], mbits[320];              // code-length RLE terms
+    uint8_t  cl[20];                             // code-length-code lengths in transmission order
 };
+// One instance per workgroup, at namespace scope so that the (non-inlined) block writer reaches it
+// with LDS instructions instead of through a generic pointer.
+__shared__ __attribute__((aligned(16))) DLds g_lds;
 
 struct Bits {                                    // LSB-first bit writer (LZ77.DeflatorOut.append)
     uint64_t acc; uint32_t nacc;
     uint64_t total;                              // bytes produced so far
     uint64_t flushed;
-    uint8_t *dst; uint64_t cap; bool overflow;
+    gbyte *dst; uint64_t cap; bool overflow;
 };
 
 __device__ __forceinline__ void put(DLds &s, Bits &b, uint32_t bits, uint32_t count, int lane)
@@ -89,11 +101,11 @@ __device__ __forceinline__ void put(DLds &s, Bits &b, uint32_t bits, uint32_t co
     b.acc |= (uint64_t)(bits & ((1u << count) - 1)) << b.nacc;
     b.nacc += count;
     while (b.nacc >= 8) {
-        if (lane == 0) s.out[b.total & (OUTB - 1)] = (uint8_t)b.acc;
+        s.out[b.total & (OUTB - 1)] = (uint8_t)b.acc;          // (every lane, same byte: no lane-dependent branch)
         b.total++; b.acc >>= 8; b.nacc -= 8;
     }
 }
-__device__ void drain(DLds &s, Bits &b, uint64_t upto, int lane)
+__device__ __forceinline__ void drain(DLds &s, Bits &b, uint64_t upto, int lane)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     for (uint64_t i = b.flushed + lane; i < upto; i += 64) {
@@ -112,8 +124,9 @@ __device__ __forceinline__ void maybe_drain(DLds &s, Bits &b, int lane)
 // in freq[0..n): code length per symbol into len[].  The heap (LZ77.Heap.swift) is replayed
 // exactly -- which two nodes merge on equal keys depends on its sift order -- but its values are
 // node ids: the reference's per-level leaf-count vectors are the depth histogram of the tree.
-__device__ void build_tree(DLds &s, const uint32_t *freq, int n, int limit, uint8_t *len, int lane)
+__device__ __attribute__((noinline)) void build_tree(const uint32_t *freq, int n, int limit, uint8_t *len, int lane)
 {
+    DLds &s = g_lds;
     for (int i = lane; i < n; i += 64) len[i] = 0;
     // rank = position in (descending frequency, ascending symbol) order
     int m = 0;
@@ -216,7 +229,7 @@ __device__ void build_tree(DLds &s, const uint32_t *freq, int n, int limit, uint
 }
 
 // canonical codewords, bit-reversed for LSB-first emission (HuffmanTree.codewords :206-230)
-__device__ void make_codes(const uint8_t *len, int n, uint16_t *code, int lane)
+__device__ __attribute__((noinline)) void make_codes(const uint8_t *len, int n, uint16_t *code, int lane)
 {
     if (lane == 0) {
         uint32_t counter = 0;
@@ -232,8 +245,9 @@ __device__ void make_codes(const uint8_t *len, int n, uint16_t *code, int lane)
 }
 
 // Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), greedy / lazy form
-__device__ void write_block(DLds &s, Bits &b, int count, bool final, int lane)
+__device__ __attribute__((noinline)) Bits write_block(Bits b, int count, bool final, int lane)
 {
+    DLds &s = g_lds;
     // DeflatorMatches.trees() (:138-159)
     for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -245,8 +259,8 @@ __device__ void write_block(DLds &s, Bits &b, int count, bool final, int lane)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) s.freq[256] = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    build_tree(s, s.freq, 286, 15, s.ll, lane);
-    build_tree(s, s.freq + 288, 30, 15, s.dl, lane);
+    build_tree(s.freq, 286, 15, s.ll, lane);
+    build_tree(s.freq + 288, 30, 15, s.dl, lane);
     if (lane < 2) { s.ll[286 + lane] = 0; s.dl[30 + lane] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 
@@ -282,23 +296,28 @@ __device__ void write_block(DLds &s, Bits &b, int count, bool final, int lane)
     }
     r = __builtin_amdgcn_readfirstlane(r); dn = __builtin_amdgcn_readfirstlane(dn); nm = __builtin_amdgcn_readfirstlane(nm);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    build_tree(s, s.freq, 19, 7, s.ml, lane);
+    build_tree(s.freq, 19, 7, s.ml, lane);
     make_codes(s.ll, 288, s.lcode, lane);
     make_codes(s.dl, 32, s.dcode, lane);
     make_codes(s.ml, 19, s.mcode, lane);
 
     // writeBlockMetadata (:577-612)
-    const int ZPOS[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};
-    uint8_t cl[19];
-    for (int k = 0; k < 19; ++k) cl[k] = 0;
-    for (int sym = 0; sym < 19; ++sym) if (s.ml[sym]) cl[ZPOS[sym]] = s.ml[sym];
-    int ncl = 19; while (ncl > 0 && cl[ncl - 1] == 0) --ncl;
+    // (in LDS: a local array indexed at run time would live in scratch memory)
+    if (lane < 19) {
+        const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   // symbol sent k-th
+        uint32_t sym = 0;
+#pragma unroll
+        for (int k = 0; k < 19; ++k) if (lane == k) sym = order[k];
+        s.cl[lane] = s.ml[sym];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    int ncl = 19; while (ncl > 0 && UNI(s.cl[ncl - 1]) == 0) --ncl;
     if (ncl < 4) ncl = 4;
     put(s, b, final ? 5 : 4, 3, lane);
     put(s, b, (uint32_t)(r - 257), 5, lane);
     put(s, b, (uint32_t)(dn - 1), 5, lane);
     put(s, b, (uint32_t)(ncl - 4), 4, lane);
-    for (int k = 0; k < ncl; ++k) put(s, b, cl[k], 3, lane);
+    for (int k = 0; k < ncl; ++k) put(s, b, UNI(s.cl[k]), 3, lane);
     // writeBlockTables (:615-623)
     for (int k = 0; k < nm; ++k) {
         const uint32_t sym = s.msym[k];
@@ -320,12 +339,13 @@ __device__ void write_block(DLds &s, Bits &b, int count, bool final, int lane)
     }
     put(s, b, s.lcode[256], s.ll[256], lane);
     maybe_drain(s, b, lane);
+    return b;
 }
 
-__device__ __forceinline__ uint32_t load32(const uint8_t *p) { return ((const U32u *)p)->v; }
+__device__ __forceinline__ uint32_t load32(const gbyte *p) { return ((const gU32u *)p)->v; }
 
 // bytes of position q.. and p.. agree for how many bytes (<= limit)?  Dword-wise from the input.
-__device__ __forceinline__ uint32_t common_prefix(const uint8_t *in, uint64_t q, uint64_t p, uint32_t limit)
+__device__ __forceinline__ uint32_t common_prefix(const gbyte *in, uint64_t q, uint64_t p, uint32_t limit)
 {
     uint32_t i = 0;
     while (i + 4 <= limit) {
@@ -350,22 +370,27 @@ __device__ __forceinline__ uint32_t common_prefix(const uint8_t *in, uint64_t q,
 __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restrict__ jobs,
                                                      spng_result *__restrict__ results)
 {
-    __shared__ __attribute__((aligned(16))) DLds s;
-    const DeflateJob job = jobs[blockIdx.x];
+    DLds &s = g_lds;
+    const DeflateJob *jp = jobs + blockIdx.x;
     const int lane = threadIdx.x;
-    const uint8_t *in = job.src;
-    const uint64_t n = job.src_len;
-    uint32_t *ring = job.ring;                                 // 65536 links: distance | tag << 16
+    // job fields are wave-uniform: pinned to scalar registers, typed as global memory
+    const gbyte *in = (const gbyte *)uni64((uint64_t)jp->src);
+    const uint64_t n = uni64(jp->src_len);
+    gword *ring = (gword *)uni64((uint64_t)jp->ring);          // 65536 links: distance | tag << 16
+    struct { gbyte *dst; uint64_t dst_cap; int32_t format, level; uint32_t image; } job = {
+        (gbyte *)uni64((uint64_t)jp->dst), uni64(jp->dst_cap), (int32_t)UNI(jp->format), (int32_t)UNI(jp->level), UNI(jp->image) };
 
     // DeflatorSearch.init(level:) (:13-35), greedy and lazy rows
     const int level = job.level < 0 ? 0 : job.level;
     const bool lazy = level >= 4;
-    const int ATT[8] = {1, 2, 4, 40, 20, 40, 64, 100}, GOAL[8] = {6, 8, 10, 24, 32, 54, 80, 160};
-    const int attempts = ATT[level & 7], goal = GOAL[level & 7];
+    // (packed constants: run-time indexed local arrays would live in scratch memory)
+    const int lv = level & 7;
+    const int attempts = lv == 0 ? 1 : lv == 1 ? 2 : lv == 2 ? 4 : lv == 3 ? 40 : lv == 4 ? 20 : lv == 5 ? 40 : lv == 6 ? 64 : 100;
+    const int goal = lv == 0 ? 6 : lv == 1 ? 8 : lv == 2 ? 10 : lv == 3 ? 24 : lv == 4 ? 32 : lv == 5 ? 54 : lv == 6 ? 80 : 160;
 
     Bits b = {0, 0, 0, 0, job.dst, job.dst_cap, false};
     if (job.format == SPNG_FORMAT_ZLIB) put(s, b, 0x0178, 16, lane);   // StreamHeader.write, exponent 15
-    for (int i = lane; i < (1 << HBITS); i += 64) s.head[i] = NONE;
+    for (int i = lane; i <= (1 << HBITS); i += 64) s.head[i] = NONE;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 
     DPROF_DECL
@@ -415,8 +440,8 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                     dist = d <= 32767 ? (uint32_t)d : 0;
                 }
                 if (p < n) ring[p & 65535] = dist | tag << 16;
-                if (live && !later) s.head[h & ((1 << HBITS) - 1)] = (uint32_t)p;
-                inserted += 64;
+                s.head[live && !later ? h & ((1 << HBITS) - 1) : 1 << HBITS] = (uint32_t)p;   // (idle lanes: the spare slot)
+                inserted = uni64(inserted + 64);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             }
         };
@@ -462,10 +487,10 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
             uint32_t t = 0;
             bool stop = false;
             while (t < 64 && w + t < last_main && !stop) {
-                if (!(unfilled() > (lazy ? 1 : 0))) { DPROF_END(2); DPROF_BEGIN(); write_block(s, b, count, false, lane); count = 0; DPROF_END(3); DPROF_BEGIN(); }
+                if (!(unfilled() > (lazy ? 1 : 0))) { DPROF_END(2); DPROF_BEGIN(); b = write_block(b, count, false, lane); count = 0; DPROF_END(3); DPROF_BEGIN(); }
                 const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)mrun, (int)t);
                 const uint32_t lit = (uint32_t)__builtin_amdgcn_readlane((int)mylit, (int)t);
-                if (!run) { if (lane == 0) s.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
+                if (!run) { s.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
                 uint32_t use_run = run, use_dist = (uint32_t)__builtin_amdgcn_readlane((int)best_dist, (int)t);
                 uint32_t adv = run;
                 if (lazy) {
@@ -474,7 +499,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                     // lazy match at a+1 (:293-299); it exists only if that position is still searched
                     const uint32_t lrun = (w + t + 1 < last_main) ? (uint32_t)__builtin_amdgcn_readlane((int)mrun, (int)(t + 1)) : 0u;
                     if (lrun > run) {
-                        if (lane == 0) s.terms[count] = 0xf8000000u | lit;
+                        s.terms[count] = 0xf8000000u | lit;
                         ++count;
                         use_run = lrun; use_dist = (uint32_t)__builtin_amdgcn_readlane((int)best_dist, (int)(t + 1));
                         adv = 1 + lrun;
@@ -482,23 +507,22 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                 }
                 // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
                 const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
-                if (lane == 0)
-                    s.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
+                s.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
                 ++count;
                 t += adv;
             }
-            w += t;
+            w = uni64(w + t);
             DPROF_END(2);
         }
         insert_upto(n);                                        // Adler-32 over the tail
         // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
         for (uint64_t p = w; p < n; ++p) {
-            if (!(unfilled() > 0)) { write_block(s, b, count, false, lane); count = 0; }
-            if (lane == 0) s.terms[count] = 0xf8000000u | in[p];
+            if (!(unfilled() > 0)) { b = write_block(b, count, false, lane); count = 0; }
+            s.terms[count] = 0xf8000000u | UNI(in[p]);
             ++count;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        write_block(s, b, count, true, lane);
+        b = write_block(b, count, true, lane);
     }
 
     if (job.format == SPNG_FORMAT_ZLIB) {
