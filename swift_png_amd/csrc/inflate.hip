@@ -758,7 +758,10 @@ __device__ __attribute__((always_inline)) void scout(Lds &s, const gbyte *src, u
                     cons_seen = UNI(LDS_LOAD(&s.c.w_cons));
                     if (k - cons_seen < WD) break;
                     stop = (UNI(LDS_LOAD(&s.c.w_stop)) == gen) | UNI(LDS_LOAD(&s.c.w_quit));
-                    __builtin_amdgcn_s_sleep(1);
+#ifndef SPNG_S_SLEEP
+#define SPNG_S_SLEEP 1
+#endif
+                    __builtin_amdgcn_s_sleep(SPNG_S_SLEEP);
                     if (spins > SPIN_LIMIT) SPIN_ABORT();
                 }
                 SPROF_ADD(sp_wait);
