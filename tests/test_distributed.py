@@ -27,7 +27,7 @@ def _make_image(i, w=24, h=10):
     return img
 
 
-def _worker(rank, world, port, total, q):
+def _worker(rank, world, port, total, q, weak=False):
     sys.path.insert(0, os.path.dirname(__file__))
     sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -37,7 +37,9 @@ def _worker(rank, world, port, total, q):
     S = w * h * 4
     lo, hi = shard(total, world, rank)
     local = []
-    for i in range(lo, hi):
+    # weak scaling (bench.py's default): every rank decodes the whole batch and contributes its
+    # shard of the result; strong: it only decodes its shard
+    for i in range(0 if weak else lo, total if weak else hi):
         img = _make_image(i, w, h)
         rows = ph.orc_filter(img.reshape(-1), w, h, 8, 4, False)
         png = ph.Png(w, h, 8, 6, False, False, zlib.compress(rows, 6))
@@ -45,6 +47,8 @@ def _worker(rank, world, port, total, q):
         assert st == 0
         local.append(torch.from_numpy(storage.copy()))
     local = torch.cat(local) if local else torch.empty(0, dtype=torch.uint8)
+    if weak:
+        local = local[lo * S:hi * S]
     out = gather_decoded(local, S, total, world, rank)
     if rank == 0:
         ok = True
@@ -57,12 +61,12 @@ def _worker(rank, world, port, total, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [7, 8])
-def test_shard_and_gather_world2(total):
+@pytest.mark.parametrize("total,weak", [(7, False), (8, False), (8, True)])
+def test_shard_and_gather_world2(total, weak):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q, weak)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
