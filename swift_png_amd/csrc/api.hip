@@ -387,6 +387,9 @@ int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t 
     }
     HIP_TRY(hipMemcpyAsync(c->d_ws, c->h_ws, upload, hipMemcpyHostToDevice, c->stream));
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
+    // A stream whose waves gave up on each other (inflate.hip: SPIN_LIMIT) never writes its result:
+    // make such a slot read as a device error instead of whatever the memory held before.
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)dr, SPNG_E_DEVICE, count * sizeof(spng_result) / 4, c->stream));
     {
         Timed t(c, SPNG_K_INFLATE);
         HIP_TRY(launch_inflate(a.dev<InflateJob>(jobs), count, dr, c->stream));
@@ -468,6 +471,7 @@ int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
     const size_t first = (res_bytes + 255) & ~(size_t)255;
     HIP_TRY(hipMemcpyAsync((char *)c->d_ws + first, (char *)c->h_ws + first, a.off - first,
                            hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)dr, SPNG_E_DEVICE, res_bytes / 4, c->stream));   // see spng_inflate_batch
     {
         Timed t(c, SPNG_K_INFLATE);
         HIP_TRY(launch_inflate(a.dev<InflateJob>(jobs), count, dr, c->stream));
