@@ -87,15 +87,15 @@ struct spng_ctx {
     {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
-        hipEventCreate(&e);
+        (void)hipEventCreate(&e);
         return e;
     }
 };
 
 struct Timed {            // records a pair of events around a launch when profiling is on
     spng_ctx *c; int k; hipEvent_t a = nullptr;
-    Timed(spng_ctx *c_, int k_) : c(c_), k(k_) { if (c->profiling) { a = c->event(); hipEventRecord(a, c->stream); } }
-    ~Timed() { if (a) { hipEvent_t b = c->event(); hipEventRecord(b, c->stream); c->spans.push_back({k, a, b}); } }
+    Timed(spng_ctx *c_, int k_) : c(c_), k(k_) { if (c->profiling) { a = c->event(); (void)hipEventRecord(a, c->stream); } }
+    ~Timed() { if (a) { hipEvent_t b = c->event(); (void)hipEventRecord(b, c->stream); c->spans.push_back({k, a, b}); } }
 };
 
 // simple bump allocator over the paired pinned/device workspaces
@@ -185,14 +185,14 @@ int32_t spng_create(int device, void *stream, spng_ctx **out)
 void spng_destroy(spng_ctx *c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    for (auto &s : c->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
-    for (auto e : c->pool) hipEventDestroy(e);
-    if (c->d_ws) hipFree(c->d_ws);
-    if (c->h_ws) hipHostFree(c->h_ws);
-    if (c->d_ring) hipFree(c->d_ring);
-    if (c->owns_stream) hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto e : c->pool) (void)hipEventDestroy(e);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->h_ws) (void)hipHostFree(c->h_ws);
+    if (c->d_ring) (void)hipFree(c->d_ring);
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -490,7 +490,7 @@ int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
 
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) hipFree(p); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
 };
 
