@@ -720,7 +720,9 @@ __device__ __attribute__((always_inline)) void scout(Lds &s, const gbyte *src, u
         const uint32_t g = UNI(LDS_LOAD(&s.c.w_gen));
         quit = UNI(LDS_LOAD(&s.c.w_quit));
         if (g == gen || quit) {
-            __builtin_amdgcn_s_sleep(2);
+            // long naps: the scout may legitimately idle for as long as the walker copies stored
+            // blocks (a whole level-0 stream), which must stay far away from the spin limit
+            __builtin_amdgcn_s_sleep(32);
             if (++idle_spins > SPIN_LIMIT) SPIN_ABORT();
             continue;
         }
