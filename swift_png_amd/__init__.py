@@ -113,6 +113,13 @@ def load_library():
     if not LIB_PATH.exists():
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # One HIP runtime per process.  libspng_mi355.so NEEDs libamdhip64.so.7; the torch wheel bundles its
+    # own copy with the same SONAME (plus its own HSA runtime).  If the system copy is mapped first and
+    # torch is imported afterwards, torch is bound to the system libamdhip64 but still loads its bundled
+    # HSA runtime, and device discovery fails ("no ROCm-capable device").  This Python host uses torch for
+    # device memory, so torch's runtime goes in first and the library rides it.  A torch-free host (the
+    # Swift binding of INTEGRATION.md, tests/test_torch_free.py) simply gets the system runtime.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(str(LIB_PATH))
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32
     rp = ctypes.POINTER(Result)

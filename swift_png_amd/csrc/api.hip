@@ -61,7 +61,17 @@ struct spng_ctx {
     bool owns_stream = false;
     // device + pinned workspaces for job tables
     void *d_ws = nullptr;  size_t d_ws_cap = 0;
-    void *h_ws = nullptr;  size_t h_ws_cap = 0;
+    // Pinned staging for the job tables.  An entry point fills a slab on the host, enqueues its
+    // upload and may return before the copy engine has read it (h_results == NULL), so the next
+    // call must not scribble over the same pinned bytes: slabs are used round-robin and each is
+    // guarded by an event recorded behind its upload.  (The device copy d_ws needs no such care: the
+    // next upload is ordered behind the kernels that read the previous tables by the stream itself.)
+    static constexpr int SLABS = 4;
+    struct Slab { void *h = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    Slab slabs[SLABS];
+    int slab_next = 0;
+    void *h_ws = nullptr;                 // the slab of the call in progress
+    Slab *cur = nullptr;
     void *d_ring = nullptr; size_t ring_cap = 0;     // deflate link rings
     // profiling
     bool profiling = false;
@@ -70,17 +80,38 @@ struct spng_ctx {
     std::vector<hipEvent_t> pool;
     std::mutex mu;
 
+    // Starts a call: device table space for `bytes`, and a pinned slab nobody is reading any more.
     int32_t reserve(size_t bytes)
     {
-        if (bytes <= d_ws_cap) return SPNG_DONE;
-        // the previous tables may still be read by in-flight kernels
-        HIP_TRY(hipStreamSynchronize(stream));
-        if (d_ws) { HIP_TRY(hipFree(d_ws)); d_ws = nullptr; }
-        if (h_ws) { HIP_TRY(hipHostFree(h_ws)); h_ws = nullptr; }
-        size_t cap = bytes + bytes / 2 + 4096;
-        HIP_TRY(hipMalloc(&d_ws, cap));
-        HIP_TRY(hipHostMalloc(&h_ws, cap, hipHostMallocDefault));
-        d_ws_cap = h_ws_cap = cap;
+        if (bytes > d_ws_cap) {
+            // the previous tables may still be read by in-flight kernels
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (d_ws) { HIP_TRY(hipFree(d_ws)); d_ws = nullptr; }
+            const size_t cap = bytes + bytes / 2 + 4096;
+            HIP_TRY(hipMalloc(&d_ws, cap));
+            d_ws_cap = cap;
+        }
+        Slab &sl = slabs[slab_next];
+        slab_next = (slab_next + 1) % SLABS;
+        if (sl.pending) { HIP_TRY(hipEventSynchronize(sl.ev)); sl.pending = false; }
+        if (bytes > sl.cap) {
+            if (sl.h) { HIP_TRY(hipHostFree(sl.h)); sl.h = nullptr; sl.cap = 0; }
+            const size_t cap = bytes + bytes / 2 + 4096;
+            HIP_TRY(hipHostMalloc(&sl.h, cap, hipHostMallocDefault));
+            sl.cap = cap;
+        }
+        if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        cur = &sl; h_ws = sl.h;
+        return SPNG_DONE;
+    }
+    // Enqueues the upload of slab bytes [from, to) to the same offsets of d_ws and marks the slab busy
+    // until the copy has executed.
+    int32_t upload(size_t from, size_t to)
+    {
+        if (to > from)
+            HIP_TRY(hipMemcpyAsync((char *)d_ws + from, (char *)h_ws + from, to - from, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(cur->ev, stream));
+        cur->pending = true;
         return SPNG_DONE;
     }
     hipEvent_t event()
@@ -190,7 +221,7 @@ void spng_destroy(spng_ctx *c)
     for (auto &s : c->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto e : c->pool) (void)hipEventDestroy(e);
     if (c->d_ws) (void)hipFree(c->d_ws);
-    if (c->h_ws) (void)hipHostFree(c->h_ws);
+    for (auto &sl : c->slabs) { if (sl.h) (void)hipHostFree(sl.h); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     if (c->d_ring) (void)hipFree(c->d_ring);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -246,6 +277,17 @@ __global__ void finish_decode_kernel(spng_result *results, const uint64_t *expec
     if (st == SPNG_E_OUTPUT_CAPACITY ||
         ((st == SPNG_DONE || st == SPNG_NEED_MORE_INPUT) && results[i].written > expected[i]))
         results[i].status = SPNG_E_EXTRANEOUS_IMAGE_DATA;
+}
+
+// A stream whose waves gave up on each other (inflate.hip: SPIN_LIMIT) never writes its result: such
+// a slot must read as a device error that wrote and consumed nothing.
+__global__ void poison_results_kernel(spng_result *results, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    results[i].status = SPNG_E_DEVICE; results[i].reserved = 0;
+    results[i].written = 0; results[i].consumed = 0;
+    results[i].aux[0] = results[i].aux[1] = 0;
 }
 
 __global__ void init_results_kernel(spng_result *results, const uint64_t *written, uint32_t count)
@@ -385,11 +427,10 @@ int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t 
         a.host<InflateJob>(jobs)[i] = InflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst,
                                                  descs[i].src_len, descs[i].dst_cap, descs[i].format, i};
     }
-    HIP_TRY(hipMemcpyAsync(c->d_ws, c->h_ws, upload, hipMemcpyHostToDevice, c->stream));
+    if (int32_t st = c->upload(0, upload)) return st;
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
-    // A stream whose waves gave up on each other (inflate.hip: SPIN_LIMIT) never writes its result:
-    // make such a slot read as a device error instead of whatever the memory held before.
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)dr, SPNG_E_DEVICE, count * sizeof(spng_result) / 4, c->stream));
+    poison_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, count);
+    HIP_TRY(hipGetLastError());
     {
         Timed t(c, SPNG_K_INFLATE);
         HIP_TRY(launch_inflate(a.dev<InflateJob>(jobs), count, dr, c->stream));
@@ -422,7 +463,7 @@ int32_t spng_unfilter_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t 
                                                            descs[i].channels, descs[i].interlaced);
     const size_t upload = a.off;
     const size_t res = a.take(count * sizeof(spng_result));
-    HIP_TRY(hipMemcpyAsync(c->d_ws, c->h_ws, upload, hipMemcpyHostToDevice, c->stream));
+    if (int32_t st = c->upload(0, upload)) return st;
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
     // results: status DONE, written = rows_len (or U); then extraneous check
     init_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(
@@ -469,9 +510,9 @@ int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
     stage_plan(plan, a, slots);
     // upload everything except the results region at the front
     const size_t first = (res_bytes + 255) & ~(size_t)255;
-    HIP_TRY(hipMemcpyAsync((char *)c->d_ws + first, (char *)c->h_ws + first, a.off - first,
-                           hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)dr, SPNG_E_DEVICE, res_bytes / 4, c->stream));   // see spng_inflate_batch
+    if (int32_t st = c->upload(first, a.off)) return st;
+    poison_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, count);
+    HIP_TRY(hipGetLastError());
     {
         Timed t(c, SPNG_K_INFLATE);
         HIP_TRY(launch_inflate(a.dev<InflateJob>(jobs), count, dr, c->stream));
@@ -504,7 +545,8 @@ int32_t spng_inflate(spng_ctx *c, const void *src, uint64_t n, int32_t format,
     HIP_TRY(hipMemcpyAsync(ds.p, src, n, hipMemcpyHostToDevice, c->stream));
     spng_stream_desc d{ds.p, n, dd.p, cap, format, 0};
     if (int32_t st = spng_inflate_batch(c, &d, 1, nullptr, result)) return st;
-    if (result->written) HIP_TRY(hipMemcpy(dst, dd.p, result->written, hipMemcpyDeviceToHost));
+    const uint64_t w = result->written < cap ? result->written : cap;
+    if (w) HIP_TRY(hipMemcpy(dst, dd.p, w, hipMemcpyDeviceToHost));
     return SPNG_DONE;
 }
 
@@ -621,7 +663,7 @@ int32_t spng_filter_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
     memcpy(a.host<uint64_t>(wslot), sizes.data(), count * 8);
     const size_t upload = a.off;
     const size_t res = a.take(count * sizeof(spng_result));
-    HIP_TRY(hipMemcpyAsync(c->d_ws, c->h_ws, upload, hipMemcpyHostToDevice, c->stream));
+    if (int32_t st = c->upload(0, upload)) return st;
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
     {
         Timed t(c, SPNG_K_FILTER);
@@ -671,8 +713,7 @@ static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_r
     }
     for (size_t i = 0; i < jobs.size(); ++i) jobs[i].ring = (uint32_t *)c->d_ring + i * 65536;
     memcpy(a.host<DeflateJob>(jslot), jobs.data(), jobs.size() * sizeof(DeflateJob));
-    HIP_TRY(hipMemcpyAsync((char *)c->d_ws + jslot, (char *)c->h_ws + jslot, jobs.size() * sizeof(DeflateJob),
-                           hipMemcpyHostToDevice, c->stream));
+    if (int32_t st = c->upload(jslot, jslot + jobs.size() * sizeof(DeflateJob))) return st;
     Timed t(c, SPNG_K_DEFLATE);
     HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)jobs.size(), dr, c->stream));
     return SPNG_DONE;

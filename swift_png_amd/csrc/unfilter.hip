@@ -120,7 +120,8 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t mine, uint32_t top)
 __device__ __forceinline__ bool skip_status(int32_t s)
 {
     // the reference assigns no rows in a push whose inflate threw (PNG.Decoder.swift:57)
-    return (s >= 16 && s < 48) || s == SPNG_E_REFERENCE_UNDEFINED;
+    // (nor is there anything to assign when the device gave up on the stream)
+    return (s >= 16 && s < 48) || s == SPNG_E_REFERENCE_UNDEFINED || s == SPNG_E_DEVICE;
 }
 
 // ---- reconstruction of one tile: generic byte-wise form (any bpp) ----------------------------
