@@ -63,7 +63,7 @@ typedef struct spng_ctx spng_ctx;     /* owns one device, one HIP stream, its wo
 /* Result of one unit of work (one stream / one image). */
 typedef struct spng_result {
     int32_t  status;
-    int32_t  reserved;
+    int32_t  reserved;                /* inflate / decode: 1 = produced by the parallel pipeline, 0 = serial kernel */
     uint64_t written;                 /* bytes produced (inflate: inflated bytes; deflate: stream bytes) */
     uint64_t consumed;                /* compressed bytes consumed through the end of the stream */
     uint64_t aux[2];                  /* error payload, see the status table */
@@ -108,9 +108,21 @@ void    spng_destroy(spng_ctx *ctx);
 void   *spng_stream(spng_ctx *ctx);                             /* the hipStream_t kernels launch on */
 int32_t spng_sync(spng_ctx *ctx);                               /* hipStreamSynchronize */
 
+/* Tuning knobs of a context (none changes results).  value 0 = automatic. */
+enum { SPNG_CFG_INFLATE_MODE = 0,   /* SPNG_INFLATE_AUTO: parallel pipeline, serial kernel for what it declines;
+                                       SPNG_INFLATE_SERIAL: serial kernel only */
+       SPNG_CFG_SEGMENT_BYTES = 1,  /* parallel inflate: nominal segment length in compressed bytes */
+       SPNG_CFG_TOKEN_BYTES = 2,    /* parallel inflate: size limit of the token buffer in bytes */
+       SPNG_CFG_COUNT = 3 };
+enum { SPNG_INFLATE_AUTO = 0, SPNG_INFLATE_SERIAL = 1 };
+int32_t spng_configure(spng_ctx *ctx, int key, int64_t value);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around every launch. */
-enum { SPNG_K_INFLATE = 0, SPNG_K_UNFILTER = 1, SPNG_K_SCATTER = 2, SPNG_K_FILTER = 3,
-       SPNG_K_DEFLATE = 4, SPNG_K_ADLER = 5, SPNG_K_COUNT = 8 };
+enum { SPNG_K_INFLATE = 0,          /* the serial inflate kernel (streams the parallel pipeline left to it) */
+       SPNG_K_UNFILTER = 1, SPNG_K_SCATTER = 2, SPNG_K_FILTER = 3,
+       SPNG_K_DEFLATE = 4, SPNG_K_ADLER = 5,
+       SPNG_K_PINFLATE = 6,         /* the parallel inflate pipeline: find + count + scan + emit + resolve */
+       SPNG_K_COUNT = 8 };
 int32_t spng_profile(spng_ctx *ctx, int enable);                /* enable/disable + reset counters  */
 int32_t spng_profile_get(spng_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
 

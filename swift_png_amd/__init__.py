@@ -29,12 +29,14 @@ E_COMPRESSION_METHOD, E_WINDOW_SIZE, E_CHECK_BITS, E_DICTIONARY = 16, 17, 18, 19
 E_EXTRANEOUS_IMAGE_DATA, E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM = 48, 49, 50
 E_OUTPUT_CAPACITY, E_ARGUMENT, E_DEVICE, E_REFERENCE_UNDEFINED = 64, 65, 66, 67
 FORMAT_ZLIB, FORMAT_IOS = 0, 1
-K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER = 0, 1, 2, 3, 4, 5
+K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER, K_PINFLATE = 0, 1, 2, 3, 4, 5, 6
+CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES = 0, 1, 2
+INFLATE_AUTO, INFLATE_SERIAL = 0, 1
 
 EXPORTS = [
     "spng_version", "spng_status_string", "spng_last_error_string", "spng_inflated_size",
     "spng_storage_size", "spng_create", "spng_destroy", "spng_stream", "spng_sync", "spng_profile",
-    "spng_profile_get", "spng_inflate_batch", "spng_unfilter_batch", "spng_decode_batch",
+    "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_unfilter_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
     "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_encode_batch",
 ]
@@ -137,6 +139,7 @@ def load_library():
     lib.spng_stream.restype = vp
     lib.spng_stream.argtypes = [vp]
     lib.spng_sync.argtypes = [vp]
+    lib.spng_configure.argtypes = [vp, ctypes.c_int, ctypes.c_int64]
     lib.spng_profile.argtypes = [vp, ctypes.c_int]
     lib.spng_profile_get.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
     lib.spng_inflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), u32, vp, rp]
@@ -211,6 +214,9 @@ class Session:
     # -- plumbing -------------------------------------------------------------------------------
     def sync(self):
         _check(self.lib, self.lib.spng_sync(self.ctx))
+
+    def configure(self, key, value):
+        _check(self.lib, self.lib.spng_configure(self.ctx, key, int(value)))
 
     def profile(self, enable=True):
         _check(self.lib, self.lib.spng_profile(self.ctx, int(enable)))

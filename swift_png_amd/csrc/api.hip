@@ -73,6 +73,10 @@ struct spng_ctx {
     void *h_ws = nullptr;                 // the slab of the call in progress
     Slab *cur = nullptr;
     void *d_ring = nullptr; size_t ring_cap = 0;     // deflate link rings
+    // parallel inflate (pinflate.hip): chunk-record slab, token buffer, knobs (spng_configure)
+    void *d_log = nullptr;  size_t log_cap = 0;
+    void *d_tok = nullptr;  size_t tok_cap = 0;      // bytes
+    int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0};
     // profiling
     bool profiling = false;
     struct Span { int kernel; hipEvent_t a, b; };
@@ -223,6 +227,8 @@ void spng_destroy(spng_ctx *c)
     if (c->d_ws) (void)hipFree(c->d_ws);
     for (auto &sl : c->slabs) { if (sl.h) (void)hipHostFree(sl.h); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     if (c->d_ring) (void)hipFree(c->d_ring);
+    if (c->d_log) (void)hipFree(c->d_log);
+    if (c->d_tok) (void)hipFree(c->d_tok);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -233,6 +239,14 @@ int32_t spng_sync(spng_ctx *c)
 {
     if (!c) return SPNG_E_ARGUMENT;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPNG_DONE;
+}
+
+int32_t spng_configure(spng_ctx *c, int key, int64_t value)
+{
+    if (!c || key < 0 || key >= SPNG_CFG_COUNT || value < 0) return SPNG_E_ARGUMENT;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->cfg[key] = value;
     return SPNG_DONE;
 }
 
@@ -396,6 +410,152 @@ static int32_t launch_plan(spng_ctx *c, const UnfilterPlan &plan, Arena &a, cons
     return SPNG_DONE;
 }
 
+// ---- inflate stage: the parallel pipeline (pinflate.hip) in front of the serial kernel (inflate.hip) ----
+struct InflatePlan {
+    std::vector<InflateJob> jobs;
+    std::vector<PStream> streams;
+    std::vector<PSeg> segs;
+    size_t log_bytes = 0;
+    uint64_t tok_cap = 0;            // tokens
+    uint32_t passes = 0;
+    bool parallel = false;
+    size_t jobs_at = 0, streams_at = 0, segs_at = 0, done_at = 0;
+    size_t bytes() const
+    {
+        return jobs.size() * (sizeof(InflateJob) + sizeof(PStream) + 4) + segs.size() * sizeof(PSeg) + 2048;
+    }
+};
+
+// Cuts every stream into segments and makes sure the context owns a chunk-record slab and a token
+// buffer.  Segment length: long enough that the search for a block header (which costs more per bit
+// than decoding) stays a small part of a segment's work, short enough that the batch yields several
+// thousand segments, i.e. a few waves per SIMD.
+static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
+{
+    p.parallel = c->cfg[SPNG_CFG_INFLATE_MODE] != SPNG_INFLATE_SERIAL && !p.jobs.empty();
+    if (!p.parallel) return SPNG_DONE;
+    uint64_t total = 0;
+    for (auto &j : p.jobs) total += j.src_len;
+    uint64_t seg_bytes = (uint64_t)c->cfg[SPNG_CFG_SEGMENT_BYTES];
+    if (!seg_bytes) {
+        seg_bytes = total / 8192;
+        if (seg_bytes < (256u << 10)) seg_bytes = 256u << 10;
+    }
+    seg_bytes = (seg_bytes + 255) & ~(uint64_t)255;
+    p.streams.resize(p.jobs.size());
+    size_t log = 0;
+    for (size_t i = 0; i < p.jobs.size(); ++i) {
+        const InflateJob &j = p.jobs[i];
+        PStream &st = p.streams[i];
+        memset(&st, 0, sizeof st);
+        st.src = j.src; st.dst = j.dst; st.src_len = j.src_len; st.dst_cap = j.dst_cap;
+        st.format = j.format; st.image = j.image;
+        st.seg_first = (uint32_t)p.segs.size();
+        uint64_t k = (j.src_len + seg_bytes - 1) / seg_bytes;
+        if (k < 1) k = 1;
+        if (p.segs.size() + k > 0x7fffffffu) return SPNG_E_ARGUMENT;
+        st.seg_count = (uint32_t)k; st.seg_bytes = seg_bytes;
+        for (uint64_t q = 0; q < k; ++q) {
+            PSeg sg;
+            memset(&sg, 0, sizeof sg);
+            sg.stream = (uint32_t)i; sg.index = (uint32_t)q;
+            const uint64_t len = q + 1 < k ? seg_bytes : j.src_len - q * seg_bytes;
+            // chunk records: 272 bytes per 2304 bytes of Huffman data, one partial chunk per block on top
+            sg.log_cap = ((len / 3 + 8192) + 15) & ~(uint64_t)15;
+            sg.log_off = log; log += sg.log_cap;
+            sg.start_bit = ~0ull;
+            p.segs.push_back(sg);
+        }
+    }
+    p.log_bytes = log;
+    if (log > c->log_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_log) { HIP_TRY(hipFree(c->d_log)); c->d_log = nullptr; c->log_cap = 0; }
+        HIP_TRY(hipMalloc(&c->d_log, log + log / 8));
+        c->log_cap = log + log / 8;
+    }
+    // Tokens: 0.6 per compressed byte from zlib on PNG scanlines, 1.3 from swift-png's own level-6
+    // streams (more literals).  Two per byte, but never more than one per output byte, is the planning
+    // figure; the budget caps the buffer and the batch then takes several passes over it.  The buffer
+    // must hold the largest stream whole.
+    uint64_t want = 0, largest = 0;
+    for (auto &j : p.jobs) {
+        uint64_t t = 2 * j.src_len + 65536;
+        if (t > j.dst_cap + 64) t = j.dst_cap + 64;
+        want += t * 4;
+        if (t * 4 > largest) largest = t * 4;
+    }
+    uint64_t budget = (uint64_t)c->cfg[SPNG_CFG_TOKEN_BYTES];
+    if (!budget) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        budget = (uint64_t)(free_b + c->tok_cap) / 2;
+        if (budget < (64ull << 20)) budget = 64ull << 20;
+    }
+    if (budget < 2 * largest && !c->cfg[SPNG_CFG_TOKEN_BYTES]) budget = 2 * largest;
+    const uint64_t need = want < budget ? want : budget;
+    if (need > c->tok_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_tok) { HIP_TRY(hipFree(c->d_tok)); c->d_tok = nullptr; c->tok_cap = 0; }
+        HIP_TRY(hipMalloc(&c->d_tok, need));
+        c->tok_cap = need;
+    }
+    p.tok_cap = c->tok_cap / 4;
+    uint64_t passes = (want + c->tok_cap - 1) / c->tok_cap + 1;
+    p.passes = (uint32_t)(passes > 8 ? 8 : passes);
+    return SPNG_DONE;
+}
+
+static void stage_inflate(InflatePlan &p, Arena &a)
+{
+    const size_t n = p.jobs.size();
+    p.jobs_at = a.take(n * sizeof(InflateJob));
+    if (p.parallel) {
+        p.streams_at = a.take(n * sizeof(PStream));
+        p.segs_at = a.take(p.segs.size() * sizeof(PSeg));
+        p.done_at = a.take(n * 4);
+        memcpy(a.host<PStream>(p.streams_at), p.streams.data(), n * sizeof(PStream));
+        memcpy(a.host<PSeg>(p.segs_at), p.segs.data(), p.segs.size() * sizeof(PSeg));
+        memset(a.host<int32_t>(p.done_at), 0, n * 4);
+        for (size_t i = 0; i < n; ++i) p.jobs[i].skip = a.dev<int32_t>(p.done_at) + i;
+    }
+    memcpy(a.host<InflateJob>(p.jobs_at), p.jobs.data(), n * sizeof(InflateJob));
+}
+
+static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_result *dr)
+{
+    const uint32_t n = (uint32_t)p.jobs.size();
+    if (p.parallel) {
+        Timed t(c, SPNG_K_PINFLATE);
+        HIP_TRY(launch_pinflate(a.dev<PStream>(p.streams_at), n, a.dev<PSeg>(p.segs_at), (uint32_t)p.segs.size(),
+                                (uint8_t *)c->d_log, (uint32_t *)c->d_tok, p.tok_cap, p.passes, dr,
+                                a.dev<int32_t>(p.done_at), c->stream));
+    }
+    if (p.parallel && getenv("SPNG_TRACE_PINFLATE")) {
+        // diagnostic: how far every stream got in the pipeline (synchronises; never on by default)
+        std::vector<PStream> hs(n);
+        std::vector<PSeg> hg(p.segs.size());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(hs.data(), a.dev<PStream>(p.streams_at), n * sizeof(PStream), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hg.data(), a.dev<PSeg>(p.segs_at), hg.size() * sizeof(PSeg), hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n && i < 4; ++i) {
+            const PStream &st = hs[i];
+            fprintf(stderr, "[pinflate] stream %u: len %llu segs %u seg_bytes %llu ok %d pass %u ntok %llu end_bit %llu\n", i,
+                    (unsigned long long)st.src_len, st.seg_count, (unsigned long long)st.seg_bytes, st.ok, st.pass,
+                    (unsigned long long)st.ntok, (unsigned long long)st.end_bit);
+            for (uint32_t k = 0; k < st.seg_count && k < 12; ++k) {
+                const PSeg &sg = hg[st.seg_first + k];
+                fprintf(stderr, "   seg %u: start %lld end %lld status %d used %u ntok %llu tok_base %llu\n", k,
+                        (long long)sg.start_bit, (long long)sg.end_bit, sg.status, sg.used, (unsigned long long)sg.ntok,
+                        (unsigned long long)sg.tok_base);
+            }
+        }
+    }
+    Timed t(c, SPNG_K_INFLATE);
+    HIP_TRY(launch_inflate(a.dev<InflateJob>(p.jobs_at), n, dr, c->stream));
+    return SPNG_DONE;
+}
+
 static const uint64_t *rows_len_in_results(void *user, uint32_t i)
 {
     return &((spng_result *)user)[i].written;
@@ -416,25 +576,24 @@ int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t 
     if (!count) return SPNG_DONE;
     HIP_TRY(hipSetDevice(c->device));
     std::lock_guard<std::mutex> g(c->mu);
-    const size_t need = count * (sizeof(InflateJob) + sizeof(spng_result)) + 1024;
-    if (int32_t st = c->reserve(need)) return st;
-    Arena a{c};
-    const size_t jobs = a.take(count * sizeof(InflateJob));
-    const size_t upload = a.off;
-    const size_t res = a.take(count * sizeof(spng_result));
+    InflatePlan plan;
+    plan.jobs.resize(count);
     for (uint32_t i = 0; i < count; ++i) {
         if ((!descs[i].d_src && descs[i].src_len) || (!descs[i].d_dst && descs[i].dst_cap)) return SPNG_E_ARGUMENT;
-        a.host<InflateJob>(jobs)[i] = InflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst,
-                                                 descs[i].src_len, descs[i].dst_cap, descs[i].format, i};
+        plan.jobs[i] = InflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst,
+                                  descs[i].src_len, descs[i].dst_cap, descs[i].format, i, nullptr};
     }
+    if (int32_t st = plan_inflate(c, plan)) return st;
+    if (int32_t st = c->reserve(plan.bytes() + count * sizeof(spng_result) + 1024)) return st;
+    Arena a{c};
+    stage_inflate(plan, a);
+    const size_t upload = a.off;
+    const size_t res = a.take(count * sizeof(spng_result));
     if (int32_t st = c->upload(0, upload)) return st;
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
     poison_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, count);
     HIP_TRY(hipGetLastError());
-    {
-        Timed t(c, SPNG_K_INFLATE);
-        HIP_TRY(launch_inflate(a.dev<InflateJob>(jobs), count, dr, c->stream));
-    }
+    if (int32_t st = launch_inflate_plan(c, plan, a, dr)) return st;
     if (h_results) {
         HIP_TRY(hipMemcpyAsync(h_results, dr, count * sizeof(spng_result), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -489,21 +648,26 @@ int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
     // results live on the device from the start: the unfilter jobs read `written` from them
     const size_t res_bytes = count * sizeof(spng_result);
     UnfilterPlan plan;
+    InflatePlan ip;
+    ip.jobs.resize(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        const spng_image_desc &d = descs[i];
+        if (!d.d_idat && d.idat_len) return SPNG_E_ARGUMENT;
+        ip.jobs[i] = InflateJob{(const uint8_t *)d.d_idat, (uint8_t *)d.d_rows, d.idat_len, d.rows_cap, d.format, i, nullptr};
+    }
+    if (int32_t st = plan_inflate(c, ip)) return st;
     // two-phase: we need the device address of the results before planning
-    const size_t fixed = count * (sizeof(InflateJob) + 8) + res_bytes + 2048;
+    const size_t fixed = ip.bytes() + count * 8 + res_bytes + 2048;
     // conservative upper bound on plan size: 7 passes per image
     if (int32_t st = c->reserve(fixed + (size_t)count * 7 * (sizeof(UnfJob) + sizeof(ScatterJob) + 4) + 8192)) return st;
     Arena a{c};
     const size_t res = a.take(res_bytes);                      // first, so its device address is stable
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
     if (int32_t st = plan_unfilter(descs, count, plan, rows_len_in_results, (void *)dr)) return st;
-    const size_t jobs = a.take(count * sizeof(InflateJob));
+    stage_inflate(ip, a);
     const size_t expected = a.take(count * 8);
     for (uint32_t i = 0; i < count; ++i) {
         const spng_image_desc &d = descs[i];
-        if (!d.d_idat && d.idat_len) return SPNG_E_ARGUMENT;
-        a.host<InflateJob>(jobs)[i] = InflateJob{(const uint8_t *)d.d_idat, (uint8_t *)d.d_rows, d.idat_len,
-                                                 d.rows_cap, d.format, i};
         a.host<uint64_t>(expected)[i] = spng_inflated_size(d.width, d.height, d.depth, d.channels, d.interlaced);
     }
     PlanSlots slots;
@@ -513,10 +677,7 @@ int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
     if (int32_t st = c->upload(first, a.off)) return st;
     poison_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, count);
     HIP_TRY(hipGetLastError());
-    {
-        Timed t(c, SPNG_K_INFLATE);
-        HIP_TRY(launch_inflate(a.dev<InflateJob>(jobs), count, dr, c->stream));
-    }
+    if (int32_t st = launch_inflate_plan(c, ip, a, dr)) return st;
     if (int32_t st = launch_plan(c, plan, a, slots, dr)) return st;
     finish_decode_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, a.dev<uint64_t>(expected), count);
     HIP_TRY(hipGetLastError());

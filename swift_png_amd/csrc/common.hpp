@@ -58,6 +58,37 @@ struct InflateJob {
     uint64_t       dst_cap;
     int32_t        format;
     uint32_t       image;
+    const int32_t *skip;          // device flag: non-zero = the parallel pipeline already produced this stream
+};
+
+// ---- the parallel inflate pipeline (pinflate.hip) -----------------------------------------------
+// One stream of a batch.  The host fills the first group of fields, the kernels the second.
+struct PStream {
+    const uint8_t *src;
+    uint8_t       *dst;
+    uint64_t       src_len, dst_cap;
+    int32_t        format;
+    uint32_t       image;
+    uint32_t       seg_first, seg_count;   // its segments in the PSeg table
+    uint64_t       seg_bytes;              // nominal segment length (multiple of 256)
+    // device side
+    uint64_t       tok_base, ntok;         // its tokens in the token buffer (of its pass)
+    uint64_t       end_bit;                // first bit after the final block
+    int32_t        ok;                     // the segment chain holds from the first bit to a final block
+    uint32_t       pass;
+};
+enum { PSEG_FAIL = 0, PSEG_CONT = 1, PSEG_FINAL = 2 };
+// One segment: the blocks that start in [index * seg_bytes, (index + 1) * seg_bytes).
+struct PSeg {
+    uint32_t stream, index;
+    uint64_t log_off, log_cap;             // its chunk records in the log slab (bytes)
+    // device side
+    uint64_t start_bit;                    // find: first block header at or after the nominal start (~0: none)
+    uint64_t end_bit;                      // count: where decoding stopped (start of the next block)
+    uint64_t ntok;                         // count
+    uint64_t tok_base;                     // scan: first token, relative to the stream's
+    int32_t  status;                       // count: PSEG_*
+    uint32_t used;                         // scan: part of the chain
 };
 
 struct DeflateJob {
@@ -81,6 +112,9 @@ hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32
                           const spng_result *d_results, uint32_t blocks_x, hipStream_t stream);
 hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results,
                           hipStream_t stream);
+hipError_t launch_pinflate(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t nsegs, uint8_t *d_logs,
+                           uint32_t *d_tokens, uint64_t tok_cap, uint32_t passes, spng_result *d_results,
+                           int32_t *d_done, hipStream_t stream);
 hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 hipError_t launch_filter(const FilterJob *d_jobs, uint32_t count, uint32_t max_rows, hipStream_t stream);
 hipError_t launch_adler_partial(const uint8_t *d, uint64_t n, uint32_t chunk, uint64_t *d_out, uint32_t blocks,
