@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- the north-star measurement: batched PNG decode (inflate + unfilter) of 4K RGBA8 images.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--mode decode|encode] [--scaling strong|weak]
+    (N > 1: one rank per GPU over RCCL; started by torch.distributed.run, or by this script itself when
+     it is run plainly with --gpus N)
 
-A "step" is one pass of the decode hot path (spng_decode_batch: inflate -> unfilter, results left
-in HBM) over the whole batch.  Workload = BASELINE.json configs[1]: 1024 synthetic 4096x4096 RGBA8
-PNG streams, mixed filters chosen by the reference's own heuristic, DEFLATE level 6.  At N > 1 the
-images are independent units and every GPU decodes its own 1024 (weak scaling: the global batch is
-1024 x N, no communication while decoding); the one exchange step of the path, gathering decoded
-rasters to rank 0 over RCCL, moves each rank's 1024/N-image shard, i.e. the 1024-image result of
-configs[2].  `--scaling strong` runs the fixed 1024-image batch sharded 1024/N per GPU instead (a
-stream is a serial chain that takes ~1.5 s however idle the GPU is, so that variant cannot speed
-up by more than the occupancy effect).  Compressed inputs are resident in HBM before the timed
-region; nothing is copied to the host inside it.  The CPU oracle is used only for the
-`cpu_baseline` leg.
+decode (default).  A "step" is one pass of the decode hot path (spng_decode_batch: inflate -> unfilter,
+results left in HBM) over the whole batch.  Workload = BASELINE.json configs[1]: 1024 synthetic
+4096x4096 RGBA8 PNG streams, mixed filters chosen by the reference's own heuristic, DEFLATE level 6.
+The headline line is measured on zlib-made level-6 streams; the same batch re-encoded by the device
+deflater (swift-png's own level-6 bitstream: a dynamic block every <= 2047 tokens) is measured in the
+same run and reported under "swiftpng_streams".  At N > 1 the default is configs[2]: the SAME 1024
+images sharded 1024/N per GPU ("strong"), every rank decoding its shard in groups whose rasters travel
+to rank 0 over RCCL (grouped point-to-point, xGMI) while the next group decodes; `--scaling weak`
+gives every GPU its own 1024 images instead.  Compressed inputs are resident in HBM before the timed
+region; nothing is copied to the host inside it.
+
+encode (`--mode encode`).  BASELINE configs[3]: random 4096x4096 RGBA8 rasters -> filter-select ->
+DEFLATE level 9 (spng_encode_batch); a step encodes the whole batch.
+
+The CPU oracle is used only for the `cpu_baseline` leg (rank 0, N = 1, bounded sample).
 """
 from __future__ import annotations
 
@@ -22,6 +27,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 import zlib
@@ -35,13 +41,13 @@ W = H = 4096
 DEPTH, CHANNELS = 8, 4
 MPIX = W * H / 1e6
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+STAGES = ("pinf_find", "pinf_count", "pinf_emit", "pinf_resolve", "inflate", "unfilter")
 
 
-def build_inputs(spng, session, unique: int, threads: int, encoder: str):
-    """-> (list of original rasters as numpy, list of zlib streams).  Product path only: synthetic
-    rasters -> GPU filter-select (spng_filter, the reference heuristic) -> level-6 DEFLATE, either
-    zlib on the host cores (default, seconds) or the device deflater (swift-png's own level-6
-    bitstream: a dynamic block every <= 2047 tokens; about a minute)."""
+def build_inputs(session, unique: int, threads: int, encoder: str):
+    """-> (rasters, filtered rows, streams).  Product path only: synthetic rasters -> GPU filter-select
+    (spng_filter, the reference heuristic) -> level-6 DEFLATE, by zlib on the host cores or by the
+    device deflater (swift-png's own bitstream)."""
     from swift_png_amd import synth
     with ThreadPoolExecutor(threads) as pool:
         images = list(pool.map(lambda s: synth.image(s, W, H, CHANNELS, DEPTH), range(unique)))
@@ -52,54 +58,245 @@ def build_inputs(spng, session, unique: int, threads: int, encoder: str):
             streams = [bytes(o[:r.written].cpu().numpy()) for o, r in zip(outs, res)]
         else:
             streams = list(pool.map(lambda r: zlib.compress(r, 6), rows))
-    for r, z in zip(rows, streams):
-        assert zlib.decompress(z) == r
+        ok = list(pool.map(lambda rz: zlib.decompress(rz[1]) == rz[0], zip(rows, streams)))
+    assert all(ok)
     return images, rows, streams
 
 
-def cpu_baseline(streams, images, cores: int, sample: int):
-    """Times the CPU oracle (restatement of swift-png's CPU path: inflate + defilter + assign) on
-    `sample` images, one image per thread.  Test infrastructure used as a reported baseline only."""
+def cpu_baseline(streams, images, rows, cores: int):
+    """The CPU oracle (restatement of swift-png's CPU path: inflate + defilter + assign) on a bounded
+    sample of the same streams: all host cores (one image per thread), one core, and -- as a sanity anchor
+    -- zlib's inflate followed by the oracle's defilter on one core (the reference publishes
+    swift-png = 1.35 x libpng decode time).  Test infrastructure used as a reported baseline only."""
     sys.path.insert(0, str(ROOT / "tests"))
     import numpy as np
     import pnghelp as ph
     lib = ph.oracle()
-    work = [(streams[i % len(streams)], i % len(streams)) for i in range(sample)]
 
-    def one(job):
-        z, k = job
+    def one(k):
+        z = streams[k % len(streams)]
         src = np.frombuffer(z, dtype=np.uint8)
         storage = np.empty(W * H * 4, dtype=np.uint8)
         aux = (ctypes.c_uint64 * 2)()
         st = lib.orc_decode(ph._ptr(src), len(z), 0, W, H, DEPTH, CHANNELS, 0, ph._ptr(storage), aux)
-        return st == 0 and bytes(storage[:4096]) == images[k].reshape(-1)[:4096].tobytes()
+        return st == 0 and bytes(storage[:4096]) == images[k % len(streams)].reshape(-1)[:4096].tobytes()
 
+    sample = max(16, cores)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as pool:
-        ok = list(pool.map(one, work))
+        ok = list(pool.map(one, range(sample)))
     dt = time.perf_counter() - t0
     assert all(ok)
+    t0 = time.perf_counter()
+    assert one(0)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    raw = zlib.decompress(streams[0])
+    st, storage = ph.orc_unfilter(raw, W, H, DEPTH, CHANNELS, False)
+    dtz = time.perf_counter() - t0
+    assert st == 0 and raw == rows[0]
     return {"value": round(sample * MPIX / dt, 1), "unit": "MPixels/s", "cores": cores, "kind": "port",
-            "sample": f"{sample} of the same 4096x4096 RGBA8 level-6 streams, one image per thread, "
-                      f"oracle inflate+defilter+assign, {dt:.1f} s wall"}
+            "sample": f"{sample} of the same 4096x4096 RGBA8 level-6 streams, one image per thread, oracle "
+                      f"inflate+defilter+assign, {dt:.1f} s wall",
+            "one_core": {"value": round(MPIX / dt1, 2), "unit": "MPixels/s", "cores": 1,
+                         "sample": f"1 image, {dt1:.1f} s"},
+            "zlib_anchor": {"value": round(MPIX / dtz, 2), "unit": "MPixels/s", "cores": 1,
+                            "sample": f"zlib 1.2.11 inflate + oracle defilter of 1 image, {dtz:.1f} s"}}
+
+
+def pmc_traffic(kind: str, images: int, unique: int):
+    """HBM bytes per launch of each kernel from the committed rocprofv3 PMC passes of this very workload
+    (profiles/r02_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes); None when the file does not describe this configuration."""
+    try:
+        pmc = json.loads((ROOT / "profiles" / "r02_pmc_traffic.json").read_text())
+        cfg = pmc["configs"][kind]
+        if cfg["images"] != images or cfg["unique"] != unique:
+            return {}
+        return {k: v["hbm_bytes_per_launch"] for k, v in cfg["kernels"].items()}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU ourselves."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class DecodeJob:
+    """One rank's share of a decode workload: descriptors over two slabs (scanline scratch, rasters)."""
+
+    def __init__(self, spng, s, torch, d_streams, n, first, unique, groups):
+        self.spng, self.s, self.n = spng, s, n
+        self.U = spng.inflated_size(W, H, DEPTH, CHANNELS, False)
+        self.S = spng.storage_size(W, H, DEPTH, CHANNELS)
+        self.rows_cap = (self.U + 4096 + 255) & ~255
+        self.d_rows = torch.empty(n * self.rows_cap, dtype=torch.uint8, device=s.tdev)
+        self.d_out = torch.empty(n * self.S, dtype=torch.uint8, device=s.tdev)
+        self.descs = (spng.ImageDesc * n)()
+        self.src = []
+        for j in range(n):
+            z = d_streams[(first + j) % unique]
+            self.src.append((first + j) % unique)
+            self.descs[j] = spng.ImageDesc(z.data_ptr(), z.numel(), self.d_rows.data_ptr() + j * self.rows_cap,
+                                           self.rows_cap, self.d_out.data_ptr() + j * self.S, W, H, DEPTH, CHANNELS,
+                                           0, 0, 0)
+        from swift_png_amd.distributed import group_bounds
+        self.groups = [group_bounds(n, groups, g) for g in range(groups)]    # (the same count on every rank)
+        self.dres = s.empty(n * ctypes.sizeof(spng.Result))
+
+    def decode_group(self, g):
+        lo, hi = self.groups[g]
+        if hi <= lo:
+            return
+        arr = (self.spng.ImageDesc * (hi - lo)).from_address(ctypes.addressof(self.descs) + lo * ctypes.sizeof(self.spng.ImageDesc))
+        rp = ctypes.c_void_p(self.dres.data_ptr() + lo * ctypes.sizeof(self.spng.Result))
+        st = self.s.lib.spng_decode_batch(self.s.ctx, arr, hi - lo, rp, None)
+        assert st == 0, st
+
+    def results(self):
+        raw = bytes(self.dres.cpu().numpy())
+        return list((self.spng.Result * self.n).from_buffer_copy(raw))
+
+
+def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gather):
+    """Builds the inputs of `kind` ("zlib" / "swiftpng"), times args.steps steps, checks every slot.
+    -> dict of measurements (rank 0 gets the max-over-ranks time)."""
+    from swift_png_amd.distributed import exchange_plan, shard
+    cores = os.cpu_count() or 1
+    images, rows, streams = build_inputs(s, unique, min(cores, 32), kind)
+    d_streams = [s.to_device(z) for z in streams]
+    C = [len(z) for z in streams]
+    weak = args.scaling == "weak" or world == 1
+    lo, hi = shard(args.images, world, rank)                 # this rank's share of a 1024-image result
+    n = args.images if weak else hi - lo
+    first = rank * args.images if weak else lo
+    do_gather = with_gather and world > 1 and not args.no_gather
+    groups = max(1, min(args.groups, -(-args.images // world))) if do_gather else 1
+    job = DecodeJob(spng, s, torch, d_streams, n, first, unique, groups)
+    S = job.S
+    gathered = None
+    if do_gather and rank == 0:
+        gathered = torch.empty(args.images * S, dtype=torch.uint8, device=s.tdev)
+
+    def step():
+        for g in range(len(job.groups)):
+            job.decode_group(g)
+            if do_gather:
+                # the only exchange step of the path: this group's rasters -> rank 0 over xGMI, as one batch of
+                # point-to-point transfers that runs (on RCCL's stream) while the next group decodes
+                glo, ghi = job.groups[g]
+                # in the weak form a rank contributes the slots of its share of the 1024-image result
+                off = lo if weak else 0
+                ops = exchange_plan(dist, job.d_out, gathered, S, args.images, world, rank,
+                                    glo, ghi, len(job.groups), g, weak_offset=off)
+                if ops:
+                    for w in dist.batch_isend_irecv(ops):
+                        step.pending.append(w)
+        for w in step.pending:
+            w.wait()
+        step.pending.clear()
+    step.pending = []
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    gather_error = None
+    if do_gather:
+        try:
+            step()
+            fence()
+        except Exception as exc:                               # noqa: BLE001  (the one piece a 1-GPU box cannot exercise)
+            gather_error = repr(exc)[:200]
+            do_gather = False
+            step.pending.clear()
+    for _ in range(args.warmup):
+        step()
+    fence()
+    s.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = {k: s.profile_get(getattr(spng, "K_" + k.upper())) for k in STAGES}
+    s.profile(False)
+
+    # parity of the whole batch: every slot equals its source raster, every status is DONE
+    res = job.results()
+    U = job.U
+    assert all(r.status == 0 and r.written == U for r in res), [r.status for r in res if r.status][:8]
+    fast = sum(r.reserved == 1 for r in res)
+    ref = [s.to_device(img.reshape(-1)) for img in images]
+    for j in range(n):
+        assert torch.equal(job.d_out[j * S:(j + 1) * S], ref[job.src[j]]), f"slot {first + j} differs"
+    if gathered is not None and do_gather:
+        for g in range(0, args.images, max(1, args.images // 16)):
+            assert torch.equal(gathered[g * S:(g + 1) * S], ref[g % unique]), f"gathered image {g} differs"
+
+    t = torch.tensor([dt], dtype=torch.float64, device=s.tdev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    total_c = sum(C[k] for k in job.src)
+    per_step = {k: prof[k][0] / args.steps for k in STAGES}
+    alg = {"pinf_find": 0, "pinf_count": total_c, "pinf_emit": total_c, "pinf_resolve": n * U,
+           "inflate": 0 if fast == n else total_c + n * U, "unfilter": n * (U + S)}
+    return {"dt": dt, "n": n, "weak": weak, "per_step_ms": per_step, "alg": alg, "total_c": total_c, "U": U, "S": S,
+            "fast": fast, "gather": bool(do_gather), "gather_error": gather_error, "hi_lo": hi - lo,
+            "ratio": round(U * unique / sum(C), 3), "streams": streams, "images": images, "rows": rows}
+
+
+def kernel_report(m, traffic):
+    rep = {}
+    for k in STAGES:
+        ms = m["per_step_ms"][k]
+        if ms <= 0.02:
+            continue
+        e = {"ms_per_step": round(ms, 3), "algorithmic_bytes": m["alg"][k]}
+        if m["alg"][k]:
+            e["gbps"] = round(m["alg"][k] / (ms * 1e-3) / 1e9, 2)
+            e["frac_of_hbm_peak"] = round(e["gbps"] / HBM_PEAK_GBPS, 4)
+        if k in traffic:
+            e["traffic"] = traffic[k]
+        rep[k] = e
+    return rep
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=("decode", "encode"), default="decode")
     ap.add_argument("--images", type=int, default=1024, help="batch size (BASELINE: 1024)")
-    ap.add_argument("--unique", type=int, default=32, help="distinct images; slot i decodes image i mod unique")
+    ap.add_argument("--unique", type=int, default=32, help="distinct images; slot i holds image i mod unique")
     ap.add_argument("--streams", choices=("zlib", "swiftpng"), default="zlib",
-                    help="level-6 encoder for the input streams: host zlib, or the device deflater (swift-png bitstream)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: every GPU decodes --images images (weak), or --images in total (strong)")
+                    help="level-6 encoder of the headline's input streams: host zlib, or the device deflater "
+                         "(swift-png's own bitstream)")
+    ap.add_argument("--no-swiftpng", action="store_true", help="skip the second measurement on swift-png-made streams")
+    ap.add_argument("--swiftpng-unique", type=int, default=8)
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: --images in total, sharded (strong, BASELINE configs[2]); or --images per GPU (weak)")
+    ap.add_argument("--groups", type=int, default=4, help="N > 1: decode/gather pipeline depth per step")
+    ap.add_argument("--level", type=int, default=9, help="encode mode: DEFLATE level (BASELINE configs[3]: 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     args = ap.parse_args()
 
-    import numpy as np
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
+
     import torch
     import torch.distributed as dist
 
@@ -113,128 +310,64 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import swift_png_amd as spng
-    from swift_png_amd.distributed import gather_decoded, shard
     s = spng.load(local)
     cores = os.cpu_count() or 1
-    images, rows, streams = build_inputs(spng, s, args.unique, min(cores, 32), args.streams)
-    U = spng.inflated_size(W, H, DEPTH, CHANNELS, False)
-    S = spng.storage_size(W, H, DEPTH, CHANNELS)
-    C = [len(z) for z in streams]
 
-    lo, hi = shard(args.images, world, rank)                 # this rank's share of a 1024-image result
-    weak = args.scaling == "weak" or world == 1
-    n = args.images if weak else hi - lo                     # images this rank decodes per step
-    first = rank * args.images if weak else lo               # global index of its first image
-    d_streams = [s.to_device(z) for z in streams]
-    # one contiguous slab each for scanline scratch and decoded rasters
-    rows_cap = (U + 4096 + 255) & ~255
-    d_rows = torch.empty(n * rows_cap, dtype=torch.uint8, device=s.tdev)
-    d_out = torch.empty(n * S, dtype=torch.uint8, device=s.tdev)
-    descs = (spng.ImageDesc * n)()
-    for j in range(n):
-        g = first + j
-        z = d_streams[g % args.unique]
-        descs[j] = spng.ImageDesc(z.data_ptr(), z.numel(), d_rows.data_ptr() + j * rows_cap, rows_cap,
-                                  d_out.data_ptr() + j * S, W, H, DEPTH, CHANNELS, 0, 0, 0)
-    gathered = None
-    do_gather = world > 1 and not args.no_gather
-    if do_gather and rank == 0:
-        per = -(-args.images // world)
-        gathered = [torch.empty(per * S, dtype=torch.uint8, device=s.tdev) for _ in range(world)]
-
-    def step():
-        s.decode_batch(descs, wait=False)
-        if do_gather:
-            # the only exchange step of the path: decoded rasters -> rank 0 over xGMI (RCCL)
-            gather_decoded(d_out[lo * S:hi * S] if weak else d_out, S, args.images, world, rank, out=gathered)
-
-    def fence():
-        torch.cuda.synchronize()
+    if args.mode == "encode":
+        from bench_encode import run_encode
+        out = run_encode(args, torch, dist, spng, s, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+            dist.destroy_process_group()
+        return
 
-    # The gather is the one piece that cannot be exercised on the single-GPU development box: if RCCL
-    # refuses it on this node, keep measuring the (communication-free) sharded decode and say so.
-    gather_error = None
-    if do_gather:
-        try:
-            step()
-            fence()
-        except Exception as exc:                               # noqa: BLE001
-            gather_error = repr(exc)[:200]
-            do_gather = False
-    for _ in range(args.warmup):
-        step()
-    fence()
-    s.profile(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = {k: s.profile_get(getattr(spng, "K_" + k.upper())) for k in ("inflate", "unfilter")}
-    s.profile(False)
-
-    # parity of the whole batch: every slot equals its source raster, every status is DONE
-    res = s.fetch_results(n)
-    assert all(r.status == 0 and r.written == U for r in res), [r.status for r in res if r.status][:8]
-    ref = [s.to_device(img.reshape(-1)) for img in images]
-    for j in range(n):
-        assert torch.equal(d_out[j * S:(j + 1) * S], ref[(first + j) % args.unique]), f"slot {first + j} differs"
-
-    t = torch.tensor([dt], dtype=torch.float64, device=s.tdev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    m = run_decode(args, torch, dist, spng, s, rank, world, args.streams, args.unique, True)
+    other = None
+    if world == 1 and not args.no_swiftpng:
+        alt = "swiftpng" if args.streams == "zlib" else "zlib"
+        other = (alt, run_decode(args, torch, dist, spng, s, rank, world, alt, args.swiftpng_unique, False))
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        total_c = sum(C[(first + j) % args.unique] for j in range(n))
-        infl_ms = prof["inflate"][0] / max(1, prof["inflate"][1])
-        unf_ms = prof["unfilter"][0] / max(1, prof["unfilter"][1])
-        infl_bytes = total_c + n * U                 # algorithmic: read C, write U
-        unf_bytes = n * (U + S)                      # algorithmic: read U, write S
-        # HBM traffic per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
-        # MI355X_MICROARCH.md prescribes; profiles/r01_pmc_traffic.json), scaled to this batch; null if absent
-        traffic = {"inflate": None, "unfilter": None}
-        try:
-            pmc = json.loads((ROOT / "profiles" / "r01_pmc_traffic.json").read_text())
-            for k in traffic:
-                traffic[k] = pmc["kernels"][k]["hbm_bytes_per_image"] * n
-        except (OSError, KeyError, ValueError):
-            pass
-        dominant = "inflate" if infl_ms >= unf_ms else "unfilter"
-        dom_bytes, dom_ms = (infl_bytes, infl_ms) if dominant == "inflate" else (unf_bytes, unf_ms)
+        weak, n = m["weak"], m["n"]
+        ms = m["dt"] / args.steps * 1e3
+        kernels = kernel_report(m, pmc_traffic(args.streams, args.images, args.unique) if world == 1 else {})
+        dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+        d = kernels[dominant]
+        infl_ms = sum(m["per_step_ms"][k] for k in ("pinf_find", "pinf_count", "pinf_emit", "pinf_resolve", "inflate"))
         out = {
             "metric": "decoded_mpixels_per_s",
-            "value": round(args.images * (world if weak else 1) * MPIX / (dt / args.steps), 1),
+            "value": round(args.images * (world if weak else 1) * MPIX / (m["dt"] / args.steps), 1),
             "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.images} x 4096x4096 RGBA8 PNG decode (inflate+unfilter), mixed "
-                                   f"filters (reference heuristic), level 6 ({args.streams} encoder); BASELINE configs[1]"
+            "config": {"workload": f"{args.images} x 4096x4096 RGBA8 PNG decode (inflate+unfilter), mixed filters "
+                                   f"(reference heuristic), level 6 ({args.streams} encoder); BASELINE configs[1]"
                                    + ("" if world == 1 else
-                                      f" per GPU (global batch {args.images * world}); each rank's {hi - lo}-image shard "
-                                      f"gathered to rank 0 over RCCL (configs[2])" if weak else
-                                      f" sharded {n}/GPU, RCCL gather to rank 0 (configs[2])"),
-                       "unique_images": args.unique, "compressed_ratio": round(U * args.unique / sum(C), 3),
-                       "gather": bool(do_gather), **({"gather_error": gather_error} if gather_error else {})},
-            "inflate_gbps": round(n * U / (infl_ms * 1e-3) / 1e9, 2),
-            "roofline": {"bound": "hbm", "kernel": f"{dominant}_kernel",
-                         "achieved": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(dom_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                         "traffic": traffic[dominant], "ms_per_launch": round(dom_ms, 3)},
-            "kernels": {
-                "inflate": {"ms_per_launch": round(infl_ms, 3), "algorithmic_bytes": infl_bytes,
-                            "gbps": round(infl_bytes / (infl_ms * 1e-3) / 1e9, 2)},
-                "unfilter": {"ms_per_launch": round(unf_ms, 3), "algorithmic_bytes": unf_bytes,
-                             "gbps": round(unf_bytes / (unf_ms * 1e-3) / 1e9, 2),
-                             "frac_of_hbm_peak": round(unf_bytes / (unf_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                             "traffic": traffic["unfilter"]},
-            },
+                                      f" per GPU (global batch {args.images * world}); each rank's {m['hi_lo']}-image share "
+                                      f"gathered to rank 0 over RCCL" if weak else
+                                      f" sharded {n}/GPU, rasters gathered to rank 0 over RCCL while decoding (configs[2])"),
+                       "unique_images": args.unique, "compressed_ratio": m["ratio"],
+                       "parallel_inflate_streams": m["fast"], "serial_inflate_streams": n - m["fast"],
+                       "gather": m["gather"], **({"gather_error": m["gather_error"]} if m["gather_error"] else {})},
+            "inflate_gbps": round(n * m["U"] / (infl_ms * 1e-3) / 1e9, 2),
+            "inflate_pipeline": {"ms_per_step": round(infl_ms, 3), "algorithmic_bytes": m["total_c"] + n * m["U"],
+                                 "gbps": round((m["total_c"] + n * m["U"]) / (infl_ms * 1e-3) / 1e9, 2)},
+            "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": d.get("gbps"),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d.get("frac_of_hbm_peak"),
+                         "traffic": d.get("traffic"), "ms_per_launch": d["ms_per_step"]},
+            "kernels": kernels,
         }
+        if other:
+            alt, mo = other
+            ko = kernel_report(mo, pmc_traffic(alt, args.images, args.swiftpng_unique))
+            io = sum(mo["per_step_ms"][k] for k in ("pinf_find", "pinf_count", "pinf_emit", "pinf_resolve", "inflate"))
+            out[alt + "_streams"] = {
+                "value": round(args.images * MPIX / (mo["dt"] / args.steps), 1), "unit": "MPixels/s",
+                "ms_per_step": round(mo["dt"] / args.steps * 1e3, 3), "unique_images": args.swiftpng_unique,
+                "compressed_ratio": mo["ratio"], "parallel_inflate_streams": mo["fast"],
+                "inflate_gbps": round(mo["n"] * mo["U"] / (io * 1e-3) / 1e9, 2), "kernels": ko}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(streams, images, cores, max(16, cores))
+            out["cpu_baseline"] = cpu_baseline(m["streams"], m["images"], m["rows"], cores)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

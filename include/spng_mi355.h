@@ -121,8 +121,9 @@ int32_t spng_configure(spng_ctx *ctx, int key, int64_t value);
 enum { SPNG_K_INFLATE = 0,          /* the serial inflate kernel (streams the parallel pipeline left to it) */
        SPNG_K_UNFILTER = 1, SPNG_K_SCATTER = 2, SPNG_K_FILTER = 3,
        SPNG_K_DEFLATE = 4, SPNG_K_ADLER = 5,
-       SPNG_K_PINFLATE = 6,         /* the parallel inflate pipeline: find + count + scan + emit + resolve */
-       SPNG_K_COUNT = 8 };
+       SPNG_K_PINFLATE = 6,         /* the parallel inflate pipeline as a whole: find + count + scan + emit + resolve */
+       SPNG_K_PINF_FIND = 8, SPNG_K_PINF_COUNT = 9, SPNG_K_PINF_EMIT = 10, SPNG_K_PINF_RESOLVE = 11,   /* its stages */
+       SPNG_K_COUNT = 16 };
 int32_t spng_profile(spng_ctx *ctx, int enable);                /* enable/disable + reset counters  */
 int32_t spng_profile_get(spng_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
 

@@ -526,10 +526,18 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
 {
     const uint32_t n = (uint32_t)p.jobs.size();
     if (p.parallel) {
-        Timed t(c, SPNG_K_PINFLATE);
-        HIP_TRY(launch_pinflate(a.dev<PStream>(p.streams_at), n, a.dev<PSeg>(p.segs_at), (uint32_t)p.segs.size(),
-                                (uint8_t *)c->d_log, (uint32_t *)c->d_tok, p.tok_cap, p.passes, dr,
-                                a.dev<int32_t>(p.done_at), c->stream));
+        Timed whole(c, SPNG_K_PINFLATE);
+        PStream *ds = a.dev<PStream>(p.streams_at);
+        PSeg *dg = a.dev<PSeg>(p.segs_at);
+        int32_t *dd = a.dev<int32_t>(p.done_at);
+        const uint32_t ng = (uint32_t)p.segs.size();
+        { Timed t(c, SPNG_K_PINF_FIND); HIP_TRY(launch_pinf_find(ds, n, dg, ng, dd, c->stream)); }
+        { Timed t(c, SPNG_K_PINF_COUNT); HIP_TRY(launch_pinf_count(ds, dg, ng, (uint8_t *)c->d_log, c->stream)); }
+        HIP_TRY(launch_pinf_scan(ds, n, dg, p.tok_cap, p.passes, c->stream));
+        for (uint32_t pass = 0; pass < p.passes; ++pass) {
+            { Timed t(c, SPNG_K_PINF_EMIT); HIP_TRY(launch_pinf_emit(ds, dg, ng, (uint8_t *)c->d_log, (uint32_t *)c->d_tok, pass, c->stream)); }
+            { Timed t(c, SPNG_K_PINF_RESOLVE); HIP_TRY(launch_pinf_resolve(ds, n, (uint32_t *)c->d_tok, dr, dd, pass, c->stream)); }
+        }
     }
     if (p.parallel && getenv("SPNG_TRACE_PINFLATE")) {
         // diagnostic: how far every stream got in the pipeline (synchronises; never on by default)

@@ -112,9 +112,13 @@ hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32
                           const spng_result *d_results, uint32_t blocks_x, hipStream_t stream);
 hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results,
                           hipStream_t stream);
-hipError_t launch_pinflate(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t nsegs, uint8_t *d_logs,
-                           uint32_t *d_tokens, uint64_t tok_cap, uint32_t passes, spng_result *d_results,
-                           int32_t *d_done, hipStream_t stream);
+hipError_t launch_pinf_find(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t nsegs, int32_t *d_done, hipStream_t stream);
+hipError_t launch_pinf_count(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint8_t *d_logs, hipStream_t stream);
+hipError_t launch_pinf_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint64_t tok_cap, uint32_t passes, hipStream_t stream);
+hipError_t launch_pinf_emit(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint8_t *d_logs, uint32_t *d_tokens, uint32_t pass,
+                            hipStream_t stream);
+hipError_t launch_pinf_resolve(PStream *d_streams, uint32_t nstreams, uint32_t *d_tokens, spng_result *d_results, int32_t *d_done,
+                               uint32_t pass, hipStream_t stream);
 hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 hipError_t launch_filter(const FilterJob *d_jobs, uint32_t count, uint32_t max_rows, hipStream_t stream);
 hipError_t launch_adler_partial(const uint8_t *d, uint64_t n, uint32_t chunk, uint64_t *d_out, uint32_t blocks,

@@ -154,7 +154,7 @@ __device__ __attribute__((always_inline)) bool build(uint32_t *hist, uint32_t *r
         if (before == 0) run[my] += (uint32_t)__popcll(same);      // one lane per length updates the tally
         if (my) {
             const uint32_t e = KIND == 0 ? litlen_entry(sym, my) : KIND == 1 ? dist_entry(sym, my) : meta_entry(sym, my);
-            sorted[o + rank] = (uint16_t)sym;
+            if (sorted) sorted[o + rank] = (uint16_t)sym;
             if (ext) ext[o + rank] = e;                       // (pinflate.hip: entries in canonical order)
             if ((int)my <= lbits) {
                 const uint32_t rev = __brev(f + rank) >> (32 - my);

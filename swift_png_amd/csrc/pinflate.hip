@@ -55,7 +55,10 @@ struct __attribute__((packed)) PU128 { u32x4 v; };
 typedef uint8_t __attribute__((address_space(1))) gbyte;
 typedef PU128 __attribute__((address_space(1))) gPU128;
 
-static constexpr int LBITS = 10, DBITS = 8, MBITS = 7;
+#ifndef SPNG_LBITS
+#define SPNG_LBITS 10
+#endif
+static constexpr int LBITS = SPNG_LBITS, DBITS = 8, MBITS = 7;
 #ifndef SPNG_SDW
 #define SPNG_SDW 9
 #endif
@@ -71,9 +74,7 @@ static constexpr uint32_t T_MATCH = 0x80000000u;    // token: T_MATCH | (distanc
 struct PLds {
     uint32_t lit[1 << LBITS];          // (the code-length-code LUT lives here while a header is parsed)
     uint32_t dist[1 << DBITS];
-    uint16_t sorted_lit[288];          // symbols in canonical order ...
-    uint16_t sorted_dist[32];
-    uint32_t ext_lit[288];             // ... and their LUT entries, for codes longer than the LUT index
+    uint32_t ext_lit[288];             // LUT entries in canonical code order, for codes longer than the LUT index
     uint32_t ext_dist[32];
     Tree     tlit, tdist;
     uint32_t hist[16], run[16];
@@ -85,7 +86,7 @@ struct PLds {
 
 // canonical codes longer than the LUT index: left-aligned (15-bit) upper limits of every length, kept
 // in scalar registers for the block
-struct Lim { uint32_t lit[5], dist[7]; };
+struct Lim { uint32_t lit[15 - LBITS], dist[15 - DBITS]; };
 
 // ---- staging ------------------------------------------------------------------------------------
 // copies `kib` x 1 KiB of the stream starting at byte `from` into dst; bytes past the end read as zero
@@ -157,6 +158,121 @@ struct Hdr {
     uint32_t stored;                   // stored blocks: LEN
 };
 
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total, int lane)
+{
+    uint32_t incl = row_scan(v);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+    const uint32_t r1 = r0 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+    const uint32_t r2 = r1 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 47);
+    incl += lane < 16 ? 0u : lane < 32 ? r0 : lane < 48 ? r1 : r2;
+    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    return incl - v;
+}
+
+// The run-length coded code lengths of a dynamic block header (readBlockTables,
+// InflatorBuffers.Stream.swift:144-263), decoded by the whole wave instead of symbol after symbol: the
+// same self-synchronisation scheme as the block data (see count_chunk), on 32-bit subsequences of a
+// 2048-bit window.  s.lit holds the code-length-code LUT.  On success s.lens[0 .. want) are the code
+// lengths and `rel` is the first bit behind them.  false: a sequence the reference rejects (repeat
+// without a previous length, a run past the declared count), or one that does not end inside the input.
+__device__ __forceinline__ uint32_t cl_symbol(const PLds &s, uint32_t q)
+{
+    uint32_t lo, hi;
+    fetch(s.stage, q, lo, hi);
+    const uint32_t e = s.lit[lo & ((1 << MBITS) - 1)];
+    const uint32_t len = e & 15, sym = e >> 16;
+    const uint32_t extra = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+    const uint32_t rep = sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + ((lo >> len) & ((1u << extra) - 1));
+    return (len + extra) | sym << 8 | rep << 16;              // bits (1 .. 14) | symbol | lengths it stands for
+}
+
+__device__ __attribute__((always_inline)) bool decode_lengths(PLds &s, uint32_t &rel, uint32_t rel_end, uint32_t want, int lane)
+{
+    uint32_t *vm = s.stage + 512, *pf = s.stage + 576, *mp = s.stage + 640;   // (the header occupies the first KiB)
+    for (int i = lane; i < 116; i += 64) ((uint32_t *)s.lens)[i] = 0;
+    uint32_t have = 0, w0 = rel;
+    uint32_t last_in = 0; bool last_ok = false;
+    for (int window = 0; window < 3; ++window) {
+        const uint32_t sub0 = w0 + 32u * lane, sub1 = sub0 + 32, wend = w0 + 2048;
+        uint32_t q = sub0, V = 0;
+        while (q < sub1) { V |= 1u << (q - sub0); q += cl_symbol(s, q) & 255; }
+        vm[lane] = V; pf[lane] = 0;
+        WSYNC();
+        uint32_t link = 64;
+        while (q < wend) {
+            const uint32_t j = (q - w0) >> 5;
+            if ((vm[j] >> ((q - w0) & 31)) & 1) { link = j; break; }
+            q += cl_symbol(s, q) & 255;
+        }
+        bool onpath = lane == 0;
+        uint32_t jump = link;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (onpath && jump < 64) pf[jump] = 1;
+            WSYNC();
+            onpath = onpath || pf[lane] != 0;
+            const uint32_t jj = (uint32_t)__shfl((int)jump, (int)(jump & 63), 64);
+            jump = jump < 64 ? jj : 64;
+        }
+        if (onpath && link < 64) mp[link] = q;
+        WSYNC();
+        const uint32_t m = lane == 0 ? w0 : mp[lane];
+        // how many lengths my symbols stand for, and what "the previous length" is behind them
+        uint32_t cnt = 0, lastv = 0; bool def = false;
+        if (onpath) {
+            for (uint32_t p = m; p < q;) {
+                const uint32_t t = cl_symbol(s, p), sym = (t >> 8) & 255;
+                cnt += t >> 16;
+                if (sym != 16) { def = true; lastv = sym < 16 ? sym : 0u; }
+                p += t & 255;
+            }
+        }
+        uint32_t tot;
+        const uint32_t base = have + wave_excl_scan(cnt, tot, lane);
+        const unsigned long long dm = __ballot(onpath && def);
+        const unsigned long long below = dm & ((1ull << lane) - 1);
+        const int pl = below ? 63 - __clzll((long long)below) : 0;
+        const uint32_t pv = (uint32_t)__shfl((int)lastv, pl, 64);
+        uint32_t lastcur = below ? pv : last_in;
+        bool lastcur_ok = below ? true : last_ok;
+        // write them
+        bool bad = false;
+        uint32_t endpos = 0xffffffffu;
+        if (onpath && base < want) {
+            uint32_t idx = base;
+            for (uint32_t p = m; p < q && idx < want;) {
+                const uint32_t t = cl_symbol(s, p), sym = (t >> 8) & 255, rep = t >> 16;
+                if (idx + rep > want) { bad = true; break; }
+                if (sym < 16) { s.lens[idx] = (uint8_t)sym; lastcur = sym; lastcur_ok = true; }
+                else if (sym == 16) {
+                    if (!lastcur_ok) { bad = true; break; }
+                    for (uint32_t r = 0; r < rep; ++r) s.lens[idx + r] = (uint8_t)lastcur;
+                } else { lastcur = 0; lastcur_ok = true; }
+                idx += rep;
+                p += t & 255;
+                if (idx == want) endpos = p;
+            }
+        }
+        if (__ballot(bad)) return false;
+        if (have + tot >= want) {
+            const unsigned long long em = __ballot(endpos != 0xffffffffu);
+            if (!em) return false;
+            rel = (uint32_t)__shfl((int)endpos, __ffsll((long long)em) - 1, 64);
+            WSYNC();
+            return rel <= rel_end;
+        }
+        // the sequence goes on behind this window
+        have += tot;
+        if (dm) { const int ll = 63 - __clzll((long long)dm); last_in = (uint32_t)__shfl((int)lastv, ll, 64); last_ok = true; }
+        const unsigned long long endm = __ballot(onpath && link == 64);
+        if (!endm) return false;
+        w0 = (uint32_t)__shfl((int)q, __ffsll((long long)endm) - 1, 64);
+        if (w0 >= rel_end) return false;
+        WSYNC();
+    }
+    return false;
+}
+
 // Parses the block header at absolute bit `pos` with the reference's rules (readBlockMetadata /
 // readBlockTables, InflatorBuffers.Stream.swift:59-263) and, for Huffman blocks, builds the decode
 // tables.  false = anything the reference would not accept as is (errors, truncation): the caller
@@ -165,7 +281,7 @@ __device__ __forceinline__ void load_limits(const PLds &s, Lim &lc)
 {
     // lengths no symbol has: limit = that of the next shorter length (count 0), so the compare chain skips them
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { const int l = LBITS + 1 + k; lc.lit[k] = UNI((uint32_t)(s.tlit.first[l] + s.tlit.count[l]) << (15 - l)); }
+    for (int k = 0; k < 15 - LBITS; ++k) { const int l = LBITS + 1 + k; lc.lit[k] = UNI((uint32_t)(s.tlit.first[l] + s.tlit.count[l]) << (15 - l)); }
 #pragma unroll
     for (int k = 0; k < 7; ++k) { const int l = DBITS + 1 + k; lc.dist[k] = UNI((uint32_t)(s.tdist.first[l] + s.tdist.count[l]) << (15 - l)); }
 }
@@ -195,10 +311,10 @@ __device__ __attribute__((always_inline)) bool parse_header(PLds &s, const gbyte
     if (h.type == 1) {
         for (int i = lane; i < 288; i += 64) s.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
         WSYNC();
-        build<0>(s.hist, s.run, s.lens, 288, s.lit, LBITS, s.sorted_lit, &s.tlit, false, lane, s.ext_lit);
+        build<0>(s.hist, s.run, s.lens, 288, s.lit, LBITS, (uint16_t *)nullptr, &s.tlit, false, lane, s.ext_lit);
         for (int i = lane; i < 32; i += 64) s.lens[i] = 5;
         WSYNC();
-        build<1>(s.hist, s.run, s.lens, 32, s.dist, DBITS, s.sorted_dist, &s.tdist, false, lane, s.ext_dist);
+        build<1>(s.hist, s.run, s.lens, 32, s.dist, DBITS, (uint16_t *)nullptr, &s.tdist, false, lane, s.ext_dist);
         h.payload = pos + 3;
         return true;
     }
@@ -216,43 +332,13 @@ __device__ __attribute__((always_inline)) bool parse_header(PLds &s, const gbyte
         s.lens[order[lane]] = (uint32_t)lane < codelengths ? (uint8_t)((packed >> (3 * lane)) & 7) : 0;
     }
     WSYNC();
-    if (!UB(build<2>(s.hist, s.run, s.lens, 19, s.lit, MBITS, s.sorted_lit, &s.tlit, false, lane))) return false;
+    if (!UB(build<2>(s.hist, s.run, s.lens, 19, s.lit, MBITS, (uint16_t *)nullptr, &s.tlit, false, lane))) return false;
     // the code lengths, run-length coded (:144-263); at most 4498 bits: inside the staged KiB
     const uint32_t rel_end = (uint32_t)((total - wbyte * 8) > 0xffffffffull ? 0xffffffffu : (total - wbyte * 8));
     const uint32_t want = literals + distances;
-    uint32_t have = 0, last = 0;
-    while (have < want) {
-        if (rel >= rel_end) return false;
-        const uint32_t bits = upeek32(s.stage, rel);
-        const uint32_t e = UNI(s.lit[bits & ((1 << MBITS) - 1)]);
-        const uint32_t len = e & 15, sym = e >> 16;
-        if (rel + len > rel_end) return false;
-        if (sym < 16) {
-            rel += len;
-            s.lens[have] = (uint8_t)sym;
-            last = sym; have += 1;
-            continue;
-        }
-        uint32_t element, extra, base;
-        if (sym == 16) {
-            if (!have) return false;
-            element = last; extra = 2; base = 3;
-        } else if (sym == 17) { element = 0; extra = 3; base = 3; }
-        else                  { element = 0; extra = 7; base = 11; }
-        if (rel + len + extra > rel_end) return false;
-        const uint32_t reps = base + ((bits >> len) & ((1u << extra) - 1));
-        rel += len + extra;
-#pragma unroll
-        for (uint32_t j = 0; j < 3; ++j) {
-            const uint32_t at = have + lane + 64 * j;
-            s.lens[at < sizeof(s.lens) - 1 ? at : sizeof(s.lens) - 1] = (uint8_t)element;
-        }
-        last = element; have += reps;
-    }
-    WSYNC();
-    if (have != want) return false;
-    const bool okd = UB(build<1>(s.hist, s.run, s.lens + literals, (int)distances, s.dist, DBITS, s.sorted_dist, &s.tdist, true, lane, s.ext_dist));
-    const bool okl = UB(build<0>(s.hist, s.run, s.lens, (int)literals, s.lit, LBITS, s.sorted_lit, &s.tlit, false, lane, s.ext_lit));
+    if (!UB(decode_lengths(s, rel, rel_end, want, lane))) return false;
+    const bool okd = UB(build<1>(s.hist, s.run, s.lens + literals, (int)distances, s.dist, DBITS, (uint16_t *)nullptr, &s.tdist, true, lane, s.ext_dist));
+    const bool okl = UB(build<0>(s.hist, s.run, s.lens, (int)literals, s.lit, LBITS, (uint16_t *)nullptr, &s.tlit, false, lane, s.ext_lit));
     if (!okl || !okd) return false;
     h.payload = wbyte * 8 + rel;
     return true;
@@ -269,8 +355,10 @@ __device__ __forceinline__ uint32_t long_code(uint32_t bits, const Lim &lim, con
     const uint32_t v = __brev(bits) >> 17;                     // next 15 bits, MSB first
     uint32_t l;
     if (KIND == 0) {
-        l = LBITS + 1 + (v >= lim.lit[0]) + (v >= lim.lit[1]) + (v >= lim.lit[2]) + (v >= lim.lit[3]);
-        if (v >= lim.lit[4]) return entry(15, 0, K_UNDEF, 0);
+        l = LBITS + 1;
+#pragma unroll
+        for (int k = 0; k < 14 - LBITS; ++k) l += v >= lim.lit[k];
+        if (v >= lim.lit[14 - LBITS]) return entry(15, 0, K_UNDEF, 0);
     } else {
         l = DBITS + 1 + (v >= lim.dist[0]) + (v >= lim.dist[1]) + (v >= lim.dist[2]) + (v >= lim.dist[3]) +
             (v >= lim.dist[4]) + (v >= lim.dist[5]);
@@ -380,16 +468,6 @@ __global__ __launch_bounds__(64) void pinf_find_kernel(const PStream *__restrict
 }
 
 // ---- count (pass 1) and emit (pass 2) ----------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total, int lane)
-{
-    uint32_t incl = row_scan(v);
-    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
-    const uint32_t r1 = r0 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
-    const uint32_t r2 = r1 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 47);
-    incl += lane < 16 ? 0u : lane < 32 ? r0 : lane < 48 ? r1 : r2;
-    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    return incl - v;
-}
 
 // One chunk of a Huffman block in the counting pass.  `cb` = absolute first bit of the chunk, `entry`
 // = absolute bit at which the first token of the chunk starts (>= cb).  Writes the chunk record and
@@ -406,9 +484,21 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total, 
 //             link, then that lane's chain up to its link, ...: the lanes reachable from lane 0
 //             (pointer doubling over the links).  A lane on the path owns the tokens from the position
 //             at which the path entered its chain up to its own link.
+#ifdef SPNG_COUNT_PROF
+#define CP_ARG , uint64_t *cp
+#define CP_PASS , cp
+#define CP(k) do { const uint64_t now_ = __builtin_readcyclecounter(); cp[k] += now_ - cp[15]; cp[15] = now_; } while (0)
+#define CPN(k, v) (cp[k] += (v))
+#else
+#define CP_ARG
+#define CP_PASS
+#define CP(k)
+#define CPN(k, v)
+#endif
 __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, StageRegs &sr, const gbyte *src, uint64_t n, uint64_t cb,
-                                                uint64_t entry, uint32_t *rec, uint64_t &next, uint32_t &ntok, int lane)
+                                                uint64_t entry, uint32_t *rec, uint64_t &next, uint32_t &ntok, int lane CP_ARG)
 {
+    CP(0);
     const uint64_t sbyte = (cb >> 5) << 2;
     stage_put(s.stage, sr, STAGE_DW / 256, lane);               // (fetched while the chunk before was decoded)
     stage_fetch(sr, src, n, ((cb + CHB) >> 5) << 2, STAGE_DW / 256, lane);
@@ -424,7 +514,9 @@ __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, S
     uint32_t dummy;
     const uint32_t q0 = lane == 0 ? (uint32_t)(entry - sbit) : sub0;
     uint32_t q = q0, st = 0;                                    // st: 0 running, 1 end of block, 2 not a token
+    CP(1);
     while (q < sub1) {
+        CPN(8, 1);
         const uint32_t t = decode_at<false>(s, lim_codes, q, lim, dummy);
         const uint32_t k = t >> 8;
         if (k) { st = k == D_EOB ? 1u : 2u; if (k == D_EOB) q += t & 255; break; }
@@ -433,9 +525,11 @@ __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, S
         q += t & 255;
     }
     WSYNC();
+    CP(2);
     uint32_t link = 64, cnt2 = 0;
     if (st == 0) {
         while (q < cend) {
+            CPN(9, 1);
             const uint32_t j = (q - off0) / SB, b = q - off0 - j * SB;
             if ((s.vmap[(b >> 5) * 64 + j] >> (b & 31)) & 1) { link = j; break; }
             const uint32_t t = decode_at<false>(s, lim_codes, q, lim, dummy);
@@ -446,6 +540,7 @@ __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, S
         }
     }
     // q: where my chain merged / left the chunk / stopped
+    CP(3);
     bool onpath = lane == 0;
     uint32_t jump = link;
 #pragma unroll
@@ -481,6 +576,9 @@ __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, S
     ntok = tot;
     rec[4 + lane] = (onpath ? m : 0u) | mine << 16;
     if (lane == 0) { rec[0] = tot; rec[1] = ste == 1 ? 1u : 0u; rec[2] = (uint32_t)next; rec[3] = (uint32_t)(next >> 32); }
+    CP(4);
+    CPN(10, 1);
+    CPN(11, tot);
     return ste;
 }
 
@@ -506,10 +604,18 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
     uint32_t cur = 0;
     uint64_t pos = start, ntok = 0;
     int32_t status = PSEG_FAIL;
+#ifdef SPNG_COUNT_PROF
+    uint64_t cp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    cp[15] = __builtin_readcyclecounter();
+#endif
     for (;;) {
         if (pos >= limit) { if (pos == limit) status = PSEG_CONT; break; }
         Hdr h;
-        if (!UB(parse_header(s, src, n, pos, h, lane))) break;
+        CP(5);
+        const bool hok = UB(parse_header(s, src, n, pos, h, lane));
+        CP(6);
+        CPN(12, 1);
+        if (!hok) break;
         if (h.type == 0) {
             ntok += h.stored;
             pos = h.payload + (uint64_t)h.stored * 8;
@@ -523,7 +629,7 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
             for (;;) {
                 if (cur + REC_DW > log_cap) { state = 2; break; }
                 uint64_t next; uint32_t nt;
-                state = UNI(count_chunk(s, lc, sr, src, n, cb, entry, log + cur, next, nt, lane));
+                state = UNI(count_chunk(s, lc, sr, src, n, cb, entry, log + cur, next, nt, lane CP_PASS));
                 next = uni64(next);
                 cur += REC_DW;
                 ntok += UNI(nt);
@@ -536,6 +642,11 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
         if (h.bfinal) { status = PSEG_FINAL; break; }
     }
     if (lane == 0) { sg.end_bit = pos; sg.ntok = ntok; sg.status = status; }
+#ifdef SPNG_COUNT_PROF
+    if (blockIdx.x == 1 && lane == 0)
+        printf("count: %lu blocks %lu chunks %lu tokens; steps r0 %lu p2 %lu; cycles: stage %lu setup %lu round0 %lu phase2 %lu path+rec %lu header %lu other %lu\n",
+               cp[12], cp[10], cp[11], cp[8], cp[9], cp[0], cp[1], cp[2], cp[3], cp[4], cp[6], cp[5]);
+#endif
 }
 
 __global__ __launch_bounds__(64) void pinf_emit_kernel(const PStream *__restrict__ streams, const PSeg *__restrict__ segs,
@@ -828,8 +939,11 @@ __global__ __launch_bounds__(RT, 2) void pinf_resolve_kernel(const PStream *__re
             }
             off = end;
         }
-        const uint32_t ptot = block_sum(s, pack, tid);           // (barrier: marks and tokens are visible)
-        const uint32_t nused = ptot >> 16, tlen = ptot & 0xffff;
+        // (everything fits: the usual case with 2048 tokens of ~4 bytes; else count what was taken)
+        uint32_t nused = TOKS, tlen = total;
+        if (ti + TOKS > ntok) nused = (uint32_t)(ntok - ti);
+        if (total > TILE) { const uint32_t ptot = block_sum(s, pack, tid); nused = ptot >> 16; tlen = ptot & 0xffff; }
+        else __syncthreads();                                    // (barrier: marks and tokens are visible)
         if (pos + tlen > cap) { bad = true; break; }
         // the next tile's tokens travel while this one is resolved
 #pragma unroll
@@ -1024,20 +1138,34 @@ __global__ void pinf_clear_kernel(int32_t *done, uint32_t count)
 }
 
 // ---- host ------------------------------------------------------------------------------------------
-hipError_t launch_pinflate(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t nsegs, uint8_t *d_logs,
-                           uint32_t *d_tokens, uint64_t tok_cap, uint32_t passes, spng_result *d_results,
-                           int32_t *d_done, hipStream_t stream)
+// The pipeline stage by stage (api.hip times each launch separately): find -> count -> scan -> per pass {emit, resolve}.
+hipError_t launch_pinf_find(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t nsegs, int32_t *d_done, hipStream_t stream)
 {
-    if (!nstreams) return hipSuccess;
     pinf_clear_kernel<<<(nstreams + 255) / 256, 256, 0, stream>>>(d_done, nstreams);
     pinf_find_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs);
+    return hipGetLastError();
+}
+hipError_t launch_pinf_count(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint8_t *d_logs, hipStream_t stream)
+{
     pinf_count_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_logs);
+    return hipGetLastError();
+}
+hipError_t launch_pinf_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint64_t tok_cap, uint32_t passes, hipStream_t stream)
+{
     pinf_scan_kernel<<<nstreams, 64, 0, stream>>>(d_streams, d_segs);
     pinf_assign_kernel<<<1, 64, 0, stream>>>(d_streams, nstreams, tok_cap, passes);
-    for (uint32_t p = 0; p < passes; ++p) {
-        pinf_emit_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_logs, d_tokens, p);
-        pinf_resolve_kernel<<<nstreams, RT, 0, stream>>>(d_streams, d_tokens, d_results, d_done, p);
-    }
+    return hipGetLastError();
+}
+hipError_t launch_pinf_emit(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint8_t *d_logs, uint32_t *d_tokens, uint32_t pass,
+                            hipStream_t stream)
+{
+    pinf_emit_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_logs, d_tokens, pass);
+    return hipGetLastError();
+}
+hipError_t launch_pinf_resolve(PStream *d_streams, uint32_t nstreams, uint32_t *d_tokens, spng_result *d_results, int32_t *d_done,
+                               uint32_t pass, hipStream_t stream)
+{
+    pinf_resolve_kernel<<<nstreams, RT, 0, stream>>>(d_streams, d_tokens, d_results, d_done, pass);
     return hipGetLastError();
 }
 
