@@ -73,7 +73,8 @@ typedef struct spng_result {
 typedef struct spng_stream_desc {
     const void *d_src;  uint64_t src_len;     /* whole stream = concatenated IDAT payloads */
     void       *d_dst;  uint64_t dst_cap;     /* inflated bytes */
-    int32_t     format; int32_t  reserved;
+    int32_t     format;
+    int32_t     reserved;                     /* deflate: window exponent 8 ... 15 (LZ77.Deflator(exponent:)); 0 = 15 */
 } spng_stream_desc;
 
 /* One image.  d_rows is the inflated scanline stream (filter byte + pitch bytes per row, pass
@@ -168,17 +169,21 @@ int32_t spng_filter(spng_ctx *ctx, const void *storage,
                     uint32_t w, uint32_t h, int depth, int channels, int interlaced,
                     void *rows, spng_result *result);
 
-/* replaces LZ77.Deflator(format:level:exponent: 15, hint:) push(all, last: true) + concatenated
- * pull() output: Sources/LZ77/Deflator/LZ77.Deflator.swift:8-44, LZ77.DeflatorBuffers.swift:46-93,
- * LZ77.DeflatorBuffers.Stream.swift:30-709.  The host re-chunks the stream into IDATs of any size
- * (the reference's own chunking is platform dependent).  d_dst capacity: spng_deflate_bound(src_len).
- * Levels <= 7 (greedy / lazy search) run on the device in this version; level >= 8 (the
- * shortest-path search) returns SPNG_E_ARGUMENT. */
+/* replaces LZ77.Deflator(format:level:exponent:hint:) push(all, last: true) + concatenated pull() output:
+ * Sources/LZ77/Deflator/LZ77.Deflator.swift:8-44, LZ77.DeflatorBuffers.swift:46-93,
+ * LZ77.DeflatorBuffers.Stream.swift:30-709, LZ77.DeflatorMatches.swift:225-379 (levels >= 8).  Every level of
+ * LZ77.DeflatorSearch (:13-35) runs on the device: greedy 0-3, lazy 4-7, shortest path 8 and up (>= 13: the
+ * last row).  `hint` only sizes the reference's output chunks (platform dependent there): the host re-chunks
+ * the concatenated stream into IDATs of any size.  d_dst capacity: spng_deflate_bound(src_len).  The window
+ * exponent travels in spng_stream_desc.reserved (batch form) / the `exponent` argument; PNG always uses 15,
+ * and LZ77.Format.ios ignores it (LZ77.DeflatorBuffers.swift:52-55). */
 uint64_t spng_deflate_bound(uint64_t n);
 int32_t spng_deflate_batch(spng_ctx *ctx, const spng_stream_desc *descs, const int32_t *levels, uint32_t count,
                            spng_result *d_results, spng_result *h_results);
 int32_t spng_deflate(spng_ctx *ctx, const void *src, uint64_t n, int32_t format, int32_t level,
                      void *dst, uint64_t cap, spng_result *result);
+int32_t spng_deflate_window(spng_ctx *ctx, const void *src, uint64_t n, int32_t format, int32_t level, int32_t exponent,
+                            void *dst, uint64_t cap, spng_result *result);
 /* replaces PNG.Encoder.pull end to end (PNG.Encoder.swift:33-129): storage -> zlib stream; d_rows is
  * scratch for the filtered scanlines (>= U bytes), d_idat receives the stream (capacity idat_len). */
 int32_t spng_encode_batch(spng_ctx *ctx, const spng_image_desc *descs, int32_t level, uint32_t count,

@@ -39,7 +39,7 @@ EXPORTS = [
     "spng_storage_size", "spng_create", "spng_destroy", "spng_stream", "spng_sync", "spng_profile",
     "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_unfilter_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
-    "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_encode_batch",
+    "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
 ]
 
 
@@ -156,6 +156,7 @@ def load_library():
     lib.spng_deflate_bound.argtypes = [u64]
     lib.spng_deflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), ctypes.POINTER(i32), u32, vp, rp]
     lib.spng_deflate.argtypes = [vp, vp, u64, i32, i32, vp, u64, rp]
+    lib.spng_deflate_window.argtypes = [vp, vp, u64, i32, i32, i32, vp, u64, rp]
     lib.spng_encode_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), i32, u32, vp, rp]
     for name in EXPORTS:
         getattr(lib, name)
@@ -339,13 +340,14 @@ class Session:
                                               ctypes.byref(res)))
         return bytes(dst[:u])
 
-    def deflate(self, data: bytes, level: int, fmt=FORMAT_ZLIB) -> bytes:
+    def deflate(self, data: bytes, level: int, fmt=FORMAT_ZLIB, exponent: int = 15) -> bytes:
         """Whole-stream LZ77.Deflator (push(all, last: true) + concatenated pull()): -> stream bytes"""
         cap = self.lib.spng_deflate_bound(len(data))
         src = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
         dst = (ctypes.c_uint8 * cap)()
         res = Result()
-        _check(self.lib, self.lib.spng_deflate(self.ctx, src, len(data), fmt, level, dst, cap, ctypes.byref(res)))
+        _check(self.lib, self.lib.spng_deflate_window(self.ctx, src, len(data), fmt, level, exponent, dst, cap,
+                                                      ctypes.byref(res)))
         if res.status != DONE:
             raise SpngError(res.status)
         return bytes(dst[:res.written])

@@ -74,6 +74,7 @@ struct spng_ctx {
     Slab *cur = nullptr;
     void *d_ring = nullptr; size_t ring_cap = 0;     // deflate link rings
     // parallel inflate (pinflate.hip): chunk-record slab, token buffer, knobs (spng_configure)
+    void *d_graph = nullptr; size_t graph_cap = 0;   // deflate levels >= 8: match graphs
     void *d_log = nullptr;  size_t log_cap = 0;
     void *d_tok = nullptr;  size_t tok_cap = 0;      // bytes
     int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0};
@@ -227,6 +228,7 @@ void spng_destroy(spng_ctx *c)
     if (c->d_ws) (void)hipFree(c->d_ws);
     for (auto &sl : c->slabs) { if (sl.h) (void)hipHostFree(sl.h); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     if (c->d_ring) (void)hipFree(c->d_ring);
+    if (c->d_graph) (void)hipFree(c->d_graph);
     if (c->d_log) (void)hipFree(c->d_log);
     if (c->d_tok) (void)hipFree(c->d_tok);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -869,7 +871,9 @@ int32_t spng_filter(spng_ctx *c, const void *storage,
 
 uint64_t spng_deflate_bound(uint64_t n) { return n + n / 4 + 4096; }
 
-// shared by spng_deflate_batch / spng_encode_batch: per-stream link rings live in a context-owned slab
+// shared by spng_deflate_batch / spng_encode_batch.  Per-stream link rings live in a context-owned slab; so
+// does the match graph of the levels >= 8 (129 bytes per vertex, up to 2^21 vertices per stream): those
+// streams are launched in groups that fit the slab, one group after the other on the stream.
 static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_result *dr, Arena &a, size_t jslot)
 {
     const size_t ring_bytes = (size_t)jobs.size() * 65536 * 4;
@@ -880,11 +884,54 @@ static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_r
         HIP_TRY(hipMalloc(&c->d_ring, ring_bytes));
         c->ring_cap = ring_bytes;
     }
-    for (size_t i = 0; i < jobs.size(); ++i) jobs[i].ring = (uint32_t *)c->d_ring + i * 65536;
-    memcpy(a.host<DeflateJob>(jslot), jobs.data(), jobs.size() * sizeof(DeflateJob));
-    if (int32_t st = c->upload(jslot, jslot + jobs.size() * sizeof(DeflateJob))) return st;
+    // greedy / lazy streams first, then the full-search ones: two contiguous job tables
+    std::vector<DeflateJob> sorted;
+    sorted.reserve(jobs.size());
+    for (auto &j : jobs) if (j.level < 8) sorted.push_back(j);
+    const size_t nfast = sorted.size();
+    uint64_t need = 0, largest = 0;
+    for (auto &j : jobs) if (j.level >= 8) {
+        sorted.push_back(j);
+        DeflateJob &f = sorted.back();
+        f.graph_vertices = (uint32_t)deflate_graph_vertices(f.src_len);
+        const uint64_t bytes = deflate_graph_bytes(f.graph_vertices);
+        need += bytes; largest = bytes > largest ? bytes : largest;
+    }
+    if (need) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        uint64_t budget = (uint64_t)(free_b + c->graph_cap) * 3 / 4;
+        if (budget < largest) budget = largest;
+        const uint64_t want = need < budget ? need : budget;
+        if (want > c->graph_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_graph) HIP_TRY(hipFree(c->d_graph));
+            c->d_graph = nullptr; c->graph_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_graph, want));
+            c->graph_cap = want;
+        }
+    }
+    for (size_t i = 0; i < sorted.size(); ++i) sorted[i].ring = (uint32_t *)c->d_ring + i * 65536;
+    // groups of full-search streams that fit the slab together
+    std::vector<std::pair<size_t, size_t>> groups;
+    for (size_t i = nfast; i < sorted.size();) {
+        uint64_t used = 0;
+        size_t k = i;
+        while (k < sorted.size()) {
+            const uint64_t bytes = deflate_graph_bytes(sorted[k].graph_vertices);
+            if (used + bytes > c->graph_cap && k > i) break;
+            sorted[k].graph = (uint32_t *)((char *)c->d_graph + used);
+            used += bytes; ++k;
+        }
+        groups.push_back({i, k});
+        i = k;
+    }
+    memcpy(a.host<DeflateJob>(jslot), sorted.data(), sorted.size() * sizeof(DeflateJob));
+    if (int32_t st = c->upload(jslot, jslot + sorted.size() * sizeof(DeflateJob))) return st;
     Timed t(c, SPNG_K_DEFLATE);
-    HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)jobs.size(), dr, c->stream));
+    if (nfast) HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)nfast, dr, c->stream));
+    for (auto &gr : groups)
+        HIP_TRY(launch_deflate_full(a.dev<DeflateJob>(jslot) + gr.first, (uint32_t)(gr.second - gr.first), dr, c->stream));
     return SPNG_DONE;
 }
 
@@ -897,9 +944,12 @@ int32_t spng_deflate_batch(spng_ctx *c, const spng_stream_desc *descs, const int
     std::lock_guard<std::mutex> g(c->mu);
     std::vector<DeflateJob> jobs(count);
     for (uint32_t i = 0; i < count; ++i) {
-        if ((!descs[i].d_src && descs[i].src_len) || !descs[i].d_dst || levels[i] > 7) return SPNG_E_ARGUMENT;
+        // spng_stream_desc.reserved: window exponent 8 ... 15 (0 = 15, as PNG always uses)
+        const int32_t e = descs[i].reserved ? descs[i].reserved : 15;
+        if ((!descs[i].d_src && descs[i].src_len) || !descs[i].d_dst || e < 8 || e > 15) return SPNG_E_ARGUMENT;
         jobs[i] = DeflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst, descs[i].src_len,
-                             descs[i].dst_cap, nullptr, descs[i].format, levels[i], i};
+                             descs[i].dst_cap, nullptr, descs[i].format, levels[i], i,
+                             descs[i].format == SPNG_FORMAT_IOS ? 15u : (uint32_t)e, nullptr, 0, 0};
     }
     if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result)) + 1024)) return st;
     Arena a{c};
@@ -917,12 +967,18 @@ int32_t spng_deflate_batch(spng_ctx *c, const spng_stream_desc *descs, const int
 int32_t spng_deflate(spng_ctx *c, const void *src, uint64_t n, int32_t format, int32_t level,
                      void *dst, uint64_t cap, spng_result *result)
 {
-    if (!c || (!src && n) || !dst || !result) return SPNG_E_ARGUMENT;
+    return spng_deflate_window(c, src, n, format, level, 15, dst, cap, result);
+}
+
+int32_t spng_deflate_window(spng_ctx *c, const void *src, uint64_t n, int32_t format, int32_t level, int32_t exponent,
+                            void *dst, uint64_t cap, spng_result *result)
+{
+    if (!c || (!src && n) || !dst || !result || exponent < 8 || exponent > 15) return SPNG_E_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
     DevBuf ds, dd;
     HIP_TRY(ds.alloc(n + 8)); HIP_TRY(dd.alloc(cap));
     HIP_TRY(hipMemcpyAsync(ds.p, src, n, hipMemcpyHostToDevice, c->stream));
-    spng_stream_desc d{ds.p, n, dd.p, cap, format, 0};
+    spng_stream_desc d{ds.p, n, dd.p, cap, format, exponent};
     if (int32_t st = spng_deflate_batch(c, &d, &level, 1, nullptr, result)) return st;
     const uint64_t w = result->written < cap ? result->written : cap;
     if (w) HIP_TRY(hipMemcpy(dst, dd.p, w, hipMemcpyDeviceToHost));
@@ -932,7 +988,7 @@ int32_t spng_deflate(spng_ctx *c, const void *src, uint64_t n, int32_t format, i
 int32_t spng_encode_batch(spng_ctx *c, const spng_image_desc *descs, int32_t level, uint32_t count,
                           spng_result *d_results, spng_result *h_results)
 {
-    if (!c || (!descs && count) || level > 7) return SPNG_E_ARGUMENT;
+    if (!c || (!descs && count)) return SPNG_E_ARGUMENT;
     if (!count) return SPNG_DONE;
     // filter-select (own lock), then deflate of the filtered scanlines
     if (int32_t st = spng_filter_batch(c, descs, count, d_results, nullptr)) return st;

@@ -99,6 +99,9 @@ struct DeflateJob {
     uint32_t      *ring;          // 65536-entry link ring (scratch, HBM)
     int32_t        format, level;
     uint32_t       image;
+    uint32_t       exponent;      // window = 2^exponent (LZ77.Deflator(exponent:); PNG: 15)
+    uint32_t      *graph;         // levels >= 8: match-graph scratch (deflate_graph_bytes)
+    uint32_t       graph_vertices, pad;
 };
 
 // PNG.adam7, PNG.Decoder.swift:6-15
@@ -120,6 +123,9 @@ hipError_t launch_pinf_emit(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, ui
 hipError_t launch_pinf_resolve(PStream *d_streams, uint32_t nstreams, uint32_t *d_tokens, spng_result *d_results, int32_t *d_done,
                                uint32_t pass, hipStream_t stream);
 hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
+hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
+uint64_t deflate_graph_vertices(uint64_t n);
+uint64_t deflate_graph_bytes(uint64_t vertices);
 hipError_t launch_filter(const FilterJob *d_jobs, uint32_t count, uint32_t max_rows, hipStream_t stream);
 hipError_t launch_adler_partial(const uint8_t *d, uint64_t n, uint32_t chunk, uint64_t *d_out, uint32_t blocks,
                                 hipStream_t stream);

@@ -286,12 +286,21 @@ __device__ __forceinline__ void load_limits(const PLds &s, Lim &lc)
     for (int k = 0; k < 7; ++k) { const int l = DBITS + 1 + k; lc.dist[k] = UNI((uint32_t)(s.tdist.first[l] + s.tdist.count[l]) << (15 - l)); }
 }
 
-__device__ __attribute__((always_inline)) bool parse_header(PLds &s, const gbyte *src, uint64_t n, uint64_t pos, Hdr &h, int lane)
+#ifdef SPNG_COUNT_PROF
+#define HP(k) do { if (hp) { const uint64_t now_ = __builtin_readcyclecounter(); hp[k] += now_ - hp[7]; hp[7] = now_; } } while (0)
+#define HP_ARG , uint64_t *hp = nullptr
+#else
+#define HP(k)
+#define HP_ARG
+#endif
+__device__ __attribute__((always_inline)) bool parse_header(PLds &s, const gbyte *src, uint64_t n, uint64_t pos, Hdr &h, int lane HP_ARG)
 {
     const uint64_t total = n * 8;
     if (pos + 3 > total) return false;
     const uint64_t wbyte = (pos >> 5) << 2;
+    HP(6);
     stage_bytes(s.stage, src, n, wbyte, 1, lane);
+    HP(0);
     uint32_t rel = (uint32_t)(pos - wbyte * 8);
     const uint32_t first = upeek32(s.stage, rel);
     h.bfinal = first & 1; h.type = (first >> 1) & 3;
@@ -333,12 +342,16 @@ __device__ __attribute__((always_inline)) bool parse_header(PLds &s, const gbyte
     }
     WSYNC();
     if (!UB(build<2>(s.hist, s.run, s.lens, 19, s.lit, MBITS, (uint16_t *)nullptr, &s.tlit, false, lane))) return false;
+    HP(1);
     // the code lengths, run-length coded (:144-263); at most 4498 bits: inside the staged KiB
     const uint32_t rel_end = (uint32_t)((total - wbyte * 8) > 0xffffffffull ? 0xffffffffu : (total - wbyte * 8));
     const uint32_t want = literals + distances;
     if (!UB(decode_lengths(s, rel, rel_end, want, lane))) return false;
+    HP(2);
     const bool okd = UB(build<1>(s.hist, s.run, s.lens + literals, (int)distances, s.dist, DBITS, (uint16_t *)nullptr, &s.tdist, true, lane, s.ext_dist));
+    HP(3);
     const bool okl = UB(build<0>(s.hist, s.run, s.lens, (int)literals, s.lit, LBITS, (uint16_t *)nullptr, &s.tlit, false, lane, s.ext_lit));
+    HP(4);
     if (!okl || !okd) return false;
     h.payload = wbyte * 8 + rel;
     return true;
@@ -605,14 +618,19 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
     uint64_t pos = start, ntok = 0;
     int32_t status = PSEG_FAIL;
 #ifdef SPNG_COUNT_PROF
-    uint64_t cp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t cp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, hpv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     cp[15] = __builtin_readcyclecounter();
 #endif
     for (;;) {
         if (pos >= limit) { if (pos == limit) status = PSEG_CONT; break; }
         Hdr h;
         CP(5);
+#ifdef SPNG_COUNT_PROF
+        hpv[7] = __builtin_readcyclecounter();
+        const bool hok = UB(parse_header(s, src, n, pos, h, lane, hpv));
+#else
         const bool hok = UB(parse_header(s, src, n, pos, h, lane));
+#endif
         CP(6);
         CPN(12, 1);
         if (!hok) break;
@@ -646,6 +664,8 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
     if (blockIdx.x == 1 && lane == 0)
         printf("count: %lu blocks %lu chunks %lu tokens; steps r0 %lu p2 %lu; cycles: stage %lu setup %lu round0 %lu phase2 %lu path+rec %lu header %lu other %lu\n",
                cp[12], cp[10], cp[11], cp[8], cp[9], cp[0], cp[1], cp[2], cp[3], cp[4], cp[6], cp[5]);
+    if (blockIdx.x == 1 && lane == 0)
+        printf("header: stage %lu precode %lu lengths %lu build-dist %lu build-lit %lu\n", hpv[0], hpv[1], hpv[2], hpv[3], hpv[4]);
 #endif
 }
 
@@ -807,7 +827,6 @@ __global__ __launch_bounds__(64) void pinf_assign_kernel(PStream *__restrict__ s
 // ---- resolve: tokens -> bytes -----------------------------------------------------------------------
 static constexpr uint32_t RT = 512;                 // threads per stream
 static constexpr uint32_t TILE = 8192;              // output bytes resolved per step (16 per thread)
-static constexpr uint32_t TOKS = 2048;              // tokens looked at per step (4 per thread)
 static constexpr uint32_t WINDOW = 32768;           // the DEFLATE window
 static constexpr uint32_t R_DONE = 0x8000;          // state: R_DONE | byte, or the tile index of an earlier byte
 
@@ -819,16 +838,18 @@ static constexpr uint32_t R_DONE = 0x8000;          // state: R_DONE | byte, or 
 #define RP(k)
 #endif
 
-struct RLds {
+template <int TPT>                     // tokens looked at per thread and step
+struct RLdsT {
     uint8_t  ring[WINDOW];             // the last 32 KiB of output, at position mod 32 KiB
     uint16_t state[TILE];              // marks while a tile is laid out, then one entry per output byte
-    uint32_t tokv[TOKS];
-    uint16_t toks[TOKS];               // first byte of each token on the tile
+    uint32_t tokv[RT * TPT];
+    uint16_t toks[RT * TPT];           // first byte of each token on the tile
     uint32_t part[24];
     uint32_t again[3];                 // pointer jumping: somebody still has an unknown byte (flag of round r: r mod 3)
 };
 
 // exclusive prefix sum over the workgroup (8 waves); every thread gets the grand total too
+template <class RLds>
 __device__ __forceinline__ uint32_t block_excl_scan(RLds &s, uint32_t v, uint32_t &total, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -843,6 +864,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(RLds &s, uint32_t v, uint32_
     total = all;
     return off + before;
 }
+template <class RLds>
 __device__ __forceinline__ uint32_t block_sum(RLds &s, uint32_t v, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -854,6 +876,7 @@ __device__ __forceinline__ uint32_t block_sum(RLds &s, uint32_t v, int tid)
     for (int w = 0; w < (int)(RT / 64); ++w) all += s.part[8 + w];
     return all;
 }
+template <class RLds>
 __device__ __forceinline__ uint32_t block_excl_max(RLds &s, uint32_t v, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
@@ -887,16 +910,23 @@ __device__ __forceinline__ uint32_t block_excl_max(RLds &s, uint32_t v, int tid)
 //            is needed (whatever is read is a valid member of the byte's chain).
 //   store    sixteen bytes per thread to the output and the ring, Adler-32 folded in (inflate.hip:
 //            struct Out).
-__global__ __launch_bounds__(RT, 2) void pinf_resolve_kernel(const PStream *__restrict__ streams, const uint32_t *__restrict__ tokens,
+// Two instantiations: 4 tokens per thread fill a tile when tokens average 4 bytes (zlib-made streams);
+// literal-heavy streams (swift-png's own level-6 output: 2 bytes per token) take 8, or their tiles would
+// be half empty.  A workgroup leaves at once when its stream belongs to the other instantiation.
+template <int TPT>
+__global__ __launch_bounds__(RT, 4) void pinf_resolve_kernel(const PStream *__restrict__ streams, const uint32_t *__restrict__ tokens,
                                                              spng_result *__restrict__ results, int32_t *__restrict__ done,
                                                              uint32_t pass)
 {
+    typedef RLdsT<TPT> RLds;
+    constexpr uint32_t TOKS = RT * TPT;
     __shared__ __attribute__((aligned(16))) RLds s;
     const int tid = threadIdx.x;
     const PStream &st = streams[blockIdx.x];
     if (!UNI(st.ok) || UNI(st.pass) != pass) return;
     const uint32_t *tk = tokens + uni64(st.tok_base);
     const uint64_t ntok = uni64(st.ntok);
+    if ((uni64(st.dst_cap) < 3 * ntok) != (TPT == 8)) return;   // (capacity ~ output size: under 3 bytes per token)
     gbyte *dst = (gbyte *)uni64((uint64_t)st.dst);
     const uint64_t cap = uni64(st.dst_cap);
     const gbyte *src = (const gbyte *)uni64((uint64_t)st.src);
@@ -906,16 +936,16 @@ __global__ __launch_bounds__(RT, 2) void pinf_resolve_kernel(const PStream *__re
     bool bad = false;
     const uint32_t j0 = (uint32_t)tid * 16;
     RP_DECL
-    uint32_t tokr[4];
+    uint32_t tokr[TPT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const uint64_t i = (uint64_t)tid * 4 + k; tokr[k] = i < ntok ? tk[i] : 0u; }
+    for (int k = 0; k < TPT; ++k) { const uint64_t i = (uint64_t)tid * TPT + k; tokr[k] = i < ntok ? tk[i] : 0u; }
     while (ti < ntok) {
         RP(0);
         // ---- lay the next tokens out on the tile
-        uint32_t len[4], sum = 0;
+        uint32_t len[TPT], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint64_t i = ti + (uint64_t)tid * 4 + k;
+        for (int k = 0; k < TPT; ++k) {
+            const uint64_t i = ti + (uint64_t)tid * TPT + k;
             len[k] = i < ntok ? ((tokr[k] & T_MATCH) ? (tokr[k] & 0x1ff) : 1u) : 0u;
             sum += len[k];
         }
@@ -928,10 +958,10 @@ __global__ __launch_bounds__(RT, 2) void pinf_resolve_kernel(const PStream *__re
         uint32_t off = block_excl_scan(s, sum, total, tid);      // (barriers inside: all marks are clear)
         uint32_t pack = 0;                                       // tokens taken << 16 | their bytes
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < TPT; ++k) {
             const uint32_t end = off + len[k];
             if (len[k] && end <= TILE) {
-                const uint32_t id = (uint32_t)tid * 4 + k;
+                const uint32_t id = (uint32_t)tid * TPT + k;
                 s.tokv[id] = tokr[k];
                 s.toks[id] = (uint16_t)off;
                 s.state[off] = (uint16_t)(id + 1);
@@ -947,7 +977,7 @@ __global__ __launch_bounds__(RT, 2) void pinf_resolve_kernel(const PStream *__re
         if (pos + tlen > cap) { bad = true; break; }
         // the next tile's tokens travel while this one is resolved
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const uint64_t i = ti + nused + (uint64_t)tid * 4 + k; tokr[k] = i < ntok ? tk[i] : 0u; }
+        for (int k = 0; k < TPT; ++k) { const uint64_t i = ti + nused + (uint64_t)tid * TPT + k; tokr[k] = i < ntok ? tk[i] : 0u; }
         RP(1);
         // ---- the token of each of my sixteen bytes
         uint32_t mkw[8];
@@ -1165,7 +1195,8 @@ hipError_t launch_pinf_emit(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, ui
 hipError_t launch_pinf_resolve(PStream *d_streams, uint32_t nstreams, uint32_t *d_tokens, spng_result *d_results, int32_t *d_done,
                                uint32_t pass, hipStream_t stream)
 {
-    pinf_resolve_kernel<<<nstreams, RT, 0, stream>>>(d_streams, d_tokens, d_results, d_done, pass);
+    pinf_resolve_kernel<4><<<nstreams, RT, 0, stream>>>(d_streams, d_tokens, d_results, d_done, pass);
+    pinf_resolve_kernel<8><<<nstreams, RT, 0, stream>>>(d_streams, d_tokens, d_results, d_done, pass);
     return hipGetLastError();
 }
 

@@ -342,10 +342,10 @@ def _deflate_payloads():
     return p
 
 
-@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_deflate_vs_oracle(gpu, level):
-    """Identical DEFLATE bitstream at the same level (BASELINE north star), greedy and lazy rows of
-    LZ77.DeflatorSearch.swift:17-24."""
+    """Identical DEFLATE bitstream at the same level (BASELINE north star): every row of
+    LZ77.DeflatorSearch.swift:17-35 -- greedy, lazy and the shortest-path search."""
     s = gpu.load()
     for kind, data in sorted(_deflate_payloads().items()):
         for fmt in (0, 1):
@@ -364,6 +364,67 @@ def test_deflate_block_boundaries(gpu):
         data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
         for level in (0, 6):
             assert s.deflate(data, level) == ph.orc_deflate(data, level), (n, level)
+
+
+def test_deflate_level9_reference_goldens(gpu):
+    """BASELINE configs[3] parity pin: the device's filter-select + level-9 DEFLATE reproduces, bit for bit,
+    the IDAT streams swift-png itself committed under Tests/Outputs (the five copied to tests/golden/encode
+    by make_golden.py; digests of all 28 in encode.json)."""
+    s = gpu.load()
+    table = json.loads((ph.GOLDEN / "encode.json").read_text())
+    seen = 0
+    for base in sorted((ph.GOLDEN / "encode").glob("*.baseline.png")):
+        name = base.name[:-len(".baseline.png")]
+        src = ph.parse_png(base.read_bytes())
+        st, storage, _ = s.decode(src.idat, src.width, src.height, src.depth, src.channels, src.interlaced)
+        assert st == 0
+        rows = s.filter(storage, src.width, src.height, src.depth, src.channels, False)
+        got = s.deflate(rows, 9)
+        want = ph.parse_png((ph.GOLDEN / "encode" / f"{name}.swiftpng9.png").read_bytes()).idat
+        assert len(got) == table[name]["idat_len"] and hashlib.sha256(got).hexdigest() == table[name]["idat_sha256"], name
+        assert got == want, name
+        seen += 1
+    assert seen == 5
+
+
+def test_deflate_full_search_block_growth(gpu):
+    """Levels >= 8 close a block after limit - 1 vertices, the limit doubling per block (2047, 4095, 8191 ...
+    vertices, LZ77.DeflatorMatches.swift:229); runs > 100 make the following vertices edgeless
+    (DeflatorBuffers.Stream.swift:376-380); the first block runs 2 x iterations passes."""
+    s = gpu.load()
+    rng = np.random.default_rng(31)
+    noisy = rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
+    runs = b"".join(bytes([int(rng.integers(0, 4))]) * int(rng.integers(90, 700)) for _ in range(120))
+    texty = (b"lorem ipsum dolor sit amet, consectetur adipiscing elit " * 900)[:40001]
+    mixed = noisy[:7000] + runs[:20000] + texty[:9000] + noisy[7000:9000]
+    for kind, data in (("noisy", noisy), ("runs", runs), ("text", texty), ("mixed", mixed)):
+        for level in (8, 9, 12):
+            got = s.deflate(data, level)
+            assert got == ph.orc_deflate(data, level), (kind, level)
+            assert zlib.decompress(got) == data
+    for n in (2046, 2047, 2048, 2049, 2050, 6141, 6142, 6143):
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert s.deflate(data, 9) == ph.orc_deflate(data, 9), n
+
+
+@pytest.mark.parametrize("exponent", [8, 11, 15])
+def test_deflate_window_exponent(gpu, exponent):
+    """LZ77.Deflator(format:level:exponent:hint:) with a small window (LZ77Tests/Compression.swift:12 uses 8):
+    zlib header, candidate reach and stream equal the oracle's at every search kind."""
+    s = gpu.load()
+    rng = np.random.default_rng(exponent)
+    data = (rng.integers(0, 6, 3000, dtype=np.uint8).tobytes() + b"abcdefgh" * 200) * 3
+    for level in (4, 7, 9, 10, 13):
+        got = s.deflate(data, level, 0, exponent)
+        assert got == ph.orc_deflate(data, level, 0, exponent), (level, exponent)
+        assert got[0] == ((exponent - 8) << 4 | 8) and zlib.decompress(got) == data
+    for count in (5, 50, 500, 5000):                            # the reference's own property test, levels 4 / 7 / 9
+        blob = rng.integers(0, 256, count, dtype=np.uint8).tobytes()
+        for level in (4, 7, 9):
+            got = s.deflate(blob, level, 0, exponent)
+            assert got == ph.orc_deflate(blob, level, 0, exponent)
+            st, out, _, _ = s.inflate(got)
+            assert st == 0 and out == blob
 
 
 def test_deflate_4k_rows_level6(gpu):
