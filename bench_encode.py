@@ -1,0 +1,124 @@
+"""bench.py --mode encode: BASELINE.json configs[3] -- random 4096x4096 RGBA8 rasters -> PNG at level 9 on one
+MI355X (filter-select + LZ77 match search + shortest-path parse + Huffman emit), bit-exact with the CPU path.
+
+A step = one spng_encode_batch over the whole batch (filter kernel, then the level-9 deflate kernel in groups
+that fit the match-graph slab).  `value` = encoded MPixels/s.  Parity: every stream of the step is inflated by
+zlib and compared with the filter kernel's scanlines, one stream is compared bit for bit with the oracle's
+level-9 stream of the same scanlines inside the cpu_baseline leg (the oracle is pinned on swift-png's own
+committed level-9 outputs)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+import time
+import zlib
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+W = H = 4096
+DEPTH, CHANNELS = 8, 4
+MPIX = W * H / 1e6
+HBM_PEAK_GBPS = 8000.0
+
+
+def run_encode(args, torch, dist, spng, s, rank, world):
+    from swift_png_amd.distributed import shard
+    lo, hi = shard(args.images, world, rank)
+    weak = args.scaling == "weak" or world == 1
+    n = args.images if weak else hi - lo
+    unique = min(args.unique, n)
+    U = spng.inflated_size(W, H, DEPTH, CHANNELS, False)
+    S = spng.storage_size(W, H, DEPTH, CHANNELS)
+    cap = s.lib.spng_deflate_bound(U)
+    gen = torch.Generator(device=s.tdev)
+    gen.manual_seed(1234 + rank)
+    rasters = [torch.randint(0, 256, (S,), dtype=torch.uint8, device=s.tdev, generator=gen) for _ in range(unique)]
+    d_rows = torch.empty(n * U, dtype=torch.uint8, device=s.tdev)
+    d_out = torch.empty(n * cap, dtype=torch.uint8, device=s.tdev)
+    descs = (spng.ImageDesc * n)()
+    for j in range(n):
+        r = rasters[j % unique]
+        descs[j] = spng.ImageDesc(d_out.data_ptr() + j * cap, cap, d_rows.data_ptr() + j * U, U, r.data_ptr(),
+                                  W, H, DEPTH, CHANNELS, 0, 0, 0)
+    dres = s.empty(n * ctypes.sizeof(spng.Result))
+
+    def step():
+        st = s.lib.spng_encode_batch(s.ctx, descs, args.level, n, ctypes.c_void_p(dres.data_ptr()), None)
+        assert st == 0, st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    s.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = {k: s.profile_get(getattr(spng, "K_" + k.upper()))[0] / args.steps for k in ("filter", "deflate")}
+    s.profile(False)
+    res = list((spng.Result * n).from_buffer_copy(bytes(dres.cpu().numpy())))
+    assert all(r.status == 0 for r in res), [r.status for r in res if r.status][:8]
+    total_c = sum(r.written for r in res)
+    # every distinct stream inflates (zlib) to the filter kernel's scanlines
+    streams = {}
+    for j in range(min(n, unique)):
+        z = bytes(d_out[j * cap:j * cap + res[j].written].cpu().numpy())
+        rows = bytes(d_rows[j * U:(j + 1) * U].cpu().numpy())
+        assert zlib.decompress(z) == rows, f"stream {j} does not inflate to its scanlines"
+        streams[j] = (z, rows)
+    t = torch.tensor([dt], dtype=torch.float64, device=s.tdev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank != 0:
+        return None
+    ms = dt / args.steps * 1e3
+    kernels = {
+        "filter": {"ms_per_step": round(prof["filter"], 3), "algorithmic_bytes": n * (S + U),
+                   "gbps": round(n * (S + U) / (prof["filter"] * 1e-3) / 1e9, 2),
+                   "frac_of_hbm_peak": round(n * (S + U) / (prof["filter"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+        "deflate": {"ms_per_step": round(prof["deflate"], 3), "algorithmic_bytes": n * U + total_c,
+                    "gbps": round((n * U + total_c) / (prof["deflate"] * 1e-3) / 1e9, 3),
+                    "frac_of_hbm_peak": round((n * U + total_c) / (prof["deflate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)},
+    }
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    out = {
+        "metric": "encoded_mpixels_per_s", "value": round(args.images * (world if weak else 1) * MPIX / (dt / args.steps), 2),
+        "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": f"{args.images} x 4096x4096 RGBA8 random rasters -> filter-select + DEFLATE level {args.level} "
+                               f"(spng_encode_batch); BASELINE configs[3]", "unique_images": unique,
+                   "compressed_ratio": round(n * U / total_c, 4)},
+        "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": kernels[dom]["gbps"], "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None,
+                     "ms_per_launch": kernels[dom]["ms_per_step"]},
+        "kernels": kernels,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        # the oracle on one core, on a bounded sample: the first 2 MiB of scanlines of stream 0 (level 9 on the
+        # whole 64 MiB image takes minutes on a core); also the bit-exactness anchor of this run
+        sys.path.insert(0, str(ROOT / "tests"))
+        import pnghelp as ph
+        z, rows = streams[0]
+        sample = rows[:2 << 20]
+        t0 = time.perf_counter()
+        want = ph.orc_deflate(sample, args.level)
+        dtc = time.perf_counter() - t0
+        got = s.deflate(sample, args.level)
+        assert got == want, "device level-%d stream differs from the oracle's" % args.level
+        out["cpu_baseline"] = {"value": round(len(sample) / 4 / 1e6 / dtc, 3), "unit": "MPixels/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle deflate level {args.level} of the first {len(sample)} scanline bytes of "
+                                         f"stream 0 (filter excluded), {dtc:.1f} s; the device stream of the same bytes is "
+                                         f"identical"}
+    return out

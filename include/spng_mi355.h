@@ -114,7 +114,8 @@ enum { SPNG_CFG_INFLATE_MODE = 0,   /* SPNG_INFLATE_AUTO: parallel pipeline, ser
                                        SPNG_INFLATE_SERIAL: serial kernel only */
        SPNG_CFG_SEGMENT_BYTES = 1,  /* parallel inflate: nominal segment length in compressed bytes */
        SPNG_CFG_TOKEN_BYTES = 2,    /* parallel inflate: size limit of the token buffer in bytes */
-       SPNG_CFG_COUNT = 3 };
+       SPNG_CFG_UNFILTER_PIECE_ROWS = 3,   /* unfilter: rows per piece a scanline chain is cut into */
+       SPNG_CFG_COUNT = 4 };
 enum { SPNG_INFLATE_AUTO = 0, SPNG_INFLATE_SERIAL = 1 };
 int32_t spng_configure(spng_ctx *ctx, int key, int64_t value);
 

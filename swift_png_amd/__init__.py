@@ -31,7 +31,7 @@ E_OUTPUT_CAPACITY, E_ARGUMENT, E_DEVICE, E_REFERENCE_UNDEFINED = 64, 65, 66, 67
 FORMAT_ZLIB, FORMAT_IOS = 0, 1
 K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER, K_PINFLATE = 0, 1, 2, 3, 4, 5, 6
 K_PINF_FIND, K_PINF_COUNT, K_PINF_EMIT, K_PINF_RESOLVE = 8, 9, 10, 11
-CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES = 0, 1, 2
+CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES, CFG_UNFILTER_PIECE_ROWS = 0, 1, 2, 3
 INFLATE_AUTO, INFLATE_SERIAL = 0, 1
 
 EXPORTS = [

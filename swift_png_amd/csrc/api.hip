@@ -77,7 +77,7 @@ struct spng_ctx {
     void *d_graph = nullptr; size_t graph_cap = 0;   // deflate levels >= 8: match graphs
     void *d_log = nullptr;  size_t log_cap = 0;
     void *d_tok = nullptr;  size_t tok_cap = 0;      // bytes
-    int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0};
+    int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0, 0};
     // profiling
     bool profiling = false;
     struct Span { int kernel; hipEvent_t a, b; };
@@ -396,9 +396,20 @@ static int32_t launch_plan(spng_ctx *c, const UnfilterPlan &plan, Arena &a, cons
     {
         Timed t(c, SPNG_K_UNFILTER);
         for (int k = 1; k <= 8; ++k)
-            if (!plan.unf[k].empty())
+            if (!plan.unf[k].empty()) {
+                // enough workgroups to fill the chip: chains are cut into pieces of piece_rows rows
+                // (unfilter.hip: at rows filtered with None / Sub) when there are few of them
+                uint64_t total_rows = 0; uint32_t max_rows = 1;
+                for (auto &j : plan.unf[k]) { total_rows += j.rows; max_rows = j.rows > max_rows ? j.rows : max_rows; }
+                uint32_t piece_rows = (uint32_t)c->cfg[SPNG_CFG_UNFILTER_PIECE_ROWS];
+                if (!piece_rows) {
+                    piece_rows = (uint32_t)((total_rows / 4096 + 63) & ~(uint64_t)63);
+                    if (piece_rows < 128) piece_rows = 128;
+                }
+                const uint32_t pieces = (max_rows + piece_rows - 1) / piece_rows;
                 HIP_TRY(launch_unfilter(a.dev<UnfJob>(slots.unf[k]), (uint32_t)plan.unf[k].size(), k,
-                                        d_results, c->stream));
+                                        d_results, pieces, piece_rows, c->stream));
+            }
     }
     if (!plan.scat.empty()) {
         Timed t(c, SPNG_K_SCATTER);

@@ -215,14 +215,15 @@ __device__ __forceinline__ void reconstruct4(uint8_t *tile, int rowb, int lane, 
 
 template <int BPP>
 __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob *__restrict__ jobs,
-                                                                     const spng_result *__restrict__ results)
+                                                                     const spng_result *__restrict__ results,
+                                                                     uint32_t sb_rows)
 {
     using C = Cfg<BPP>;
     constexpr int NW = SPNG_UNF_NW;
     __shared__ __attribute__((aligned(16))) uint8_t tiles[NW][65 * C::ROWB];
     __shared__ uint32_t done[NW];                        // tiles completed by each wave
 
-    const UnfJob job = jobs[blockIdx.x];
+    UnfJob job = jobs[blockIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (results && skip_status(results[job.image].status)) return;
     if (threadIdx.x < NW) done[threadIdx.x] = 0;
@@ -234,6 +235,28 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         const uint64_t len = *job.rows_len;
         const uint64_t avail = len > job.stream_off ? (len - job.stream_off) / job.in_stride : 0;
         rows = avail < rows ? (uint32_t)avail : rows;
+    }
+    // A chain is cut into pieces that different workgroups take: a row filtered with None or Sub does not
+    // look at the row above (PNG.Decoder.swift:160-168), so a piece may start there as if it were a first
+    // row.  Workgroup y owns the rows from the first such row at or after y * sb_rows up to the first one at
+    // or after (y + 1) * sb_rows.  (The filter bytes are never written, also when rows are defiltered in place.)
+    if (gridDim.y > 1) {
+        auto cut = [&](uint64_t x) -> uint32_t {
+            if (x == 0) return 0;
+            for (uint64_t r0 = x; r0 < rows; r0 += 64) {
+                const uint64_t r = r0 + lane;
+                const uint32_t ft = r < rows ? job.in[r * job.in_stride] : 0u;
+                const unsigned long long m = __ballot(r < rows && ft <= 1);
+                if (m) return (uint32_t)(r0 + __ffsll((long long)m) - 1);
+            }
+            return rows;
+        };
+        const uint32_t first = cut((uint64_t)blockIdx.y * sb_rows);
+        const uint32_t last = blockIdx.y + 1 == gridDim.y ? rows : cut((uint64_t)(blockIdx.y + 1) * sb_rows);
+        if (first >= last) return;
+        job.in += (uint64_t)first * job.in_stride;
+        job.out += (uint64_t)first * job.out_stride;
+        rows = last - first;
     }
     const int64_t pitch = job.pitch;
     const uint32_t W = job.pitch / BPP;
@@ -369,17 +392,18 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
 }
 
 hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, spng_result *d_results,
-                           hipStream_t stream)
+                           uint32_t pieces, uint32_t piece_rows, hipStream_t stream)
 {
     if (!count) return hipSuccess;
     constexpr int T = SPNG_UNF_NW * 64;
+    const dim3 grid(count, pieces ? pieces : 1);
     switch (bpp) {
-    case 1: unfilter_kernel<1><<<count, T, 0, stream>>>(d_jobs, d_results); break;
-    case 2: unfilter_kernel<2><<<count, T, 0, stream>>>(d_jobs, d_results); break;
-    case 3: unfilter_kernel<3><<<count, T, 0, stream>>>(d_jobs, d_results); break;
-    case 4: unfilter_kernel<4><<<count, T, 0, stream>>>(d_jobs, d_results); break;
-    case 6: unfilter_kernel<6><<<count, T, 0, stream>>>(d_jobs, d_results); break;
-    case 8: unfilter_kernel<8><<<count, T, 0, stream>>>(d_jobs, d_results); break;
+    case 1: unfilter_kernel<1><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
+    case 2: unfilter_kernel<2><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
+    case 3: unfilter_kernel<3><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
+    case 4: unfilter_kernel<4><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
+    case 6: unfilter_kernel<6><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
+    case 8: unfilter_kernel<8><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
