@@ -124,6 +124,7 @@ enum { SPNG_K_INFLATE = 0,          /* the serial inflate kernel (streams the pa
        SPNG_K_UNFILTER = 1, SPNG_K_SCATTER = 2, SPNG_K_FILTER = 3,
        SPNG_K_DEFLATE = 4, SPNG_K_ADLER = 5,
        SPNG_K_PINFLATE = 6,         /* the parallel inflate pipeline as a whole: find + count + scan + emit + resolve */
+       SPNG_K_UNPACK = 7,
        SPNG_K_PINF_FIND = 8, SPNG_K_PINF_COUNT = 9, SPNG_K_PINF_EMIT = 10, SPNG_K_PINF_RESOLVE = 11,   /* its stages */
        SPNG_K_COUNT = 16 };
 int32_t spng_profile(spng_ctx *ctx, int enable);                /* enable/disable + reset counters  */
@@ -160,6 +161,31 @@ int32_t spng_decode(spng_ctx *ctx, const void *idat, uint64_t n, int32_t format,
                     void *storage, spng_result *result);
 /* Adler-32 of a host buffer computed on the device (LZ77.MRC32, Wrappers/LZ77.MRC32.swift:26-50) */
 int32_t spng_adler32(spng_ctx *ctx, const void *data, uint64_t n, uint32_t *out);
+
+/* ---- pixels: the step behind the decode path ----------------------------------------------------- */
+/* One image to unpack.  palette: indexed formats only, palette_count x 4 bytes (r, g, b, a): PLTE with the
+ * tRNS alphas folded in, as PNG.Format keeps it.  key: the tRNS chroma key of a v / rgb / bgr format. */
+typedef struct spng_unpack_desc {
+    const void *d_storage;                      /* PNG.Image.storage, S bytes                        */
+    void       *d_out;                          /* width * height RGBA quadruplets of `target` bits  */
+    const void *d_palette;
+    uint32_t    width, height;
+    uint32_t    palette_count;
+    uint16_t    key[3];
+    uint8_t     depth, channels;                /* as in spng_image_desc                             */
+    uint8_t     indexed;                        /* PNG.Format.indexed1/2/4/8                         */
+    uint8_t     bgr;                            /* PNG.Format.bgr8 / bgra8 (CgBI)                    */
+    uint8_t     has_key;
+    uint8_t     target;                         /* 8 or 16: PNG.RGBA<UInt8> / PNG.RGBA<UInt16>       */
+} spng_unpack_desc;
+/* replaces PNG.RGBA<T>.unpack(_:of:deindexer:) with the default deindexer, T = UInt8 / UInt16
+ * (Sources/PNG/ColorTargets/PNG.RGBA.swift:259-365, depth rescaling Sources/PNG/PNG.swift:255-312,
+ * 495-524); what PNG.Image.unpack(as: PNG.RGBA<T>.self) returns.  All descs of a call share `target`.
+ * Output: r, g, b, a per pixel in host byte order. */
+int32_t spng_unpack_batch(spng_ctx *ctx, const spng_unpack_desc *descs, uint32_t count);
+int32_t spng_unpack(spng_ctx *ctx, const void *storage, uint32_t w, uint32_t h, int depth, int channels,
+                    int indexed, int bgr, int target, const void *palette, uint32_t palette_count,
+                    const uint16_t *key, void *out);
 
 /* ---- encode -------------------------------------------------------------------------------- */
 /* replaces PNG.Encoder.filter (PNG.Encoder.swift:132-204) + PNG.Image.collect

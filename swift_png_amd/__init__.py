@@ -30,6 +30,7 @@ E_EXTRANEOUS_IMAGE_DATA, E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM =
 E_OUTPUT_CAPACITY, E_ARGUMENT, E_DEVICE, E_REFERENCE_UNDEFINED = 64, 65, 66, 67
 FORMAT_ZLIB, FORMAT_IOS = 0, 1
 K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER, K_PINFLATE = 0, 1, 2, 3, 4, 5, 6
+K_UNPACK = 7
 K_PINF_FIND, K_PINF_COUNT, K_PINF_EMIT, K_PINF_RESOLVE = 8, 9, 10, 11
 CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES, CFG_UNFILTER_PIECE_ROWS = 0, 1, 2, 3
 INFLATE_AUTO, INFLATE_SERIAL = 0, 1
@@ -39,7 +40,7 @@ EXPORTS = [
     "spng_storage_size", "spng_create", "spng_destroy", "spng_stream", "spng_sync", "spng_profile",
     "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_unfilter_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
-    "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
+    "spng_unpack_batch", "spng_unpack", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
 ]
 
 
@@ -152,6 +153,9 @@ def load_library():
     lib.spng_decode.argtypes = [vp, vp, u64, i32, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, rp]
     lib.spng_adler32.argtypes = [vp, vp, u64, ctypes.POINTER(u32)]
     lib.spng_filter.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, rp]
+    lib.spng_unpack_batch.argtypes = [vp, vp, u32]
+    lib.spng_unpack.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                vp, u32, vp, vp]
     lib.spng_deflate_bound.restype = u64
     lib.spng_deflate_bound.argtypes = [u64]
     lib.spng_deflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), ctypes.POINTER(i32), u32, vp, rp]
@@ -339,6 +343,18 @@ class Session:
         _check(self.lib, self.lib.spng_filter(self.ctx, src, w, h, depth, channels, int(bool(interlaced)), dst,
                                               ctypes.byref(res)))
         return bytes(dst[:u])
+
+    def unpack(self, storage: bytes, w, h, depth, channels, indexed=False, bgr=False, target=16, palette=None, key=None):
+        """PNG.Image.unpack(as: PNG.RGBA<UInt8 / UInt16>.self): -> bytes of r, g, b, a per pixel (host order).
+        palette: bytes of (r, g, b, a) quadruplets (PLTE with the tRNS alphas folded in); key: tRNS chroma key."""
+        n = w * h * 4 * (target // 8)
+        src = (ctypes.c_uint8 * max(len(storage), 1)).from_buffer_copy(bytes(storage) or b"\0")
+        out = (ctypes.c_uint8 * max(n, 1))()
+        pal = (ctypes.c_uint8 * max(len(palette or b""), 1)).from_buffer_copy(bytes(palette or b"\0"))
+        k = (ctypes.c_uint16 * 3)(*(list(key) + [0, 0, 0])[:3]) if key is not None else None
+        _check(self.lib, self.lib.spng_unpack(self.ctx, src, w, h, depth, channels, int(bool(indexed)), int(bool(bgr)), target,
+                                              pal if palette else None, len(palette or b"") // 4, k, out))
+        return bytes(out[:n])
 
     def deflate(self, data: bytes, level: int, fmt=FORMAT_ZLIB, exponent: int = 15) -> bytes:
         """Whole-stream LZ77.Deflator (push(all, last: true) + concatenated pull()): -> stream bytes"""

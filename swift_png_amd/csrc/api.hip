@@ -880,6 +880,64 @@ int32_t spng_filter(spng_ctx *c, const void *storage,
 }
 
 
+int32_t spng_unpack_batch(spng_ctx *c, const spng_unpack_desc *descs, uint32_t count)
+{
+    if (!c || (!descs && count)) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    const int target = descs[0].target;
+    if (target != 8 && target != 16) return SPNG_E_ARGUMENT;
+    if (int32_t st = c->reserve(count * sizeof(UnpackJob) + 1024)) return st;
+    Arena a{c};
+    const size_t jslot = a.take(count * sizeof(UnpackJob));
+    uint64_t maxpix = 1;
+    for (uint32_t i = 0; i < count; ++i) {
+        const spng_unpack_desc &d = descs[i];
+        if (!valid_format(d.depth, d.channels) || !d.d_storage || !d.d_out || d.target != target ||
+            (d.indexed && (d.channels != 1 || d.depth > 8 || (!d.d_palette && d.palette_count))))
+            return SPNG_E_ARGUMENT;
+        UnpackJob j;
+        memset(&j, 0, sizeof j);
+        j.storage = (const uint8_t *)d.d_storage; j.out = d.d_out; j.palette = (const uint8_t *)d.d_palette;
+        j.width = d.width; j.height = d.height; j.palette_count = d.palette_count;
+        j.key[0] = d.key[0]; j.key[1] = d.key[1]; j.key[2] = d.key[2];
+        j.depth = d.depth; j.channels = d.channels; j.indexed = d.indexed; j.bgr = d.bgr; j.has_key = d.has_key;
+        a.host<UnpackJob>(jslot)[i] = j;
+        const uint64_t px = (uint64_t)d.width * d.height;
+        maxpix = px > maxpix ? px : maxpix;
+    }
+    if (int32_t st = c->upload(0, a.off)) return st;
+    uint64_t bx = (maxpix + 1023) / 1024;
+    if (bx > 4096) bx = 4096;
+    Timed t(c, SPNG_K_UNPACK);
+    HIP_TRY(launch_unpack(a.dev<UnpackJob>(jslot), count, (uint32_t)bx, target, c->stream));
+    return SPNG_DONE;
+}
+
+int32_t spng_unpack(spng_ctx *c, const void *storage, uint32_t w, uint32_t h, int depth, int channels,
+                    int indexed, int bgr, int target, const void *palette, uint32_t palette_count,
+                    const uint16_t *key, void *out)
+{
+    if (!c || !storage || !out || !valid_format(depth, channels) || (target != 8 && target != 16)) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t s = spng_storage_size(w, h, depth, channels), o = (uint64_t)w * h * 4 * (target / 8);
+    DevBuf ds, dout, dp;
+    HIP_TRY(ds.alloc(s)); HIP_TRY(dout.alloc(o)); HIP_TRY(dp.alloc((size_t)palette_count * 4));
+    HIP_TRY(hipMemcpyAsync(ds.p, storage, s, hipMemcpyHostToDevice, c->stream));
+    if (palette_count) HIP_TRY(hipMemcpyAsync(dp.p, palette, (size_t)palette_count * 4, hipMemcpyHostToDevice, c->stream));
+    spng_unpack_desc d{};
+    d.d_storage = ds.p; d.d_out = dout.p; d.d_palette = palette_count ? dp.p : nullptr;
+    d.width = w; d.height = h; d.palette_count = palette_count;
+    if (key) { d.key[0] = key[0]; d.key[1] = key[1]; d.key[2] = key[2]; d.has_key = 1; }
+    d.depth = (uint8_t)depth; d.channels = (uint8_t)channels; d.indexed = (uint8_t)(indexed != 0); d.bgr = (uint8_t)(bgr != 0);
+    d.target = (uint8_t)target;
+    if (int32_t st = spng_unpack_batch(c, &d, 1)) return st;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (o) HIP_TRY(hipMemcpy(out, dout.p, o, hipMemcpyDeviceToHost));
+    return SPNG_DONE;
+}
+
 uint64_t spng_deflate_bound(uint64_t n) { return n + n / 4 + 4096; }
 
 // shared by spng_deflate_batch / spng_encode_batch.  Per-stream link rings live in a context-owned slab; so

@@ -51,6 +51,17 @@ struct FilterJob {
     uint32_t       pitch;
 };
 
+// One image to unpack: PNG.Image.storage -> RGBA<UInt8 / UInt16> (unpack.hip)
+struct UnpackJob {
+    const uint8_t *storage;
+    void          *out;
+    const uint8_t *palette;       // indexed formats: palette_count x (r, g, b, a)
+    uint32_t       width, height;
+    uint32_t       palette_count;
+    uint16_t       key[3];        // tRNS chroma key, at the source depth
+    uint8_t        depth, channels, indexed, bgr, has_key, pad;
+};
+
 struct InflateJob {
     const uint8_t *src;
     uint8_t       *dst;
@@ -126,6 +137,7 @@ hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result 
 hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 uint64_t deflate_graph_vertices(uint64_t n);
 uint64_t deflate_graph_bytes(uint64_t vertices);
+hipError_t launch_unpack(const UnpackJob *d_jobs, uint32_t count, uint32_t blocks_x, int target, hipStream_t stream);
 hipError_t launch_filter(const FilterJob *d_jobs, uint32_t count, uint32_t max_rows, hipStream_t stream);
 hipError_t launch_adler_partial(const uint8_t *d, uint64_t n, uint32_t chunk, uint64_t *d_out, uint32_t blocks,
                                 hipStream_t stream);

@@ -331,6 +331,40 @@ def test_synthetic_4k_image_roundtrip(gpu):
     assert st == 0 and storage == img.tobytes()
 
 
+# ------------------------------------------------------------------------------------------ unpack
+def _palette_quads(png):
+    if png.palette is None:
+        return None
+    pal = np.frombuffer(png.palette, dtype=np.uint8).reshape(-1, 3)
+    quads = np.full((len(pal), 4), 255, dtype=np.uint8)
+    quads[:, :3] = pal
+    if png.trns:
+        t = np.frombuffer(png.trns, dtype=np.uint8)[:len(pal)]
+        quads[:len(t), 3] = t
+    return quads.tobytes()
+
+
+@pytest.mark.parametrize("name", sorted(TABLE))
+def test_unpack_rgba_vs_reference_goldens(gpu, name):
+    """PNG.Image.unpack(as: PNG.RGBA<UInt16>.self) on the device equals the reference's own
+    .rgba golden of every PngSuite fixture (digests in pngsuite.json; CgBI goldens premultiplied as
+    Roundtripping.swift:206-215 does); the UInt8 target is the same pixels at 8 bits."""
+    import struct
+    s = gpu.load()
+    png = ph.parse_png((ph.GOLDEN / "pngsuite" / name).read_bytes())
+    st, storage, _ = s.decode(png.idat, png.width, png.height, png.depth, png.channels, png.interlaced, png.fmt)
+    assert st == 0
+    key = None
+    if png.trns and png.color in (0, 2):
+        key = struct.unpack(">" + "H" * (1 if png.color == 0 else 3), png.trns[:2 if png.color == 0 else 6])
+    kw = dict(indexed=png.color == 3, bgr=png.ios and png.color in (2, 6), palette=_palette_quads(png) if png.color == 3 else None,
+              key=key)
+    got16 = s.unpack(storage, png.width, png.height, png.depth, png.channels, target=16, **kw)
+    assert hashlib.sha256(got16).hexdigest() == TABLE[name]["rgba16_sha256"], name
+    got8 = s.unpack(storage, png.width, png.height, png.depth, png.channels, target=8, **kw)
+    assert got8 == (np.frombuffer(got16, dtype="<u2") >> 8).astype(np.uint8).tobytes()
+
+
 # ------------------------------------------------------------------------------------------ deflate
 def _deflate_payloads():
     rng = np.random.default_rng(21)
