@@ -47,6 +47,13 @@ enum {
     SPNG_E_EXTRANEOUS_IMAGE_DATA = 48,         /* extraneousImageData */
     SPNG_E_EXTRANEOUS_COMPRESSED_DATA = 49,    /* extraneousImageDataCompressedData (host side) */
     SPNG_E_INCOMPLETE_DATASTREAM = 50,         /* incompleteImageDataCompressedDatastream (host side) */
+    /* PNG.LexingError, Sources/PNG/Lexing/PNG.LexingError.swift:9-35 (spng_lex_batch) */
+    SPNG_E_TRUNCATED_SIGNATURE = 80,           /* truncatedSignature */
+    SPNG_E_SIGNATURE = 81,                     /* invalidSignature(aux0 = the eight bytes, big-endian) */
+    SPNG_E_TRUNCATED_CHUNK_HEADER = 82,        /* truncatedChunkHeader (also: no IEND before the end) */
+    SPNG_E_TRUNCATED_CHUNK_BODY = 83,          /* truncatedChunkBody(expected: aux0) */
+    SPNG_E_CHUNK_TYPE = 84,                    /* invalidChunkTypeCode(aux0) */
+    SPNG_E_CHUNK_CHECKSUM = 85,                /* invalidChunkChecksum(declared: aux0, computed: aux1) */
     /* boundary-level conditions with no reference counterpart */
     SPNG_E_OUTPUT_CAPACITY = 64,      /* destination buffer too small */
     SPNG_E_ARGUMENT = 65,             /* bad argument (null pointer, depth/channels combination, ...) */
@@ -125,6 +132,7 @@ enum { SPNG_K_INFLATE = 0,          /* the serial inflate kernel (streams the pa
        SPNG_K_DEFLATE = 4, SPNG_K_ADLER = 5,
        SPNG_K_PINFLATE = 6,         /* the parallel inflate pipeline as a whole: find + count + scan + emit + resolve */
        SPNG_K_UNPACK = 7,
+       SPNG_K_LEX = 12,             /* chunk lexing + CRC-32 / IDAT chunk emission */
        SPNG_K_PINF_FIND = 8, SPNG_K_PINF_COUNT = 9, SPNG_K_PINF_EMIT = 10, SPNG_K_PINF_RESOLVE = 11,   /* its stages */
        SPNG_K_COUNT = 16 };
 int32_t spng_profile(spng_ctx *ctx, int enable);                /* enable/disable + reset counters  */
@@ -161,6 +169,43 @@ int32_t spng_decode(spng_ctx *ctx, const void *idat, uint64_t n, int32_t format,
                     void *storage, spng_result *result);
 /* Adler-32 of a host buffer computed on the device (LZ77.MRC32, Wrappers/LZ77.MRC32.swift:26-50) */
 int32_t spng_adler32(spng_ctx *ctx, const void *data, uint64_t n, uint32_t *out);
+
+/* ---- files: the step in front of the decode path, and behind the encode path ------------------------ */
+/* One PNG file resident in HBM, and where its concatenated IDAT payloads go (capacity: len is always enough). */
+typedef struct spng_file_desc {
+    const void *d_png;  uint64_t len;
+    void       *d_idat; uint64_t idat_cap;
+} spng_file_desc;
+typedef struct spng_lexed {
+    int32_t  status;                            /* SPNG_DONE: lexed through IEND with every checksum right */
+    uint32_t chunks;                            /* chunks lexed */
+    uint64_t aux[2];                            /* error payload */
+    uint32_t width, height;                     /* IHDR */
+    uint8_t  depth, color, compression, filter, interlace;
+    uint8_t  ios;                               /* a CgBI chunk was seen (PNG.Standard.ios) */
+    uint8_t  pad[2];
+    uint64_t idat_len;                          /* bytes written to d_idat */
+    uint64_t plte_off, trns_off;                /* offsets of the PLTE / tRNS payloads in the file (0: absent) */
+    uint32_t plte_len, trns_len;
+    uint64_t consumed;                          /* bytes lexed */
+} spng_lexed;
+/* replaces the lexing half of PNG.Image.decompress(stream:): signature(), chunk() with its CRC-32 check and
+ * chunk-type validation (Sources/PNG/Lexing/PNG.BytestreamSource.swift:44-108, PNG.Chunk.swift:69-88), the
+ * IHDR layout, and the IDAT loop (PNG.Image.swift:385-389) -- for whole files already in HBM. */
+int32_t spng_lex_batch(spng_ctx *ctx, const spng_file_desc *files, uint32_t count,
+                       spng_lexed *d_infos, spng_lexed *h_infos);
+/* One zlib stream to cut into IDAT chunks of chunk_bytes payload bytes (the last one shorter). */
+typedef struct spng_chunking_desc {
+    const void *d_stream; uint64_t len;
+    void       *d_out;    uint64_t out_cap;     /* len + 12 * ceil(len / chunk_bytes) bytes are written */
+    uint64_t    chunk_bytes;
+} spng_chunking_desc;
+/* replaces PNG.BytestreamDestination.format(type: .IDAT, data:) for every chunk PNG.Encoder.pull returns
+ * (Sources/PNG/Lexing/PNG.BytestreamDestination.swift:66-88, PNG.Image.swift:658-665). */
+int32_t spng_write_idat_batch(spng_ctx *ctx, const spng_chunking_desc *descs, uint32_t count,
+                              spng_result *d_results, spng_result *h_results);
+/* CRC-32 of a host buffer computed on the device (swift-hash CRC32 as used by chunk()) */
+int32_t spng_crc32(spng_ctx *ctx, const void *data, uint64_t n, uint32_t *out);
 
 /* ---- pixels: the step behind the decode path ----------------------------------------------------- */
 /* One image to unpack.  palette: indexed formats only, palette_count x 4 bytes (r, g, b, a): PLTE with the

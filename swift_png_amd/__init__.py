@@ -28,6 +28,8 @@ E_COMPRESSION_METHOD, E_WINDOW_SIZE, E_CHECK_BITS, E_DICTIONARY = 16, 17, 18, 19
  E_CODELENGTH_SEQUENCE, E_HUFFMAN_TABLE, E_STRING_REFERENCE) = range(32, 40)
 E_EXTRANEOUS_IMAGE_DATA, E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM = 48, 49, 50
 E_OUTPUT_CAPACITY, E_ARGUMENT, E_DEVICE, E_REFERENCE_UNDEFINED = 64, 65, 66, 67
+(E_TRUNCATED_SIGNATURE, E_SIGNATURE, E_TRUNCATED_CHUNK_HEADER, E_TRUNCATED_CHUNK_BODY, E_CHUNK_TYPE,
+ E_CHUNK_CHECKSUM) = range(80, 86)
 FORMAT_ZLIB, FORMAT_IOS = 0, 1
 K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER, K_PINFLATE = 0, 1, 2, 3, 4, 5, 6
 K_UNPACK = 7
@@ -40,7 +42,7 @@ EXPORTS = [
     "spng_storage_size", "spng_create", "spng_destroy", "spng_stream", "spng_sync", "spng_profile",
     "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_unfilter_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
-    "spng_unpack_batch", "spng_unpack", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
+    "spng_lex_batch", "spng_write_idat_batch", "spng_crc32", "spng_unpack_batch", "spng_unpack", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
 ]
 
 
@@ -59,6 +61,24 @@ class ImageDesc(ctypes.Structure):
                 ("rows_cap", ctypes.c_uint64), ("d_storage", ctypes.c_void_p), ("width", ctypes.c_uint32),
                 ("height", ctypes.c_uint32), ("depth", ctypes.c_uint8), ("channels", ctypes.c_uint8),
                 ("interlaced", ctypes.c_uint8), ("format", ctypes.c_uint8), ("reserved", ctypes.c_uint32)]
+
+
+class FileDesc(ctypes.Structure):
+    _fields_ = [("d_png", ctypes.c_void_p), ("len", ctypes.c_uint64), ("d_idat", ctypes.c_void_p), ("idat_cap", ctypes.c_uint64)]
+
+
+class Lexed(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int32), ("chunks", ctypes.c_uint32), ("aux", ctypes.c_uint64 * 2),
+                ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("depth", ctypes.c_uint8), ("color", ctypes.c_uint8),
+                ("compression", ctypes.c_uint8), ("filter", ctypes.c_uint8), ("interlace", ctypes.c_uint8),
+                ("ios", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 2), ("idat_len", ctypes.c_uint64),
+                ("plte_off", ctypes.c_uint64), ("trns_off", ctypes.c_uint64), ("plte_len", ctypes.c_uint32),
+                ("trns_len", ctypes.c_uint32), ("consumed", ctypes.c_uint64)]
+
+
+class ChunkingDesc(ctypes.Structure):
+    _fields_ = [("d_stream", ctypes.c_void_p), ("len", ctypes.c_uint64), ("d_out", ctypes.c_void_p),
+                ("out_cap", ctypes.c_uint64), ("chunk_bytes", ctypes.c_uint64)]
 
 
 # ---- error mirror --------------------------------------------------------------------------------
@@ -82,6 +102,10 @@ class DecodingError(SpngError):          # PNG.DecodingError
     pass
 
 
+class LexingError(SpngError):            # PNG.LexingError
+    pass
+
+
 _NAMES = {
     16: "invalidCompressionMethod", 17: "invalidWindowSize", 18: "invalidCheckBits", 19: "unexpectedDictionary",
     32: "invalidStreamChecksum", 33: "invalidBlockTypeCode", 34: "invalidBlockElementCountParity",
@@ -90,6 +114,8 @@ _NAMES = {
     48: "extraneousImageData", 49: "extraneousImageDataCompressedData",
     50: "incompleteImageDataCompressedDatastream", 64: "outputCapacity", 65: "invalidArgument",
     66: "deviceError", 67: "referenceUndefined",
+    80: "truncatedSignature", 81: "invalidSignature", 82: "truncatedChunkHeader", 83: "truncatedChunkBody",
+    84: "invalidChunkTypeCode", 85: "invalidChunkChecksum",
 }
 
 
@@ -102,6 +128,8 @@ def raise_for(status, aux=(0, 0)):
         raise DecompressionError(status, aux)
     if 48 <= status < 64:
         raise DecodingError(status, aux)
+    if 80 <= status < 96:
+        raise LexingError(status, aux)
     raise SpngError(status, aux)
 
 
@@ -153,6 +181,9 @@ def load_library():
     lib.spng_decode.argtypes = [vp, vp, u64, i32, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, rp]
     lib.spng_adler32.argtypes = [vp, vp, u64, ctypes.POINTER(u32)]
     lib.spng_filter.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, rp]
+    lib.spng_lex_batch.argtypes = [vp, ctypes.POINTER(FileDesc), u32, vp, ctypes.POINTER(Lexed)]
+    lib.spng_write_idat_batch.argtypes = [vp, ctypes.POINTER(ChunkingDesc), u32, vp, rp]
+    lib.spng_crc32.argtypes = [vp, vp, u64, ctypes.POINTER(u32)]
     lib.spng_unpack_batch.argtypes = [vp, vp, u32]
     lib.spng_unpack.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                 vp, u32, vp, vp]
@@ -343,6 +374,36 @@ class Session:
         _check(self.lib, self.lib.spng_filter(self.ctx, src, w, h, depth, channels, int(bool(interlaced)), dst,
                                               ctypes.byref(res)))
         return bytes(dst[:u])
+
+    def lex_batch(self, files):
+        """files: list of PNG file bytes -> (list[Lexed], list of concatenated IDAT payloads as bytes).
+        The lexing half of PNG.Image.decompress(stream:) for files resident in HBM."""
+        n = len(files)
+        d_png = [self.to_device(f) for f in files]
+        d_idat = [self.empty(len(f)) for f in files]
+        descs = (FileDesc * n)()
+        for i, (f, a, b) in enumerate(zip(files, d_png, d_idat)):
+            descs[i] = FileDesc(self._ptr(a), len(f), self._ptr(b), len(f))
+        infos = (Lexed * n)()
+        _check(self.lib, self.lib.spng_lex_batch(self.ctx, descs, n, None, infos))
+        return list(infos), [bytes(b[:r.idat_len].cpu().numpy()) for b, r in zip(d_idat, infos)]
+
+    def write_idat(self, stream: bytes, chunk_bytes: int) -> bytes:
+        """The IDAT chunks (length, type, data, CRC-32 each) of a zlib stream cut every chunk_bytes bytes."""
+        pieces = -(-len(stream) // chunk_bytes) if stream else 0
+        cap = len(stream) + 12 * pieces
+        src, dst = self.to_device(stream), self.empty(cap)
+        d = (ChunkingDesc * 1)(ChunkingDesc(self._ptr(src), len(stream), self._ptr(dst), cap, chunk_bytes))
+        res = (Result * 1)()
+        _check(self.lib, self.lib.spng_write_idat_batch(self.ctx, d, 1, None, res))
+        raise_for(res[0].status)
+        return bytes(dst[:res[0].written].cpu().numpy())
+
+    def crc32(self, data: bytes) -> int:
+        src = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+        out = ctypes.c_uint32(0)
+        _check(self.lib, self.lib.spng_crc32(self.ctx, src, len(data), ctypes.byref(out)))
+        return out.value
 
     def unpack(self, storage: bytes, w, h, depth, channels, indexed=False, bgr=False, target=16, palette=None, key=None):
         """PNG.Image.unpack(as: PNG.RGBA<UInt8 / UInt16>.self): -> bytes of r, g, b, a per pixel (host order).

@@ -166,6 +166,12 @@ const char *spng_status_string(int32_t s)
     case SPNG_E_EXTRANEOUS_IMAGE_DATA: return "image data buffer not empty after decoding final scanline";
     case SPNG_E_EXTRANEOUS_COMPRESSED_DATA: return "extraneous compressed image data after end of compressed stream";
     case SPNG_E_INCOMPLETE_DATASTREAM: return "reached end-of-image chunk while compressed image data stream is incomplete";
+    case SPNG_E_TRUNCATED_SIGNATURE: return "signature truncated";
+    case SPNG_E_SIGNATURE: return "invalid png signature bytes";
+    case SPNG_E_TRUNCATED_CHUNK_HEADER: return "chunk header truncated";
+    case SPNG_E_TRUNCATED_CHUNK_BODY: return "chunk body truncated";
+    case SPNG_E_CHUNK_TYPE: return "invalid chunk type code";
+    case SPNG_E_CHUNK_CHECKSUM: return "invalid chunk checksum";
     case SPNG_E_OUTPUT_CAPACITY: return "destination buffer too small";
     case SPNG_E_ARGUMENT: return "invalid argument";
     case SPNG_E_DEVICE: return "device error";
@@ -879,6 +885,80 @@ int32_t spng_filter(spng_ctx *c, const void *storage,
     return SPNG_DONE;
 }
 
+
+int32_t spng_lex_batch(spng_ctx *c, const spng_file_desc *files, uint32_t count, spng_lexed *d_infos, spng_lexed *h_infos)
+{
+    if (!c || (!files && count) || (!d_infos && !h_infos && count)) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    if (int32_t st = c->reserve(count * (sizeof(spng_file_desc) + sizeof(spng_lexed)) + 1024)) return st;
+    Arena a{c};
+    const size_t fslot = a.take(count * sizeof(spng_file_desc));
+    for (uint32_t i = 0; i < count; ++i) {
+        if ((!files[i].d_png && files[i].len) || (!files[i].d_idat && files[i].idat_cap)) return SPNG_E_ARGUMENT;
+        a.host<spng_file_desc>(fslot)[i] = files[i];
+    }
+    const size_t upload = a.off;
+    const size_t oslot = a.take(count * sizeof(spng_lexed));
+    if (int32_t st = c->upload(0, upload)) return st;
+    spng_lexed *dout = d_infos ? d_infos : a.dev<spng_lexed>(oslot);
+    { Timed t(c, SPNG_K_LEX); HIP_TRY(launch_lex(a.dev<spng_file_desc>(fslot), count, dout, c->stream)); }
+    if (h_infos) {
+        HIP_TRY(hipMemcpyAsync(h_infos, dout, count * sizeof(spng_lexed), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SPNG_DONE;
+}
+
+int32_t spng_write_idat_batch(spng_ctx *c, const spng_chunking_desc *descs, uint32_t count,
+                              spng_result *d_results, spng_result *h_results)
+{
+    if (!c || (!descs && count) || (!d_results && !h_results && count)) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    if (int32_t st = c->reserve(count * (sizeof(spng_chunking_desc) + sizeof(spng_result)) + 1024)) return st;
+    Arena a{c};
+    const size_t dslot = a.take(count * sizeof(spng_chunking_desc));
+    uint64_t most = 1;
+    for (uint32_t i = 0; i < count; ++i) {
+        if ((!descs[i].d_stream && descs[i].len) || !descs[i].d_out || !descs[i].chunk_bytes ||
+            descs[i].chunk_bytes > 0x7fffffffull) return SPNG_E_ARGUMENT;
+        a.host<spng_chunking_desc>(dslot)[i] = descs[i];
+        const uint64_t pieces = (descs[i].len + descs[i].chunk_bytes - 1) / descs[i].chunk_bytes;
+        most = pieces > most ? pieces : most;
+    }
+    const size_t upload = a.off;
+    const size_t rslot = a.take(count * sizeof(spng_result));
+    if (int32_t st = c->upload(0, upload)) return st;
+    spng_result *dr = d_results ? d_results : a.dev<spng_result>(rslot);
+    { Timed t(c, SPNG_K_LEX); HIP_TRY(launch_write_idat(a.dev<spng_chunking_desc>(dslot), count, (uint32_t)(most > 4096 ? 4096 : most), dr, c->stream)); }
+    if (h_results) {
+        HIP_TRY(hipMemcpyAsync(h_results, dr, count * sizeof(spng_result), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SPNG_DONE;
+}
+
+int32_t spng_crc32(spng_ctx *c, const void *data, uint64_t n, uint32_t *out)
+{
+    if (!c || (!data && n) || !out) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint64_t piece = 1u << 20;
+    const uint32_t pieces = (uint32_t)((n + piece - 1) / piece);
+    std::vector<uint32_t> part(pieces ? pieces : 1);
+    if (pieces) {
+        DevBuf dd, dp;
+        HIP_TRY(dd.alloc(n)); HIP_TRY(dp.alloc((size_t)pieces * 4));
+        HIP_TRY(hipMemcpyAsync(dd.p, data, n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_crc_partial((const uint8_t *)dd.p, n, piece, (uint32_t *)dp.p, pieces, c->stream));
+        HIP_TRY(hipMemcpyAsync(part.data(), dp.p, (size_t)pieces * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    *out = crc32_fold(part.data(), pieces, n, piece);
+    return SPNG_DONE;
+}
 
 int32_t spng_unpack_batch(spng_ctx *c, const spng_unpack_desc *descs, uint32_t count)
 {

@@ -10,6 +10,10 @@
                                 says the decode must unpack to, plus sha256 of PNG.Image.storage as
                                 produced by the CPU oracle *after* it matched that golden here.
 
+  invalid/*.png                 the reference's negative lexing inputs (Inputs/Invalid, 14 PngSuite "x" files):
+                                bad signatures, the two bad chunk checksums pinned in
+                                PNGIntegrationTests/ErrorHandling.swift:30,42, bad IHDR codes, missing IDAT.
+
 The GPU box has no /root/reference; its tests read only what this script wrote.
 """
 import hashlib, json, shutil, sys
@@ -42,6 +46,10 @@ def main():
                 "storage_sha256": hashlib.sha256(storage.tobytes()).hexdigest(),
             }
     (HERE / "pngsuite.json").write_text(json.dumps(table, indent=1, sort_keys=True) + "\n")
+    inv = HERE / "invalid"
+    inv.mkdir(exist_ok=True)
+    for f in sorted((base / "Inputs" / "Invalid").glob("*.png")):
+        shutil.copyfile(f, inv / f.name)
     print(len(table), "fixtures written")
 
     # encoder goldens: swift-png's own committed level-9 outputs (Tests/Outputs, written by
