@@ -63,9 +63,9 @@ def test_lex_reference_negative_fixtures(gpu):
     f = (ph.GOLDEN / "pngsuite" / "common" / "basn6a08.png").read_bytes()
     assert s.lex_batch([f[:5]])[0][0].status == gpu.E_TRUNCATED_SIGNATURE
     assert s.lex_batch([f[:12]])[0][0].status == gpu.E_TRUNCATED_CHUNK_HEADER
-    assert s.lex_batch([f[:40]])[0][0].status == gpu.E_TRUNCATED_CHUNK_BODY
+    assert s.lex_batch([f[:30]])[0][0].status == gpu.E_TRUNCATED_CHUNK_BODY             # inside IHDR's body
     assert s.lex_batch([f[:-12]])[0][0].status == gpu.E_TRUNCATED_CHUNK_HEADER      # no IEND
-    bad = bytearray(f); bad[8 + 4] = ord("1")                                          # "1HDR": not a chunk type
+    bad = bytearray(f); bad[8 + 6] = ord("d")                                          # "IHdR": reserved bit set
     r = s.lex_batch([bytes(bad)])[0][0]
     assert r.status == gpu.E_CHUNK_TYPE and r.aux[0] == struct.unpack(">I", bytes(bad[12:16]))[0]
 
