@@ -59,6 +59,55 @@ class LZ77:
             return data
 
 
+    class Deflator:
+        """LZ77.Deflator (Sources/LZ77/Deflator/LZ77.Deflator.swift:8-44): init(format:level:exponent:hint:),
+        push(_:last:), pull(), pop().  The device compresses whole streams (the concatenated output does not
+        depend on how the input was pushed), so the bytes become available with the push
+        that carries last: true; pop() then hands out complete chunks of 2 * hint bytes (the reference's chunk is
+        2 * ManagedBuffer.capacity >= 2 * hint bytes, a platform-dependent size) and pull() also the final
+        partial one -- their concatenation is the reference's stream bit for bit.  One known difference, on a
+        reference bug: a row-by-row pushed stream whose last non-final compress() leaves fewer than three bytes
+        queued makes the reference emit a corrupt stored tail (DeflatorBuffers.Stream.swift:45-60); this class
+        emits the correct stream instead."""
+
+        def __init__(self, format=FORMAT_ZLIB, level=9, exponent=15, hint=1 << 12, session=None):
+            from . import load
+            if not 8 <= exponent <= 15:
+                raise ValueError("exponent must be 8 ... 15")
+            self._s = session or load()
+            self._format, self._level, self._exponent = format, level, exponent
+            self._chunk = 2 * max(int(hint), 1)
+            self._in = bytearray()
+            self._out = None
+            self._cursor = 0
+
+        def push(self, data, last=False):
+            if self._out is not None:
+                raise RuntimeError("push after the last block")
+            self._in += bytes(data)
+            if last:
+                self._out = self._s.deflate(bytes(self._in), self._level, self._format, self._exponent)
+                self._in = bytearray()
+
+        def pop(self):
+            """A complete chunk, or None (:40-43)."""
+            if self._out is None or len(self._out) - self._cursor < self._chunk:
+                return None
+            data = self._out[self._cursor:self._cursor + self._chunk]
+            self._cursor += self._chunk
+            return data
+
+        def pull(self):
+            """A complete chunk if there is one, else whatever has been written so far, else None (:31-35)."""
+            data = self.pop()
+            if data is not None:
+                return data
+            if self._out is None or self._cursor >= len(self._out):
+                return None
+            data, self._cursor = self._out[self._cursor:], len(self._out)
+            return data
+
+
 class PNG:
     class Standard:
         common = FORMAT_ZLIB
@@ -90,6 +139,31 @@ class PNG:
             assert pitch % delay == 0
             rows = s.filter(bytes(last[1:]) + bytes(line[1:]), pitch // delay, 2, depth, channels, False)
             return rows[pitch + 1:]
+
+    class ImageEncoder:
+        """PNG.Encoder driven over a whole image (PNG.Encoder.pull, Sources/PNG/Encoding/PNG.Encoder.swift:33-129,
+        as PNG.Image.compress(stream:level:hint:) loops over it, PNG.Image.swift:658-665): every pull returns the
+        payload of the next IDAT chunk, None when the stream is exhausted.  Filter selection and DEFLATE run on the
+        device in one spng_encode_batch call at the first pull."""
+
+        def __init__(self, storage: bytes, size, depth, channels, interlaced=False, standard=FORMAT_ZLIB, level=9,
+                     hint=1 << 15, session=None):
+            from . import load
+            self._s = session or load()
+            self._args = (bytes(storage), size[0], size[1], depth, channels, bool(interlaced))
+            self._standard, self._level = standard, level
+            self._chunk = 2 * max(int(hint), 1)
+            self._out, self._cursor = None, 0
+
+        def pull(self):
+            if self._out is None:
+                rows = self._s.filter(*self._args)
+                self._out = self._s.deflate(rows, self._level, self._standard)
+            if self._cursor >= len(self._out):
+                return None
+            data = self._out[self._cursor:self._cursor + self._chunk]
+            self._cursor += len(data)
+            return data
 
     class Context:
         """PNG.Context (Sources/PNG/Decoding/PNG.Context.swift:56-147), image side reduced to the

@@ -271,6 +271,56 @@ def test_mirror_inflator_and_context(gpu):
         ctx.push(b"\0")                                        # extraneousImageDataCompressedData
 
 
+@pytest.mark.parametrize("level,count", [(4, 5), (4, 5000), (7, 50), (7, 5000), (9, 5), (9, 500), (9, 5000)])
+def test_mirror_deflator_roundtrip(gpu, level, count):
+    """LZ77Tests/Compression.swift:7-27 through the mirrored seam: Deflator(level:exponent: 8, hint: 16), pull until
+    nil, push everything into an Inflator, identity -- plus the stream equals the oracle's at that exponent."""
+    rng = np.random.default_rng(level * 10007 + count)
+    data = rng.integers(0, 256, count, dtype=np.uint8).tobytes()
+    deflator = gpu.LZ77.Deflator(level=level, exponent=8, hint=16)
+    half = count // 2
+    deflator.push(data[:half])
+    assert deflator.pop() is None and deflator.pull() is None       # nothing before the last push (whole-stream device path)
+    deflator.push(data[half:], last=True)
+    chunks = []
+    while True:
+        c = deflator.pull()
+        if c is None:
+            break
+        chunks.append(c)
+    assert all(len(c) == 32 for c in chunks[:-1]) and 0 < len(chunks[-1]) <= 32
+    stream = b"".join(chunks)
+    assert stream == ph.orc_deflate(data, level, 0, 8)
+    inflator = gpu.LZ77.Inflator()
+    status = ()
+    for c in chunks:
+        status = inflator.push(c)
+    assert status is None and inflator.pull() == data
+
+
+def test_mirror_image_encoder(gpu):
+    """PNG.Image.compress's loop over PNG.Encoder.pull (PNG.Image.swift:658-665): the IDAT payloads concatenate
+    to the oracle's PNG.Encoder output at the reference's default level 9, and decode back."""
+    rng = np.random.default_rng(77)
+    w, h = 37, 23
+    storage = ((np.arange(w * h * 4) * 7 + rng.integers(0, 2, w * h * 4)) % 256).astype(np.uint8).tobytes()
+    enc = gpu.PNG.ImageEncoder(storage, (w, h), 8, 4, interlaced=True, level=9, hint=64)
+    payloads = []
+    while True:
+        p = enc.pull()
+        if p is None:
+            break
+        payloads.append(p)
+    assert len(payloads) > 1 and all(len(p) == 128 for p in payloads[:-1])
+    idat = b"".join(payloads)
+    assert idat == ph.orc_deflate(ph.orc_filter(np.frombuffer(storage, np.uint8), w, h, 8, 4, True), 9)
+    ctx = gpu.PNG.Context((w, h), 8, 4, True)
+    for p in payloads:
+        ctx.push(p)
+    ctx.push_ancillary_iend()
+    assert ctx.storage == storage
+
+
 @pytest.mark.parametrize("delay", [1, 2, 3, 4, 6, 8])
 def test_mirror_filter_defilter_roundtrip(gpu, delay):
     """PNGTests/Filtering.swift:9-64: Encoder.filter -> Decoder.defilter identity, and both agree
