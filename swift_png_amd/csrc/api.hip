@@ -479,8 +479,9 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
             memset(&sg, 0, sizeof sg);
             sg.stream = (uint32_t)i; sg.index = (uint32_t)q;
             const uint64_t len = q + 1 < k ? seg_bytes : j.src_len - q * seg_bytes;
-            // chunk records: 272 bytes per 2304 bytes of Huffman data, one partial chunk per block on top
-            sg.log_cap = ((len / 3 + 8192) + 15) & ~(uint64_t)15;
+            // chunk records: 272 bytes per 2304 bytes of Huffman data, one partial chunk and a 352-byte block
+            // record per block on top (swift-png's own level-6 streams: a block every ~3 KB)
+            sg.log_cap = ((len / 2 + 16384) + 15) & ~(uint64_t)15;
             sg.log_off = log; log += sg.log_cap;
             sg.start_bit = ~0ull;
             p.segs.push_back(sg);

@@ -56,8 +56,11 @@ typedef uint8_t __attribute__((address_space(1))) gbyte;
 typedef PU128 __attribute__((address_space(1))) gPU128;
 
 #ifndef SPNG_LBITS
-#define SPNG_LBITS 10
+#define SPNG_LBITS 9
 #endif
+// (a 2^9-entry lit/len LUT: 2 KB less LDS per wave than 2^10 buys three more waves per CU and halves the
+//  per-block table fill, which pays for the extra long-code lookups: -2 % on zlib-made streams, -14 % on
+//  swift-png's own small blocks; profiles/r02_inflate_tuning.md)
 static constexpr int LBITS = SPNG_LBITS, DBITS = 8, MBITS = 7;
 #ifndef SPNG_SDW
 #define SPNG_SDW 9
@@ -65,8 +68,9 @@ static constexpr int LBITS = SPNG_LBITS, DBITS = 8, MBITS = 7;
 static constexpr int SDW = SPNG_SDW;                // dwords per lane subsequence (odd: conflict-free LDS stride)
 static constexpr uint32_t SB = SDW * 32;            // bits per subsequence
 static constexpr uint32_t CHB = 64 * SB;            // bits per chunk
-static constexpr int STAGE_DW = ((CHB / 8 + 64 + 1023) / 1024) * 256;   // staged compressed data, whole KiB
+static constexpr int STAGE_DW = ((CHB / 8 + 64 + 255) / 256) * 64 < 264 ? 264 : ((CHB / 8 + 64 + 255) / 256) * 64;   // staged compressed data (>= a header window)
 static constexpr uint32_t REC_DW = 68;              // chunk record: 4 header dwords + one per lane
+static constexpr uint32_t BREC_DW = 88;             // block record: 8 header dwords + 320 bytes of code lengths
 static constexpr uint64_t NONE = ~0ull;
 static constexpr uint32_t T_MATCH = 0x80000000u;    // token: T_MATCH | (distance - 1) << 16 | run;  else the literal byte
 
@@ -78,10 +82,12 @@ struct PLds {
     uint32_t ext_dist[32];
     Tree     tlit, tdist;
     uint32_t hist[16], run[16];
-    uint8_t  lens[464];
+    union {
+        uint8_t  lens[512];            // a header's code lengths (<= 318 + run-length overshoot)
+        struct { uint32_t flag[64], mpos[64]; };   // count_chunk: lanes on the true chain, where it enters their chains
+    };
     uint32_t stage[STAGE_DW];          // compressed data around the current position
     uint32_t vmap[SDW * 64];           // count: visited-token-start bitmaps; find: the search window
-    uint32_t flag[64], mpos[64];       // count: lanes on the true chain, where it enters their chains
 };
 
 // canonical codes longer than the LUT index: left-aligned (15-bit) upper limits of every length, kept
@@ -89,45 +95,38 @@ struct PLds {
 struct Lim { uint32_t lit[15 - LBITS], dist[15 - DBITS]; };
 
 // ---- staging ------------------------------------------------------------------------------------
-// copies `kib` x 1 KiB of the stream starting at byte `from` into dst; bytes past the end read as zero
-__device__ __forceinline__ void stage_bytes(uint32_t *dst, const gbyte *src, uint64_t n, uint64_t from, int kib, int lane)
+// copies `dwords` dwords (a multiple of 4) of the stream starting at byte `from` into dst; bytes past the end read as zero
+__device__ __forceinline__ u32x4 stage_load16(const gbyte *src, uint64_t n, uint64_t off)
 {
-    for (int k = 0; k < kib; ++k) {
-        const uint64_t off = from + (uint64_t)k * 1024 + (uint64_t)lane * 16;
-        u32x4 v = {0, 0, 0, 0};
-        if (off + 16 <= n) v = ((const gPU128 *)(src + off))->v;
-        else if (off < n) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (int b = 0; b < 16; ++b) if (off + b < n) w[b >> 2] |= (uint32_t)src[off + b] << (8 * (b & 3));
-            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-        }
-        *(u32x4 *)(dst + k * 256 + lane * 4) = v;
+    u32x4 v = {0, 0, 0, 0};
+    if (off + 16 <= n) v = ((const gPU128 *)(src + off))->v;
+    else if (off < n) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int b = 0; b < 16; ++b) if (off + b < n) w[b >> 2] |= (uint32_t)src[off + b] << (8 * (b & 3));
+        v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
     }
+    return v;
+}
+__device__ __forceinline__ void stage_bytes(uint32_t *dst, const gbyte *src, uint64_t n, uint64_t from, int dwords, int lane)
+{
+    for (int k = 0; k * 256 < dwords; ++k)
+        if (k * 256 + lane * 4 < dwords) *(u32x4 *)(dst + k * 256 + lane * 4) = stage_load16(src, n, from + (uint64_t)k * 1024 + (uint64_t)lane * 16);
     WSYNC();
 }
 
 // The same in two halves, so that a chunk's bytes travel while the chunk before it is decoded.
-struct StageRegs { u32x4 v[4]; };
-__device__ __forceinline__ void stage_fetch(StageRegs &r, const gbyte *src, uint64_t n, uint64_t from, int kib, int lane)
+struct StageRegs { u32x4 v[(STAGE_DW + 255) / 256]; };
+__device__ __forceinline__ void stage_fetch(StageRegs &r, const gbyte *src, uint64_t n, uint64_t from, int lane)
 {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k >= kib) break;
-        const uint64_t off = from + (uint64_t)k * 1024 + (uint64_t)lane * 16;
-        u32x4 v = {0, 0, 0, 0};
-        if (off + 16 <= n) v = ((const gPU128 *)(src + off))->v;
-        else if (off < n) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (int b = 0; b < 16; ++b) if (off + b < n) w[b >> 2] |= (uint32_t)src[off + b] << (8 * (b & 3));
-            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-        }
-        r.v[k] = v;
-    }
+    for (int k = 0; k < (STAGE_DW + 255) / 256; ++k)
+        if (k * 256 + lane * 4 < STAGE_DW) r.v[k] = stage_load16(src, n, from + (uint64_t)k * 1024 + (uint64_t)lane * 16);
 }
-__device__ __forceinline__ void stage_put(uint32_t *dst, const StageRegs &r, int kib, int lane)
+__device__ __forceinline__ void stage_put(uint32_t *dst, const StageRegs &r, int lane)
 {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (k < kib) *(u32x4 *)(dst + k * 256 + lane * 4) = r.v[k];
+    for (int k = 0; k < (STAGE_DW + 255) / 256; ++k)
+        if (k * 256 + lane * 4 < STAGE_DW) *(u32x4 *)(dst + k * 256 + lane * 4) = r.v[k];
     WSYNC();
 }
 
@@ -156,6 +155,7 @@ struct Hdr {
     uint32_t type, bfinal;
     uint64_t payload;                  // first bit of the compressed data / first BYTE of stored data * 8
     uint32_t stored;                   // stored blocks: LEN
+    uint32_t literals, distances;      // dynamic blocks: HLIT + 257, HDIST + 1 (their code lengths are in s.lens)
 };
 
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total, int lane)
@@ -188,8 +188,8 @@ __device__ __forceinline__ uint32_t cl_symbol(const PLds &s, uint32_t q)
 
 __device__ __attribute__((always_inline)) bool decode_lengths(PLds &s, uint32_t &rel, uint32_t rel_end, uint32_t want, int lane)
 {
-    uint32_t *vm = s.stage + 512, *pf = s.stage + 576, *mp = s.stage + 640;   // (the header occupies the first KiB)
-    for (int i = lane; i < 116; i += 64) ((uint32_t *)s.lens)[i] = 0;
+    uint32_t *vm = s.ext_lit, *pf = s.ext_lit + 64, *mp = s.ext_lit + 128;   // (free until the lit/len table is built)
+    for (int i = lane; i < 128; i += 64) ((uint32_t *)s.lens)[i] = 0;
     uint32_t have = 0, w0 = rel;
     uint32_t last_in = 0; bool last_ok = false;
     for (int window = 0; window < 3; ++window) {
@@ -299,12 +299,12 @@ __device__ __attribute__((always_inline)) bool parse_header(PLds &s, const gbyte
     if (pos + 3 > total) return false;
     const uint64_t wbyte = (pos >> 5) << 2;
     HP(6);
-    stage_bytes(s.stage, src, n, wbyte, 1, lane);
+    stage_bytes(s.stage, src, n, wbyte, 256, lane);
     HP(0);
     uint32_t rel = (uint32_t)(pos - wbyte * 8);
     const uint32_t first = upeek32(s.stage, rel);
     h.bfinal = first & 1; h.type = (first >> 1) & 3;
-    h.stored = 0;
+    h.stored = 0; h.literals = 0; h.distances = 0;
     if (h.type == 0) {
         const uint64_t boundary = (pos + 3 + 7) & ~(uint64_t)7;
         if (boundary + 32 > total) return false;
@@ -354,6 +354,7 @@ __device__ __attribute__((always_inline)) bool parse_header(PLds &s, const gbyte
     HP(4);
     if (!okl || !okd) return false;
     h.payload = wbyte * 8 + rel;
+    h.literals = literals; h.distances = distances;
     return true;
 }
 
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(64) void pinf_find_kernel(const PStream *__restrict
         const uint64_t hi_bit = lo_bit + sb < total ? lo_bit + sb : total;
         uint32_t *win = s.vmap;                                 // 2 KiB + slack
         for (uint64_t wb = lo_bit; wb < hi_bit && found == NONE; wb += 16384) {
-            stage_bytes(win, src, n, wb >> 3, 2, lane);
+            stage_bytes(win, src, n, wb >> 3, 512, lane);
             {   // the 64 bytes behind the window (a header straddling its end)
                 const uint64_t off = (wb >> 3) + 2048 + (uint64_t)lane * 4;
                 uint32_t v = 0;
@@ -513,8 +514,8 @@ __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, S
 {
     CP(0);
     const uint64_t sbyte = (cb >> 5) << 2;
-    stage_put(s.stage, sr, STAGE_DW / 256, lane);               // (fetched while the chunk before was decoded)
-    stage_fetch(sr, src, n, ((cb + CHB) >> 5) << 2, STAGE_DW / 256, lane);
+    stage_put(s.stage, sr, lane);                               // (fetched while the chunk before was decoded)
+    stage_fetch(sr, src, n, ((cb + CHB) >> 5) << 2, lane);
     const uint64_t sbit = sbyte * 8;
     const uint64_t left = n * 8 - sbit;
     const uint32_t lim = left > 0xffffffffull ? 0xffffffffu : (uint32_t)left;
@@ -634,6 +635,22 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
         CP(6);
         CPN(12, 1);
         if (!hok) break;
+        // the block record: what emit needs to set the block up again without parsing its header (the code
+        // lengths; the payload position; stored length)
+        if (cur + BREC_DW > log_cap) break;
+        {
+            uint32_t *br = log + cur;
+            if (lane < 8) {
+                const uint32_t hdr[8] = {h.type | h.bfinal << 8, h.literals | h.distances << 16, (uint32_t)h.payload,
+                                         (uint32_t)(h.payload >> 32), h.stored, 0, 0, 0};
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v = lane == k ? hdr[k] : v;
+                br[lane] = v;
+            }
+            if (h.type == 2) for (int i = lane; i < 80; i += 64) br[8 + i] = ((const uint32_t *)s.lens)[i];
+            cur += BREC_DW;
+        }
         if (h.type == 0) {
             ntok += h.stored;
             pos = h.payload + (uint64_t)h.stored * 8;
@@ -643,7 +660,7 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
             Lim lc;
             load_limits(s, lc);
             StageRegs sr;
-            stage_fetch(sr, src, n, (cb >> 5) << 2, STAGE_DW / 256, lane);
+            stage_fetch(sr, src, n, (cb >> 5) << 2, lane);
             for (;;) {
                 if (cur + REC_DW > log_cap) { state = 2; break; }
                 uint64_t next; uint32_t nt;
@@ -688,8 +705,26 @@ __global__ __launch_bounds__(64) void pinf_emit_kernel(const PStream *__restrict
     const bool final_seg = UNI(sg.status) == PSEG_FINAL;
     for (;;) {
         if (!final_seg && pos >= stop) break;
+        // the block as count recorded it
         Hdr h;
-        if (!UB(parse_header(s, src, n, pos, h, lane))) break;     // (cannot happen: count parsed the same bits)
+        {
+            const uint32_t *br = log + cur;
+            cur += BREC_DW;
+            const uint32_t tb = UNI(br[0]), ld = UNI(br[1]);
+            h.type = tb & 0xff; h.bfinal = tb >> 8;
+            h.literals = ld & 0xffff; h.distances = ld >> 16;
+            h.payload = (uint64_t)UNI(br[3]) << 32 | UNI(br[2]);
+            h.stored = UNI(br[4]);
+            if (h.type == 2) {
+                for (int i = lane; i < 80; i += 64) ((uint32_t *)s.lens)[i] = br[8 + i];
+                WSYNC();
+                build<1>(s.hist, s.run, s.lens + h.literals, (int)h.distances, s.dist, DBITS, (uint16_t *)nullptr, &s.tdist, true, lane, s.ext_dist);
+                build<0>(s.hist, s.run, s.lens, (int)h.literals, s.lit, LBITS, (uint16_t *)nullptr, &s.tlit, false, lane, s.ext_lit);
+            } else if (h.type == 1) {
+                Hdr dummy;
+                if (!UB(parse_header(s, src, n, pos, dummy, lane))) break;   // (fixed tables; cannot fail: count parsed the same bits)
+            }
+        }
         if (h.type == 0) {
             const uint64_t from = h.payload / 8;
             for (uint32_t k = 0; k < h.stored; k += 64)
@@ -701,15 +736,15 @@ __global__ __launch_bounds__(64) void pinf_emit_kernel(const PStream *__restrict
             Lim lc;
             load_limits(s, lc);
             StageRegs sr;
-            stage_fetch(sr, src, n, (cb >> 5) << 2, STAGE_DW / 256, lane);
+            stage_fetch(sr, src, n, (cb >> 5) << 2, lane);
             for (;;) {
                 const uint32_t *rec = log + cur;
                 cur += REC_DW;
                 const uint32_t tot = UNI(rec[0]), last = UNI(rec[1]);
                 const uint64_t next = (uint64_t)UNI(rec[3]) << 32 | UNI(rec[2]);
                 const uint32_t mine = rec[4 + lane];
-                stage_put(s.stage, sr, STAGE_DW / 256, lane);
-                if (!last) stage_fetch(sr, src, n, ((cb + CHB) >> 5) << 2, STAGE_DW / 256, lane);
+                stage_put(s.stage, sr, lane);
+                if (!last) stage_fetch(sr, src, n, ((cb + CHB) >> 5) << 2, lane);
                 uint32_t t2;
                 const uint32_t off = wave_excl_scan(mine >> 16, t2, lane);
                 uint32_t q = mine & 0xffff;
