@@ -1,40 +1,49 @@
-"""Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/r01_pmc_traffic.json.
+"""Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one bench.py step into
+profiles/r02_pmc_traffic.json (the file bench.py reads `roofline.traffic` / `kernels.*.traffic` from).
 
-    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <images> <out.json>
+    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <kind> <images> <unique> <out.json>
 
-Corrections as MI355X_MICROARCH.md prescribes for gfx950: both counters are in KiB; FETCH_SIZE reports
-half of the bytes of wide (16 B/lane) coalesced reads, so corrected fetch = 2 x raw."""
-import csv, glob, json, sys
+The passes run `python bench.py --steps 1 --warmup 0 --no-swiftpng --no-cpu-baseline [--streams <kind>]`, i.e. the very
+workload of the headline line, one decode step; every launch of a kernel inside that step is summed ("per launch" =
+per step; the parallel inflate stages launch once per token-buffer pass).
+Corrections as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: both counters are in KiB; FETCH_SIZE reports
+half of the bytes of wide (16 B/lane) coalesced reads, so corrected fetch = 2 x raw for the kernels whose reads are
+16 B/lane streams (unfilter, count / emit staging, the serial kernel); the resolve kernel reads its tokens as dwords
+(uncalibrated width): its raw and doubled figures are both given and the doubled one is used, as an upper bound."""
+import csv, glob, json, os, sys
+
+NAMES = {"pinf_find_kernel": "pinf_find", "pinf_count_kernel": "pinf_count", "pinf_emit_kernel": "pinf_emit",
+         "pinf_resolve_kernel": "pinf_resolve", "inflate_kernel": "inflate", "unfilter_kernel": "unfilter"}
+
 
 def collect(d, counter):
     out = {}
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") != counter: continue
-            k = row["Kernel_Name"]
-            key = "inflate" if "inflate_kernel" in k else "unfilter" if "unfilter_kernel" in k else None
-            if key is None: continue
-            e = out.setdefault(key, {"value": 0.0, "VGPR_Count": row.get("VGPR_Count") or row.get("Arch_VGPR_Count"), "LDS_Block_Size": row.get("LDS_Block_Size")})
+            if row.get("Counter_Name") != counter:
+                continue
+            key = next((v for k, v in NAMES.items() if k in row["Kernel_Name"]), None)
+            if key is None:
+                continue
+            e = out.setdefault(key, {"value": 0.0, "launches": 0})
             e["value"] += float(row["Counter_Value"])
+            e["launches"] += 1
     return out
 
-fetch, write, images, dst = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE"), int(sys.argv[3]), sys.argv[4]
-W = H = 4096
-U, S = H * (W * 4 + 1), W * H * 4
-doc = {"note": "rocprofv3 --kernel-trace --pmc <counter> -- python bench.py --steps 1 --warmup 0 --images %d --unique 8 "
-               "--no-cpu-baseline; one counter per pass. Units KiB. Per MI355X_MICROARCH.md FETCH_SIZE reports 1/2 of the "
-               "bytes of wide (16 B/lane) coalesced reads on gfx950: corrected = 2 x raw; WRITE_SIZE is exact "
-               "(the inflate kernel's aligned 16 B/lane flushes write images x %d B)." % (images, U),
-       "images": images, "kernels": {}}
-for k in ("inflate", "unfilter"):
+
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+kind, images, unique, dst = sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+doc = json.load(open(dst)) if os.path.exists(dst) else {
+    "note": "rocprofv3 --kernel-trace --pmc <counter> -- python bench.py --steps 1 --warmup 0 --no-swiftpng --no-cpu-baseline "
+            "[--streams <kind>]; one counter per pass; units KiB; FETCH_SIZE x 2 (MI355X_MICROARCH.md, gfx950); summed over "
+            "the launches of one decode step", "configs": {}}
+cfg = {"images": images, "unique": unique, "kernels": {}}
+for k in NAMES.values():
     f, w = fetch.get(k, {}).get("value"), write.get(k, {}).get("value")
-    if f is None or w is None: continue
-    total = int(2 * f * 1024 + w * 1024)
-    e = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "VGPR_Count": fetch[k]["VGPR_Count"], "LDS_Block_Size": fetch[k]["LDS_Block_Size"],
-         "hbm_bytes_corrected": total, "hbm_bytes_per_image": total // images}
-    if k == "unfilter":
-        e["algorithmic_bytes"] = images * (U + S)
-        e["traffic_over_algorithmic"] = round(total / (images * (U + S)), 3)
-    doc["kernels"][k] = e
+    if f is None or w is None:
+        continue
+    cfg["kernels"][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "launches": fetch[k]["launches"],
+                         "hbm_bytes_raw": int((f + w) * 1024), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+doc["configs"][kind] = cfg
 json.dump(doc, open(dst, "w"), indent=1)
-print(json.dumps(doc["kernels"], indent=1))
+print(json.dumps(cfg, indent=1))
