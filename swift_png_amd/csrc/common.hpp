@@ -100,6 +100,7 @@ struct PSeg {
     uint64_t tok_base;                     // scan: first token, relative to the stream's
     int32_t  status;                       // count: PSEG_*
     uint32_t used;                         // scan: part of the chain
+    uint32_t next, pad;                    // count: index of the segment that starts where this one stopped
 };
 
 struct DeflateJob {

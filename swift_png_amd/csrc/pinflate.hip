@@ -84,7 +84,10 @@ struct PLds {
     uint32_t hist[16], run[16];
     union {
         uint8_t  lens[512];            // a header's code lengths (<= 318 + run-length overshoot)
-        struct { uint32_t flag[64], mpos[64]; };   // count_chunk: lanes on the true chain, where it enters their chains
+        struct {                       // count_chunk:
+            uint16_t flag[64], mpos[64];   //   lanes on the true chain; where it merges into their chains
+            uint32_t ent[64];              //   where it enters each subsequence | tokens it decodes there before merging << 16
+        };
     };
     uint32_t stage[STAGE_DW];          // compressed data around the current position
     uint32_t vmap[SDW * 64];           // count: visited-token-start bitmaps; find: the search window
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(64) void pinf_find_kernel(const PStream *__restrict
             }
         }
     }
-    if (lane == 0) { sg.start_bit = found; sg.end_bit = 0; sg.ntok = 0; sg.tok_base = 0; sg.status = PSEG_FAIL; sg.used = 0; }
+    if (lane == 0) { sg.start_bit = found; sg.end_bit = 0; sg.ntok = 0; sg.tok_base = 0; sg.status = PSEG_FAIL; sg.used = 0; sg.next = 0; }
 }
 
 // ---- count (pass 1) and emit (pass 2) ----------------------------------------------------------------
@@ -496,8 +499,13 @@ __global__ __launch_bounds__(64) void pinf_find_kernel(const PStream *__restrict
 //             lane a link: (lane it merged into, position).
 //   path      lane 0 starts on a true token boundary, so the true chain is lane 0's chain up to its
 //             link, then that lane's chain up to its link, ...: the lanes reachable from lane 0
-//             (pointer doubling over the links).  A lane on the path owns the tokens from the position
-//             at which the path entered its chain up to its own link.
+//             (pointer doubling over the links).
+//   record    per subsequence: the bit at which the true chain enters it and the number of tokens that
+//             start in it.  A lane on the path knows both for every subsequence its chain crossed in
+//             round 1 (it notes position and token count at each crossing; tokens are shorter than a
+//             subsequence, so none is skipped) and for the prefix of the one it merged into; the rest
+//             of that one is the owner's marks behind the merge point.  emit then gives every lane
+//             exactly its own subsequence's tokens: no lane replays a long unmerged chain alone.
 #ifdef SPNG_COUNT_PROF
 #define CP_ARG , uint64_t *cp
 #define CP_PASS , cp
@@ -524,6 +532,7 @@ __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, S
 #pragma unroll
     for (int w = 0; w < SDW; ++w) s.vmap[w * 64 + lane] = 0;
     s.flag[lane] = 0;
+    s.ent[lane] = 0;
     WSYNC();
     uint32_t dummy;
     const uint32_t q0 = lane == 0 ? (uint32_t)(entry - sbit) : sub0;
@@ -540,11 +549,17 @@ __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, S
     }
     WSYNC();
     CP(2);
-    uint32_t link = 64, cnt2 = 0;
+    uint32_t link = 64, cnt2 = 0, nh = 0, lastj = (uint32_t)lane;
+    uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;                    // crossings: position | tokens before it << 16
     if (st == 0) {
         while (q < cend) {
             CPN(9, 1);
             const uint32_t j = (q - off0) / SB, b = q - off0 - j * SB;
+            if (j != lastj) {
+                const uint32_t v = q | cnt2 << 16;
+                x0 = nh == 0 ? v : x0; x1 = nh == 1 ? v : x1; x2 = nh == 2 ? v : x2; x3 = nh == 3 ? v : x3;
+                nh += 1; lastj = j;
+            }
             if ((s.vmap[(b >> 5) * 64 + j] >> (b & 31)) & 1) { link = j; break; }
             const uint32_t t = decode_at<false>(s, lim_codes, q, lim, dummy);
             const uint32_t k = t >> 8;
@@ -565,12 +580,26 @@ __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, S
         const uint32_t jj = (uint32_t)__shfl((int)jump, (int)(jump & 63), 64);
         jump = jump < 64 ? jj : 64;
     }
-    if (onpath && link < 64) s.mpos[link] = q;
-    WSYNC();
-    const uint32_t m = lane == 0 ? q0 : s.mpos[lane];           // where the true chain enters mine
-    uint32_t mine = 0;
     if (onpath) {
-        mine = cnt2;
+        // the subsequences my chain crossed (beyond the fourth crossing they all count for the fourth: rare)
+        const uint32_t nrec = nh < 4 ? nh : 4;
+        const uint32_t xs[5] = {x0, x1, x2, x3, 0};
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            if ((uint32_t)h < nrec) {
+                const uint32_t upto = (uint32_t)h + 1 < nrec ? xs[h + 1] >> 16 : cnt2;
+                s.ent[lane + 1 + h] = (xs[h] & 0xffff) | (upto - (xs[h] >> 16)) << 16;
+            }
+        if (link < 64) {
+            s.mpos[link] = (uint16_t)q;
+            if (link != (uint32_t)lane + nrec) s.ent[link] = q;  // (merged behind the recorded crossings: no prefix)
+        }
+    }
+    WSYNC();
+    const uint32_t e = lane == 0 ? q0 : s.ent[lane];
+    const uint32_t m = lane == 0 ? q0 : s.mpos[lane];           // where the true chain merges into mine
+    uint32_t mine = e >> 16;
+    if (onpath) {
         const uint32_t mb = m - sub0;                            // 0 .. SB - 1
 #pragma unroll
         for (int w = 0; w < SDW; ++w) {
@@ -588,7 +617,7 @@ __device__ __forceinline__ uint32_t count_chunk(PLds &s, const Lim &lim_codes, S
     const uint32_t qe = (uint32_t)__shfl((int)q, el, 64), ste = endm ? (uint32_t)__shfl((int)st, el, 64) : 2u;
     next = sbit + qe;
     ntok = tot;
-    rec[4 + lane] = (onpath ? m : 0u) | mine << 16;
+    rec[4 + lane] = (e & 0xffff) | mine << 16;
     if (lane == 0) { rec[0] = tot; rec[1] = ste == 1 ? 1u : 0u; rec[2] = (uint32_t)next; rec[3] = (uint32_t)(next >> 32); }
     CP(4);
     CPN(10, 1);
@@ -607,12 +636,20 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
     if (start == NONE) return;
     const gbyte *src = (const gbyte *)uni64((uint64_t)st.src);
     const uint64_t n = uni64(st.src_len);
-    // this segment ends where the next one that was found begins
+    // this segment ends where a later one begins: at the first found start it stops ON.  One it runs past
+    // was no block start (a look-alike inside stored data or inside a block); whatever its wave decodes
+    // from there stays off the chain (scan).
     uint64_t limit = NONE;
-    for (uint32_t k = UNI(sg.index) + 1; k < UNI(st.seg_count); ++k) {
-        const uint64_t v = uni64(segs[UNI(st.seg_first) + k].start_bit);
-        if (v != NONE) { limit = v; break; }
-    }
+    uint32_t nk = UNI(sg.index) + 1;
+    const uint32_t seg_first = UNI(st.seg_first), seg_count = UNI(st.seg_count);
+    auto advance = [&](uint64_t from) {
+        limit = NONE;
+        for (; nk < seg_count; ++nk) {
+            const uint64_t v = uni64(segs[seg_first + nk].start_bit);
+            if (v != NONE && v >= from) { limit = v; break; }
+        }
+    };
+    advance(start + 1);
     uint32_t *log = (uint32_t *)(logs + uni64(sg.log_off));
     const uint32_t log_cap = UNI((uint32_t)(uni64(sg.log_cap) / 4));
     uint32_t cur = 0;
@@ -623,7 +660,11 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
     cp[15] = __builtin_readcyclecounter();
 #endif
     for (;;) {
-        if (pos >= limit) { if (pos == limit) status = PSEG_CONT; break; }
+        if (pos >= limit) {
+            if (pos == limit) { status = PSEG_CONT; break; }
+            nk += 1; advance(pos);
+            continue;
+        }
         Hdr h;
         CP(5);
 #ifdef SPNG_COUNT_PROF
@@ -676,7 +717,7 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
         }
         if (h.bfinal) { status = PSEG_FINAL; break; }
     }
-    if (lane == 0) { sg.end_bit = pos; sg.ntok = ntok; sg.status = status; }
+    if (lane == 0) { sg.end_bit = pos; sg.ntok = ntok; sg.status = status; sg.next = nk; }
 #ifdef SPNG_COUNT_PROF
     if (blockIdx.x == 1 && lane == 0)
         printf("count: %lu blocks %lu chunks %lu tokens; steps r0 %lu p2 %lu; cycles: stage %lu setup %lu round0 %lu phase2 %lu path+rec %lu header %lu other %lu\n",
@@ -765,56 +806,31 @@ __global__ __launch_bounds__(64) void pinf_emit_kernel(const PStream *__restrict
 }
 
 // ---- scan: the segment chain of every stream, token offsets, passes ------------------------------------
-// one wave per stream
+// One wave per stream walks the chain: segment 0, then the segment count says it stopped at, ... up to the
+// first one that saw the final block.  A found start that no chain member stops at (a bit pattern inside
+// stored data or in the middle of a block that happens to parse as a header) is simply not on the chain.
 __global__ __launch_bounds__(64) void pinf_scan_kernel(PStream *__restrict__ streams, PSeg *__restrict__ segs)
 {
     const int lane = threadIdx.x;
     PStream &st = streams[blockIdx.x];
     const uint32_t first = UNI(st.seg_first), count = UNI(st.seg_count);
-    bool ok = true, done = false;
-    uint64_t carry_end = 0, tok = 0, end_bit = 0;
-    bool have_prev = false;
-    for (uint32_t base = 0; base < count && ok && !done; base += 64) {
-        const uint32_t i = base + lane;
-        const bool in = i < count;
-        PSeg *sg = segs + first + (in ? i : 0);
-        const uint64_t start = in ? sg->start_bit : NONE;
-        const uint64_t end = in ? sg->end_bit : 0;
-        const int32_t status = in ? sg->status : PSEG_FAIL;
-        const uint64_t nt = in ? sg->ntok : 0;
-        const bool present = start != NONE;
-        const unsigned long long pm = __ballot(present);
-        // my predecessor among the present segments
-        const unsigned long long below = pm & ((1ull << lane) - 1);
-        const int pl = below ? 63 - __clzll((long long)below) : -1;
-        const uint64_t pend_lo = (uint32_t)__shfl((int)(uint32_t)end, pl < 0 ? 0 : pl, 64);
-        const uint64_t pend_hi = (uint32_t)__shfl((int)(uint32_t)(end >> 32), pl < 0 ? 0 : pl, 64);
-        const uint64_t pend = pl < 0 ? carry_end : (pend_hi << 32 | pend_lo);
-        const bool has_prev = pl >= 0 || have_prev;
-        bool good = !present || (status != PSEG_FAIL && (has_prev ? pend == start : (base + lane) == 0));
-        // the first FINAL segment ends the stream; what lies behind it does not count
-        const unsigned long long fm = __ballot(present && status == PSEG_FINAL);
-        const unsigned long long bm = __ballot(present && !good);
-        const int fl = fm ? __ffsll((long long)fm) - 1 : 64;
-        const int bl = bm ? __ffsll((long long)bm) - 1 : 64;
-        if (bl <= fl && bl < 64) { ok = false; break; }
-        const bool used = present && lane <= fl;
-        uint32_t t2;
-        // token offsets (64-bit: two 32-bit scans would do, but segment counts are < 2^32 anyway)
-        const uint32_t mine = used ? (uint32_t)nt : 0u;
-        const uint32_t off = wave_excl_scan(mine, t2, lane);
-        if (in) { sg->tok_base = tok + off; sg->used = used ? 1u : 0u; }
-        tok += t2;
-        if (fl < 64) { done = true; end_bit = (uint64_t)(uint32_t)__shfl((int)(uint32_t)(end >> 32), fl, 64) << 32 |
-                                             (uint32_t)__shfl((int)(uint32_t)end, fl, 64); }
-        if (pm) {
-            const int ll = 63 - __clzll((long long)pm);
-            carry_end = (uint64_t)(uint32_t)__shfl((int)(uint32_t)(end >> 32), ll, 64) << 32 | (uint32_t)__shfl((int)(uint32_t)end, ll, 64);
-            have_prev = true;
-        }
+    bool ok = false;
+    uint64_t tok = 0, end_bit = 0;
+    uint32_t k = 0;
+    for (uint32_t hops = 0; hops < count; ++hops) {
+        PSeg *sg = segs + first + k;
+        const uint64_t start = uni64(sg->start_bit), end = uni64(sg->end_bit);
+        const int32_t status = (int32_t)UNI(sg->status);
+        if (start == NONE || status == PSEG_FAIL) break;
+        if (lane == 0) { sg->tok_base = tok; sg->used = 1; }
+        tok += uni64(sg->ntok);
+        if (status == PSEG_FINAL) { ok = true; end_bit = end; break; }
+        const uint32_t nx = UNI(sg->next);
+        if (nx <= k || nx >= count) break;
+        if (uni64(segs[first + nx].start_bit) != end) break;
+        k = nx;
     }
-    // segments of later batches behind the final one are unused
-    if (lane == 0) { st.ok = (ok && done) ? 1 : 0; st.ntok = tok; st.end_bit = end_bit; st.pass = 0; st.tok_base = 0; }
+    if (lane == 0) { st.ok = ok ? 1 : 0; st.ntok = tok; st.end_bit = end_bit; st.pass = 0; st.tok_base = 0; }
 }
 
 // single wave: global token offsets and passes.  capacity = tokens the token buffer holds.

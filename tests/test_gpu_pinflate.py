@@ -1,0 +1,109 @@
+"""The intra-stream parallel inflate pipeline (csrc/pinflate.hip) on the kinds of stream it must take itself:
+output bit-exact AND produced by the pipeline (spng_result.reserved == 1), not by the serial kernel it falls
+back to -- a silent fallback would keep every parity test green and lose the speed."""
+import zlib
+
+import numpy as np
+import pytest
+
+import swift_png_amd as spng
+
+pytestmark = pytest.mark.gpu
+
+
+def scanlines(seed, n):
+    """filtered-PNG-like bytes: small deltas, runs, the occasional noisy row"""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(-3, 4, n).astype(np.int16)
+    a[rng.random(n) < 0.6] = 0
+    rows = a.astype(np.uint8).reshape(-1, 4096)
+    rows[::37] = rng.integers(0, 256, (len(rows[::37]), 4096), dtype=np.uint8)
+    rows[::4, 0] = 1
+    return rows.tobytes()
+
+
+def make(kind, n):
+    rng = np.random.default_rng(99)
+    if kind.startswith("zlib"):
+        return zlib.compress(scanlines(1, n), int(kind[4:]))
+    if kind == "noise":                       # incompressible: zlib stores it
+        return zlib.compress(rng.integers(0, 256, n, dtype=np.uint8).tobytes(), 6)
+    if kind == "huffonly":                    # the same bytes Huffman-coded without matches: ~8-bit codes everywhere
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_HUFFMAN_ONLY)
+        return co.compress(rng.integers(0, 256, n, dtype=np.uint8).tobytes()) + co.flush()
+    if kind == "text16":                      # 16 symbols, 4-bit codes
+        return zlib.compress(rng.integers(0, 16, n, dtype=np.uint8).tobytes(), 6)
+    if kind == "zeros":                       # maximal runs, distance 1
+        return zlib.compress(bytes(n), 6)
+    if kind == "period4":                     # runs longer than their distance (RGBA of one colour)
+        return zlib.compress(bytes([1, 2, 3, 255]) * (n // 4), 6)
+    if kind == "fixed":
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+        return co.compress(scanlines(2, n)) + co.flush()
+    if kind == "flushes":                     # many short blocks, empty stored blocks between them
+        co = zlib.compressobj(6)
+        d = scanlines(3, n)
+        out = b""
+        for i in range(0, n, 50000):
+            out += co.compress(d[i:i + 50000]) + co.flush(zlib.Z_FULL_FLUSH if (i // 50000) % 3 else zlib.Z_SYNC_FLUSH)
+        return out + co.flush()
+    if kind == "stored_mix":                  # stored blocks between Huffman blocks
+        d = scanlines(4, n)
+        co = zlib.compressobj(0)
+        head = co.compress(d[:n // 3]) + co.flush(zlib.Z_FULL_FLUSH)      # zlib header + stored blocks
+        c6 = zlib.compressobj(6, zlib.DEFLATED, -15)
+        tail = c6.compress(d[n // 3:]) + c6.flush()
+        return head + tail + zlib.adler32(d).to_bytes(4, "big")
+    raise KeyError(kind)
+
+
+KINDS = ["zlib1", "zlib6", "zlib9", "noise", "huffonly", "text16", "zeros", "period4", "fixed", "flushes", "stored_mix"]
+
+
+@pytest.mark.parametrize("segment", [0, 16384])
+@pytest.mark.parametrize("kind", KINDS)
+def test_pipeline_takes_regular_streams(gpu, kind, segment):
+    s = gpu.load()
+    n = 3 << 20
+    z = make(kind, n)
+    want = zlib.decompress(z)
+    s.configure(spng.CFG_SEGMENT_BYTES, segment)          # 0: the default (>= 256 KiB); 16 KiB: ~100 segments
+    try:
+        outs, res = s.inflate_batch([s.to_device(z)], [len(want) + 64])
+    finally:
+        s.configure(spng.CFG_SEGMENT_BYTES, 0)
+    assert res[0].status == 0 and res[0].written == len(want) and res[0].consumed == len(z)
+    assert bytes(outs[0][:len(want)].cpu().numpy()) == want
+    assert res[0].reserved == 1, f"{kind}: fell back to the serial kernel"
+
+
+def test_pipeline_takes_swiftpng_made_streams(gpu):
+    """swift-png's own level-6 output: 2047-token blocks (LZ77.DeflatorBuffers.Stream.swift), one chunk of
+    subsequences per block."""
+    s = gpu.load()
+    d = scanlines(5, 2 << 20)
+    z = s.deflate(d, 6)
+    outs, res = s.inflate_batch([s.to_device(z)], [len(d) + 64])
+    assert res[0].status == 0 and res[0].reserved == 1
+    assert bytes(outs[0][:len(d)].cpu().numpy()) == d
+
+
+def test_pipeline_batch_of_ragged_streams(gpu):
+    """one call, streams from 0 bytes to MiBs, valid and not: the pipeline's verdicts never differ from zlib's"""
+    s = gpu.load()
+    rng = np.random.default_rng(5)
+    datas = [scanlines(10 + i, int(4096 * rng.integers(1, 400))) for i in range(24)] + [b"", b"a"]
+    zs = [zlib.compress(d, int(rng.integers(1, 10))) for d in datas]
+    zs[3] = zs[3][:len(zs[3]) // 2]                       # truncated
+    bad = bytearray(zs[5]); bad[len(bad) // 2] ^= 0x10; zs[5] = bytes(bad)    # corrupted
+    outs, res = s.inflate_batch([s.to_device(z) for z in zs], [len(d) + 16 for d in datas])
+    for i, (d, z) in enumerate(zip(datas, zs)):
+        if i in (3, 5):
+            continue
+        assert res[i].status == 0 and bytes(outs[i][:len(d)].cpu().numpy()) == d, i
+    assert res[3].status != 0
+    try:
+        ok5 = zlib.decompress(zs[5]) == datas[5]
+    except zlib.error:
+        ok5 = False
+    assert (res[5].status == 0) == ok5
