@@ -31,6 +31,7 @@
 // the reference's heap-based length-limited Huffman construction (ranked in parallel, merged on
 // one lane because its tie-breaking is order dependent), code-length RLE, and the token bits.
 #include "common.hpp"
+#include "huffman.hpp"      // UNI / uni64, WSYNC, DPP scans
 
 namespace spng {
 
@@ -42,9 +43,6 @@ struct __attribute__((packed)) U128u { u32x4 v; };
 typedef uint8_t __attribute__((address_space(1))) gbyte;
 typedef uint32_t __attribute__((address_space(1))) gword;
 typedef U32u __attribute__((address_space(1))) gU32u;
-// wave-uniform values, said so to the compiler (see inflate.hip)
-#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)UNI(v >> 32) << 32 | UNI((uint32_t)v); }
 
 static constexpr int HBITS = 13;                 // bucket heads in LDS
 static constexpr uint32_t NONE = 0xffffffffu;
@@ -72,33 +70,24 @@ __device__ __forceinline__ uint32_t dist_decade(uint32_t d)
     return 2 * e + 2 + ((x >> e) & 1);
 }
 
-static constexpr int CHV = 2048;                 // vertices per back-trace chunk
 struct DLds {
     uint32_t head[(1 << HBITS) + 1];             // most recent position per bucket (low 32 bits); + a slot nobody reads
     union {
         uint32_t terms[2048];                    // greedy / lazy: the queued terms
         uint32_t cslot[30 * 64];                 // full: per lane, the best run of every distance decade (distance << 16 | run)
     };
-    // full search (levels >= 8): forward pass / back-trace scratch
-    union {
-        struct {
-            uint32_t win_depth[512], win_up[512];    // the next vertices' best depth and the edge it came by
-            uint32_t batch[64 * 30];                 // edge slots of the 64 vertices being explored
-        };
-        struct {
-            uint32_t upc[CHV];                       // chunk of the per-vertex incoming edges
-            uint16_t jump[2][CHV];                   // pointer doubling over the chunk
-        };
-    };
-    uint8_t  onpath[CHV];
+    // full search (levels >= 8), forward pass: the best way into each of the next vertices found so far, as
+    // one 64-bit key (depth << 32 | writer order: see full_forward), and the edge slots of the 64 vertices at hand
+    uint64_t win[512];
+    uint32_t batch[64 * 30];
     uint8_t  depths[544];                        // LZ77.DeflatorMatches.Depths: cost of every symbol in quarter bits
     uint32_t freq[320];                          // 0..287 lit/len, 288..319 distance
-    uint8_t  out[OUTB];
+    union { uint8_t out[OUTB]; uint32_t out32[OUTB / 4]; };   // output staging ring; bytes not written yet are zero
     // Huffman scratch (one tree at a time)
     uint16_t order[288];                         // symbols by descending frequency (stable)
-    uint64_t heap[288];                          // heap entries: key << 32 | node id
+    uint64_t heap[288];                          // heap entries: key << 32 | node id; afterwards ancestor / depth of every node
     uint16_t parent[576];                        // tree nodes: leaves 0..m-1 (in `order`), then merges
-    uint16_t depthcnt[300];                      // leaves per depth
+    uint32_t depthcnt[300];                      // leaves per depth
     uint8_t  ll[288], dl[32], ml[19];            // code lengths
     uint16_t lcode[288], dcode[32], mcode[19];   // bit-reversed codewords
     uint8_t  msym[320], mbits[320];              // code-length RLE terms
@@ -129,6 +118,7 @@ __device__ __forceinline__ void drain(DLds &s, Bits &b, uint64_t upto, int lane)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     for (uint64_t i = b.flushed + lane; i < upto; i += 64) {
         if (i < b.cap) b.dst[i] = s.out[i & (OUTB - 1)];
+        s.out[i & (OUTB - 1)] = 0;                              // (the ring ahead of the writer is all zero: bulk_put ORs into it)
     }
     if (upto > b.cap) b.overflow = true;
     b.flushed = upto;
@@ -137,6 +127,28 @@ __device__ __forceinline__ void drain(DLds &s, Bits &b, uint64_t upto, int lane)
 __device__ __forceinline__ void maybe_drain(DLds &s, Bits &b, int lane)
 {
     if (b.total - b.flushed >= OUTB / 2) drain(s, b, b.total, lane);
+}
+
+// Up to 64 bit strings at once (lane order = stream order): `n` <= 48 bits of `v` per lane, n = 0 for a lane
+// without one.  Prefix sum of the lengths, then every lane ORs its bits into the staging ring (LDS atomics:
+// neighbours share dwords).  At most 384 bytes per call; the caller drains in between (maybe_drain).
+__device__ __forceinline__ void bulk_put(DLds &s, Bits &b, uint64_t v, uint32_t n, int lane)
+{
+    uint32_t tot;
+    const uint32_t off = wave_excl_scan(n, tot, lane);
+    if (b.nacc) s.out[b.total & (OUTB - 1)] = (uint8_t)b.acc;  // the pending bits of the serial writer join the ring
+    if (n) {
+        const uint64_t pos = b.total * 8 + b.nacc + off;
+        const uint32_t w = (uint32_t)(pos >> 5), sh = (uint32_t)pos & 31;
+        const uint64_t x = v << sh;
+        atomicOr(&s.out32[w & (OUTB / 4 - 1)], (uint32_t)x);
+        if (sh + n > 32) atomicOr(&s.out32[(w + 1) & (OUTB / 4 - 1)], (uint32_t)(x >> 32));
+        if (sh + n > 64) atomicOr(&s.out32[(w + 2) & (OUTB / 4 - 1)], (uint32_t)(v >> (64 - sh)));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    const uint64_t end = b.total * 8 + b.nacc + tot;
+    b.total = end >> 3; b.nacc = (uint32_t)end & 7;
+    b.acc = b.nacc ? UNI(s.out[b.total & (OUTB - 1)]) : 0;      // (the unfinished byte stays in the ring; put() overwrites it)
 }
 
 // HuffmanTree.init(frequencies:limit:) (HuffmanTree.swift:247-344) for `n` symbols with counts
@@ -210,39 +222,75 @@ __device__ __attribute__((noinline)) void build_tree(const uint32_t *freq, int n
             }
             hp[i - 1] = (uint64_t)key << 32 | id;
         }
-        // depth histogram: depthcnt[d-1] = leaves at depth d
-        int maxd = 0;
-        for (int d = 0; d < 300; ++d) s.depthcnt[d] = 0;
-        for (int k = 0; k < m; ++k) {
-            int d = 0;
-            for (uint16_t v = (uint16_t)k; v != root; v = s.parent[v]) ++d;
-            s.depthcnt[d - 1]++;
-            if (d > maxd) maxd = d;
+        s.parent[root] = root;                                 // (root == 2 m - 2: the last merge)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    // depth of every node by pointer jumping (the heap's storage is free now): leaves per depth.
+    // The reference's per-level leaf-count vectors are exactly this histogram.
+    const uint32_t nodes = 2 * (uint32_t)m - 1, root = nodes - 1;
+    uint16_t *anc = (uint16_t *)s.heap, *dep = anc + 576;
+    for (uint32_t v = lane; v < nodes; v += 64) { anc[v] = s.parent[v]; dep[v] = v == root ? 0 : 1; }
+    for (int i = lane; i < 300; i += 64) s.depthcnt[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    for (int round = 0; round < 10; ++round) {
+        uint32_t na[9], nd[9];
+        bool moving = false;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const uint32_t v = (uint32_t)lane + 64u * j;
+            if (v < nodes) {
+                const uint32_t a = anc[v];
+                na[j] = anc[a]; nd[j] = dep[v] + dep[a];
+                moving = moving || a != root;
+            }
         }
-        // HuffmanTree.limitHeight (:348-404)
-        int nl = maxd;
-        if (nl > limit) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const uint32_t v = (uint32_t)lane + 64u * j;
+            if (v < nodes) { anc[v] = (uint16_t)na[j]; dep[v] = (uint16_t)nd[j]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (!__ballot(moving)) break;
+    }
+    uint32_t maxd = 0;
+    for (int k = lane; k < m; k += 64) {
+        const uint32_t d = dep[k];
+        atomicAdd(&s.depthcnt[d - 1], 1u);
+        maxd = d > maxd ? d : maxd;
+    }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)maxd, w, 64); maxd = o > maxd ? o : maxd; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    // HuffmanTree.limitHeight (:348-404)
+    int nl = (int)maxd;
+    if (nl > limit) {
+        if (lane == 0) {
             int unhoused = 0;
             for (int l = nl - 1; l >= limit; --l) {
-                const int pairs = s.depthcnt[l] >> 1;
+                const int pairs = (int)(s.depthcnt[l] >> 1);
                 unhoused += pairs;
-                s.depthcnt[l - 1] += (uint16_t)pairs;
+                s.depthcnt[l - 1] += (uint32_t)pairs;
             }
-            nl = limit;
             int split = limit - 2;
             while (unhoused > 0) {
                 if (!(s.depthcnt[split] > 0)) { split--; continue; }
-                const int resettled = s.depthcnt[split] < unhoused ? s.depthcnt[split] : unhoused;
+                const int resettled = (int)s.depthcnt[split] < unhoused ? (int)s.depthcnt[split] : unhoused;
                 unhoused -= resettled;
-                s.depthcnt[split] -= (uint16_t)resettled;
-                s.depthcnt[split + 1] += (uint16_t)(2 * resettled);
+                s.depthcnt[split] -= (uint32_t)resettled;
+                s.depthcnt[split + 1] += (uint32_t)(2 * resettled);
                 if (split < limit - 2) split++;
             }
         }
-        // most frequent symbols take the shortest codes (:306-337)
-        int at = 0;
-        for (int l = 0; l < nl; ++l)
-            for (int k = 0; k < s.depthcnt[l]; ++k) len[s.order[at++]] = (uint8_t)(l + 1);
+        nl = limit;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    }
+    // most frequent symbols take the shortest codes (:306-337): rank r gets the level its slot falls into
+    for (int base = 0; base < m; base += 64) {
+        const int r = base + lane;
+        uint32_t acc = 0, l1 = 1;
+        for (int l = 0; l < nl; ++l) { acc += UNI(s.depthcnt[l]); l1 += (uint32_t)r >= acc; }
+        if (r < m) len[s.order[r]] = (uint8_t)l1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 }
@@ -250,15 +298,28 @@ __device__ __attribute__((noinline)) void build_tree(const uint32_t *freq, int n
 // canonical codewords, bit-reversed for LSB-first emission (HuffmanTree.codewords :206-230)
 __device__ __attribute__((noinline)) void make_codes(const uint8_t *len, int n, uint16_t *code, int lane)
 {
-    if (lane == 0) {
-        uint32_t counter = 0;
-        for (int l = 1; l <= 15; ++l) {
-            for (int sym = 0; sym < n; ++sym) if (len[sym] == l) {
-                code[sym] = (uint16_t)(__brev(counter) >> (32 - l));
-                counter++;
-            }
-            counter <<= 1;
+    // codes of one length are consecutive in symbol order; the first code of length l is
+    // (first of l-1 + count of l-1) << 1
+    uint32_t my[5], cw[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) { const int sym = c * 64 + lane; my[c] = sym < n ? len[sym] : 0u; cw[c] = 0; }
+    uint32_t next = 0, prev = 0;
+    for (uint32_t l = 1; l <= 15; ++l) {
+        next = (next + prev) << 1;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const unsigned long long mk = __ballot(my[c] == l);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0));
+            if (my[c] == l) cw[c] = next + cnt + before;
+            cnt += (uint32_t)__popcll(mk);
         }
+        prev = cnt;
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        const int sym = c * 64 + lane;
+        if (sym < n && my[c]) code[sym] = (uint16_t)(__brev(cw[c]) >> (32 - my[c]));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 }
@@ -325,14 +386,32 @@ __device__ __attribute__((noinline)) Bits write_tables(Bits b, bool final, int l
     put(s, b, (uint32_t)(dn - 1), 5, lane);
     put(s, b, (uint32_t)(ncl - 4), 4, lane);
     for (int k = 0; k < ncl; ++k) put(s, b, UNI(s.cl[k]), 3, lane);
-    // writeBlockTables (:615-623)
-    for (int k = 0; k < nm; ++k) {
-        const uint32_t sym = s.msym[k];
-        put(s, b, s.mcode[sym], s.ml[sym], lane);
-        put(s, b, s.mbits[k], sym == 18 ? 7 : sym == 17 ? 3 : sym == 16 ? 2 : 0, lane);
+    // writeBlockTables (:615-623), 64 terms at a time
+    for (int k0 = 0; k0 < nm; k0 += 64) {
+        const int k = k0 + lane;
+        uint64_t v = 0; uint32_t nb = 0;
+        if (k < nm) {
+            const uint32_t sym = s.msym[k], l = s.ml[sym];
+            v = (uint64_t)s.mcode[sym] | (uint64_t)s.mbits[k] << l;
+            nb = l + (sym == 18 ? 7u : sym == 17 ? 3u : sym == 16 ? 2u : 0u);
+        }
+        bulk_put(s, b, v, nb, lane);
     }
     maybe_drain(s, b, lane);
     return b;
+}
+
+// the bits of one term: a literal, or run code + extra bits + distance code + extra bits (<= 48)
+__device__ __forceinline__ uint64_t literal_bits(const DLds &s, uint32_t lit, uint32_t &nb)
+{
+    nb = s.ll[lit];
+    return s.lcode[lit];
+}
+__device__ __forceinline__ uint64_t match_bits(const DLds &s, uint32_t rd, uint32_t rextra, uint32_t dd, uint32_t dextra, uint32_t &nb)
+{
+    const uint32_t sym = 256 | rd, l1 = s.ll[sym], e1 = run_extra_bits(rd), l2 = s.dl[dd], e2 = dist_extra_bits(dd);
+    nb = l1 + e1 + l2 + e2;
+    return (uint64_t)s.lcode[sym] | (uint64_t)rextra << l1 | (uint64_t)s.dcode[dd] << (l1 + e1) | (uint64_t)dextra << (l1 + e1 + l2);
 }
 
 // Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), greedy / lazy form
@@ -353,17 +432,18 @@ __device__ __attribute__((noinline)) Bits write_block(Bits b, int count, bool fi
     build_tree(s.freq, 286, 15, s.ll, lane);
     build_tree(s.freq + 288, 30, 15, s.dl, lane);
     b = write_tables(b, final, lane);
-    // writeBlock(with:) (:626-659)
-    for (int i = 0; i < count; ++i) {
-        const uint32_t t = s.terms[i];
-        const uint32_t sym = t & 0x1ff, dsym = t >> 27;
-        put(s, b, s.lcode[sym], s.ll[sym], lane);
-        if (sym > 256) {
-            put(s, b, (t >> 9) & 0x1f, run_extra_bits(sym & 0xff), lane);
-            put(s, b, s.dcode[dsym], s.dl[dsym], lane);
-            put(s, b, (t >> 14) & 0x1fff, dist_extra_bits(dsym), lane);
+    // writeBlock(with:) (:626-659), 64 terms at a time
+    for (int i0 = 0; i0 < count; i0 += 64) {
+        const int i = i0 + lane;
+        uint64_t v = 0; uint32_t nb = 0;
+        if (i < count) {
+            const uint32_t t = s.terms[i];
+            const uint32_t sym = t & 0x1ff;
+            if (sym > 256) v = match_bits(s, sym & 0xff, (t >> 9) & 0x1f, t >> 27, (t >> 14) & 0x1fff, nb);
+            else v = literal_bits(s, sym, nb);
         }
-        if ((i & 255) == 255) maybe_drain(s, b, lane);
+        bulk_put(s, b, v, nb, lane);
+        maybe_drain(s, b, lane);
     }
     put(s, b, s.lcode[256], s.ll[256], lane);
     maybe_drain(s, b, lane);
@@ -385,11 +465,55 @@ __device__ __forceinline__ uint32_t common_prefix(const gbyte *in, uint64_t q, u
     return i;
 }
 
+// Hash insertion of the 64 positions inserted .. inserted + 63 (LZ77.DeflatorWindow.update, :78-128): every
+// lane hashes its 4-byte key; a position's link is the distance to the previous position of its bucket --
+// the nearest lower lane with the same bucket (radix match over the hash bits: one ballot per bit), else
+// the bucket head -- and the last lane of every bucket becomes the new head.  Adler-32 sums ride along.
+__device__ __forceinline__ void insert_batch(DLds &s, const gbyte *in, uint64_t n, gword *ring, uint64_t inserted,
+                                             uint32_t &accS, uint32_t &accI, int lane)
+{
+    const uint64_t p = inserted + lane;
+    const bool live = p + 4 <= n;                              // the last three positions never start a match
+    uint32_t key = 0;
+    if (live) key = load32(in + p);
+    else for (int k = 0; k < 4; ++k) if (p + k < n) key |= (uint32_t)in[p + k] << (8 * k);
+    if (p < n) {                                               // Adler-32 accumulators
+        const uint32_t byte = key & 0xff;
+        accS += byte;
+        accI = (accI + (uint32_t)(p % 65521) * byte) % 65521;
+    }
+    const uint32_t mix = key * 0x9E3779B1u;
+    const uint32_t h = mix >> (32 - HBITS);
+    const uint32_t tag = (mix >> 3) & 0xffffu;
+    unsigned long long same = __ballot(live);
+#pragma unroll
+    for (int k = 0; k < HBITS; ++k) {
+        const unsigned long long bk = __ballot((h >> k) & 1);
+        same &= (h >> k) & 1 ? bk : ~bk;
+    }
+    const unsigned long long lower = (1ull << lane) - 1;
+    const unsigned long long below = same & lower, above = same & ~lower & ~(1ull << lane);
+    uint32_t prev = live ? s.head[h] : NONE;
+    if (below) prev = (uint32_t)(inserted + (63 - __clzll((long long)below)));
+    uint32_t dist = 0;
+    if (live && prev != NONE) {
+        const uint64_t d = (uint32_t)((uint32_t)p - prev);
+        dist = d <= 32767 ? (uint32_t)d : 0;
+    }
+    if (p < n) ring[p & 65535] = dist | tag << 16;
+    s.head[live && !above ? h : 1u << HBITS] = (uint32_t)p;    // (idle lanes: the spare slot)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+}
+
 #ifdef SPNG_DEFLATE_PROF
+// full kernel: cycles per phase, kept in LDS so that the non-inlined passes can add to them
+__shared__ uint64_t g_prof[12];
+#define FPROF(k) do { const uint64_t now_ = __builtin_readcyclecounter(); if (threadIdx.x == 0) { g_prof[k] += now_ - g_prof[11]; g_prof[11] = now_; } } while (0)
 #define DPROF_DECL uint64_t pt[6] = {0,0,0,0,0,0}, p_t0 = 0;
 #define DPROF_BEGIN() p_t0 = __builtin_readcyclecounter()
 #define DPROF_END(k) pt[k] += __builtin_readcyclecounter() - p_t0
 #else
+#define FPROF(k)
 #define DPROF_DECL
 #define DPROF_BEGIN()
 #define DPROF_END(k)
@@ -416,6 +540,8 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
     const int attempts = lv == 0 ? 1 : lv == 1 ? 2 : lv == 2 ? 4 : lv == 3 ? 40 : lv == 4 ? 20 : lv == 5 ? 40 : lv == 6 ? 64 : 100;
     const int goal = lv == 0 ? 6 : lv == 1 ? 8 : lv == 2 ? 10 : lv == 3 ? 24 : lv == 4 ? 32 : lv == 5 ? 54 : lv == 6 ? 80 : 160;
 
+    for (int i = lane; i < OUTB / 4; i += 64) s.out32[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     Bits b = {0, 0, 0, 0, job.dst, job.dst_cap, false};
     const uint32_t wmask = (1u << UNI(jp->exponent)) - 1;    // window 2^exponent (LZ77.Deflator(exponent:); PNG: 15)
     if (job.format == SPNG_FORMAT_ZLIB) {
@@ -446,37 +572,8 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         uint64_t w = 0;                                        // parse position
         auto insert_upto = [&](uint64_t target) {
             while (inserted < target && inserted < n) {
-                const uint64_t p = inserted + lane;
-                const bool live = p + 4 <= n;                  // the last three positions never start a match
-                uint32_t key = 0;
-                if (live) key = load32(in + p);
-                else for (int k = 0; k < 4; ++k) if (p + k < n) key |= (uint32_t)in[p + k] << (8 * k);
-                if (p < n) {                                   // Adler-32 accumulators
-                    const uint32_t byte = key & 0xff;
-                    accS += byte;
-                    accI = (accI + (uint32_t)(p % 65521) * byte) % 65521;
-                }
-                const uint32_t mix = key * 0x9E3779B1u;
-                const uint32_t h = live ? mix >> (32 - HBITS) : 0xffffffffu - lane;
-                const uint32_t tag = (mix >> 3) & 0xffffu;
-                uint32_t prev = live ? s.head[h & ((1 << HBITS) - 1)] : NONE;
-                bool later = false;
-#pragma unroll
-                for (int j = 0; j < 64; ++j) {
-                    const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
-                    const bool same = hj == h;
-                    prev = (same && j < lane) ? (uint32_t)(inserted + j) : prev;
-                    later |= same && j > lane;
-                }
-                uint32_t dist = 0;
-                if (live && prev != NONE) {
-                    const uint64_t d = (uint32_t)((uint32_t)p - prev);
-                    dist = d <= 32767 ? (uint32_t)d : 0;
-                }
-                if (p < n) ring[p & 65535] = dist | tag << 16;
-                s.head[live && !later ? h & ((1 << HBITS) - 1) : 1 << HBITS] = (uint32_t)p;   // (idle lanes: the spare slot)
+                insert_batch(s, in, n, ring, inserted, accS, accI, lane);
                 inserted = uni64(inserted + 64);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             }
         };
 
@@ -605,11 +702,18 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
 //     frequencies and hand their edge to the vertex it starts from.
 //   * trees, cost update, repeat (2 x iterations passes for the first block, iterations after);
 //     then the block is written walking the path forwards.
-struct FullArrays {
-    gword *slots;        // [vertex][30]: distance << 16 | longest run of that distance decade
-    gword *up;           // [vertex]: incoming edge of the cheapest path, run << 16 | decade << 8 (literal: 1 << 16 | 0xff00)
-    gword *step;         // [vertex]: the path's edge that STARTS here (set by the back-trace)
-    gbyte *pathb;        // [vertex]: on the path
+struct FullArrays {      // (two registers' worth: passed to the non-inlined passes in SGPRs, not through scratch memory)
+    gword *base; uint32_t vcap;
+    // [vertex][30]: distance << 16 | longest run of that distance decade
+    __device__ __forceinline__ gword *slots_() const { return base; }
+    // [vertex]: incoming edge of the cheapest path, run << 16 | decade << 8 (literal: 1 << 16 | 0xff00)
+    __device__ __forceinline__ gword *up_() const { return base + (uint64_t)vcap * 30; }
+    // [vertex]: the path's edge that STARTS here (set by the back-trace)
+    __device__ __forceinline__ gword *step_() const { return up_() + vcap + 1; }
+    // [vertex]: on the path
+    __device__ __forceinline__ gbyte *pathb_() const { return (gbyte *)(step_() + vcap + 1); }
+    // [vertex]: has edges (its thirty slots are valid); vertices without ones never touch `slots`
+    __device__ __forceinline__ gbyte *flag_() const { return pathb_() + vcap + 1; }
 };
 
 __device__ __forceinline__ uint32_t run_base(uint32_t dec)       // LZ77.Composites.swift:25-63
@@ -624,109 +728,159 @@ __device__ __forceinline__ uint32_t depth_default(uint32_t i)    // Depths.defau
     return i < 256 ? 33u : i < 512 ? 30u + 4 * run_extra_bits(run_decade(i - 253)) : 19u + 4 * dist_extra_bits(i - 512);
 }
 
-// minimize() forwards (:262-280, explore :322-379): best depth and incoming edge of every vertex
+// minimize() forwards (:262-280, explore :322-379): best depth and incoming edge of every vertex.
+//
+// The reference visits the vertices in order and lets every edge of a vertex overwrite its target when it is
+// strictly cheaper -- so among equally cheap ways into a vertex the FIRST writer stays: the edge from the
+// earliest vertex (= the longest edge), then the literal before the matches, then the lowest distance decade.
+// That makes the best way into a vertex the minimum of one 64-bit key over all its incoming edges,
+//     depth << 32 | (258 - length) << 8 | (literal: 0, match: decade + 1)
+// and the order in which edges are tried irrelevant, as long as every edge is tried with the final depth of
+// the vertex it leaves.  So, 64 vertices at a time:
+//   * the keys the matches have offered so far sit in an LDS ring (ds_min_u64);
+//   * depth(v) = min(offered(v), depth(v - 1) + literal cost) along the batch is a prefix scan under
+//     (a1, b1) o (a2, b2) = (a1 + a2, min(b1 + a2, b2)), in DPP steps, no memory;
+//   * a match is at least 3 long: the depths of three consecutive vertices are final before any of their
+//     own edges is relaxed.  Vertices with edges are taken three positions at a time (lanes spread over the
+//     run lengths, costs in registers), then the scan is repeated.  Batches without edges (incompressible
+//     data) cost one scan.
+static constexpr uint32_t DINF = 0x3fffffffu;    // "no way in yet" (real depths stay below 2^28)
+__device__ __forceinline__ uint32_t minplus_scan(uint32_t a, uint32_t b, uint32_t x, int lane)
+{
+    // inclusive composition inside each row of 16 lanes
+#define SPNG_MP_STEP(ctrl)                                                                         \
+    {                                                                                              \
+        const uint32_t as = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, ctrl, 0xf, 0xf, false);          \
+        const uint32_t bs = (uint32_t)__builtin_amdgcn_update_dpp((int)DINF, (int)b, ctrl, 0xf, 0xf, false);  \
+        const uint32_t nb = bs + a < b ? bs + a : b;                                               \
+        a += as; b = nb;                                                                           \
+    }
+    SPNG_MP_STEP(0x111) SPNG_MP_STEP(0x112) SPNG_MP_STEP(0x114) SPNG_MP_STEP(0x118)
+#undef SPNG_MP_STEP
+    // the value entering each row
+    uint32_t x1, x2, x3;
+    {
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)a, 15), b0 = (uint32_t)__builtin_amdgcn_readlane((int)b, 15);
+        const uint32_t a1 = (uint32_t)__builtin_amdgcn_readlane((int)a, 31), b1 = (uint32_t)__builtin_amdgcn_readlane((int)b, 31);
+        const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)a, 47), b2 = (uint32_t)__builtin_amdgcn_readlane((int)b, 47);
+        x1 = x + a0 < b0 ? x + a0 : b0;
+        x2 = x1 + a1 < b1 ? x1 + a1 : b1;
+        x3 = x2 + a2 < b2 ? x2 + a2 : b2;
+    }
+    const uint32_t xin = lane < 16 ? x : lane < 32 ? x1 : lane < 48 ? x2 : x3;
+    return xin + a < b ? xin + a : b;
+}
+
 __device__ __attribute__((noinline)) void full_forward(const FullArrays g, const gbyte *in, uint64_t bbase, uint32_t count, int lane)
 {
     DLds &s = g_lds;
-    if (lane == 0) { s.win_depth[0] = 0; s.win_up[0] = 0; }
-    uint32_t inited = 1;
-    for (uint32_t b0 = 0; b0 < count; b0 += 64) {
+    // costs in registers: distance decade `lane`; run lengths 3 + lane + 64 j
+    const uint32_t dcost = lane < 30 ? s.depths[512 + lane] : 0u;
+    uint32_t rc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t L = 3u + (uint32_t)lane + 64u * j; rc[j] = L <= 258 ? s.depths[253 + L] : 0u; }
+    if (lane == 0) s.win[0] = 0;                               // vertex 0: depth 0
+    uint32_t inited = 1, carry = DINF;                         // carry: depth of the vertex in front of the batch
+    for (uint32_t b0 = 0; b0 <= count; b0 += 64) {
         const uint32_t need = (b0 + 64 + 258 < count ? b0 + 64 + 258 : count) + 1;
-        for (uint32_t j = inited + lane; j < need; j += 64) { s.win_depth[j & 511] = 0xffffffffu; s.win_up[j & 511] = 0; }
+        for (uint32_t j = inited + lane; j < need; j += 64) s.win[j & 511] = ~0ull;
         inited = inited > need ? inited : need;
-        const uint32_t nv = count - b0 < 64 ? count - b0 : 64;
-        for (uint32_t i = lane; i < nv * 30; i += 64) s.batch[i] = g.slots[(uint64_t)b0 * 30 + i];
-        const uint32_t lit = (uint32_t)lane < nv ? in[bbase + b0 + lane] : 0u;
+        const uint32_t nv = count + 1 - b0 < 64 ? count + 1 - b0 : 64;      // vertices b0 .. b0 + nv - 1 (the last one: `count`, the end)
+        const uint32_t v = b0 + (uint32_t)lane;
+        const unsigned long long em = __ballot(v < count && g.flag_()[v] != 0);
+        if (em) {
+            const uint32_t ns = count - b0 < 64 ? count - b0 : 64;
+            for (uint32_t i = lane; i < ns * 30; i += 64) s.batch[i] = g.slots_()[(uint64_t)b0 * 30 + i];
+        }
+        const uint32_t cin = (v >= 1 && v <= count) ? s.depths[in[bbase + v - 1]] : 0u;   // the literal edge INTO v
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        for (uint32_t k = 0; k < nv; ++k) {
-            const uint32_t v = b0 + k;
-            const uint32_t cur = UNI(s.win_depth[v & 511]);
-            const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lit, (int)k);
-            const uint32_t ld = cur + UNI(s.depths[l]);
-            const uint32_t t1 = (v + 1) & 511;
-            if (ld < UNI(s.win_depth[t1])) { s.win_depth[t1] = ld; s.win_up[t1] = 0x0001ff00u; }   // (every lane, same values)
-            const uint32_t rem = count - v;
-            if (rem >= 3) {
-                const uint32_t mine = lane < 30 ? s.batch[k * 30 + lane] : 0u;
-                const uint32_t run = mine & 0xffff;
+        uint64_t W; uint32_t Wd, D;
+        uint32_t k = 0;
+        for (;;) {
+            W = (uint32_t)lane < nv ? s.win[v & 511] : ~0ull;
+            Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
+            D = minplus_scan(cin, Wd, carry, lane);
+            const unsigned long long rest = k < 64 ? (em >> k) << k : 0ull;
+            if (!rest) break;
+            const uint32_t kk = (uint32_t)__ffsll((long long)rest) - 1;
+            for (uint32_t kq = kk; kq < kk + 3 && kq < 64; ++kq) {
+                if (!((em >> kq) & 1)) continue;
+                const uint32_t vv = b0 + kq, rem = count - vv;
+                if (rem < 3) continue;
+                const uint32_t Dk = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kq);
+                const uint32_t run = lane < 30 ? s.batch[kq * 30 + lane] & 0xffffu : 0u;
                 unsigned long long m = __ballot(run > 0);
                 while (m) {
                     const int dec = __ffsll((long long)m) - 1;
                     m &= m - 1;
                     const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)run, dec);
                     const uint32_t maxlen = r < rem ? r : rem;
-                    const uint32_t base = cur + UNI(s.depths[512 + dec]);
-                    for (uint32_t L = 3 + lane; L <= maxlen; L += 64) {
-                        const uint32_t dd = base + s.depths[253 + L];
-                        const uint32_t tt = (v + L) & 511;
-                        if (dd < s.win_depth[tt]) { s.win_depth[tt] = dd; s.win_up[tt] = L << 16 | (uint32_t)dec << 8; }
+                    const uint32_t base = Dk + (uint32_t)__builtin_amdgcn_readlane((int)dcost, dec);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (3u + 64u * j > maxlen) break;
+                        const uint32_t L = 3u + (uint32_t)lane + 64u * j;
+                        if (L <= maxlen) {
+                            const uint64_t key = (uint64_t)(base + rc[j]) << 32 | (258u - L) << 8 | ((uint32_t)dec + 1u);
+                            __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
                 }
             }
+            k = kk + 3;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         }
-        if ((uint32_t)lane < nv) g.up[b0 + 1 + lane] = s.win_up[(b0 + 1 + lane) & 511];
+        // the way in: the literal only when strictly cheaper than what the matches offer
+        if ((uint32_t)lane < nv && v >= 1) {
+            const uint32_t low = (uint32_t)W;
+            g.up_()[v] = D < Wd ? 0x0001ff00u : (258u - (low >> 8)) << 16 | ((low & 0xff) - 1u) << 8;
+        }
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)(nv - 1));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// minimize() backwards (:282-320): the path from the last vertex to the first, symbol frequencies
-// into s.freq, every path edge handed to the vertex it starts from
+// minimize() backwards (:282-320): the path from the last vertex to the first, symbol frequencies into
+// s.freq, every path edge handed to the vertex it starts from.  64 vertices at a time, descending from a
+// vertex on the path: lane i holds the way into vertex hi - i; the path hops through the batch on the
+// scalar unit (v_readlane with the hop's length), and a batch of nothing but literals is all path.
 __device__ __attribute__((noinline)) void full_backward(const FullArrays g, const gbyte *in, uint64_t bbase, uint32_t count, int lane)
 {
     DLds &s = g_lds;
     for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    uint32_t cur = count;
-    while (cur > 0) {
-        const uint32_t hi = cur, lo = hi >= CHV ? hi - CHV + 1 : 0, nn = hi - lo + 1;
-        for (uint32_t k = lane; k < nn; k += 64) {
-            const uint32_t c = lo + k;
-            const uint32_t u = c ? g.up[c] : 0u;
-            s.upc[k] = u;
-            const uint32_t len = u >> 16;
-            s.jump[0][k] = (c == 0 || len > k) ? (uint16_t)0xffff : (uint16_t)(k - len);
-            s.onpath[k] = k == nn - 1;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        int cb = 0;
-        for (int r = 0; r < 11; ++r) {                         // 2^11 = CHV
-            for (uint32_t k = lane; k < nn; k += 64) {
-                const uint32_t j = s.jump[cb][k];
-                if (s.onpath[k] && j != 0xffff) s.onpath[j] = 1;
+    uint32_t hi = count;
+    for (;;) {
+        const bool valid = (uint32_t)lane <= hi;
+        const uint32_t c = valid ? hi - (uint32_t)lane : 0u;
+        const uint32_t u = (valid && c > 0) ? g.up_()[c] : 0u;
+        const uint32_t len = u >> 16;                          // 0: vertex 0 (or nothing)
+        unsigned long long pm = 0;
+        uint32_t pos = 0;
+        if (!__ballot(valid && c > 0 && len != 1)) { pm = __ballot(valid); pos = 64; }
+        else {
+            while (pos < 64) {
+                pm |= 1ull << pos;
+                const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)pos);
+                if (!l) break;
+                pos += l;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            for (uint32_t k = lane; k < nn; k += 64) {
-                const uint32_t j = s.jump[cb][k];
-                s.jump[cb ^ 1][k] = j == 0xffff ? (uint16_t)0xffff : s.jump[cb][j];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            cb ^= 1;
         }
-        uint32_t exit_to = 0;
-        for (uint32_t k = lane; k - lane < nn; k += 64) {      // (uniform trip count: ballot inside)
-            const bool in_chunk = k < nn;
-            const uint32_t c = lo + k;
-            const bool on = in_chunk && s.onpath[k];
-            if (in_chunk && c < count) g.pathb[c] = on ? 1 : 0;
-            const uint32_t u = in_chunk ? s.upc[k] : 0u;
-            const uint32_t len = u >> 16;
-            const bool hop = on && c > 0;
-            if (hop) {
-                const uint32_t nxt = c - len;
-                g.step[nxt] = u & 0xffffff00u;
-                if (len == 1) atomicAdd(&s.freq[in[bbase + nxt]], 1u);
-                else { atomicAdd(&s.freq[256 | run_decade(len)], 1u); atomicAdd(&s.freq[288 + ((u >> 8) & 0xff)], 1u); }
-            }
-            const unsigned long long em = __ballot(hop && len > k);            // the hop that leaves the chunk
-            if (em) exit_to = lo + k - lane + (__ffsll((long long)em) - 1) - (uint32_t)__shfl((int)len, __ffsll((long long)em) - 1, 64);
+        const bool on = ((pm >> lane) & 1) != 0;
+        if (valid && c < count) g.pathb_()[c] = on ? 1 : 0;
+        if (on && c > 0) {
+            const uint32_t nxt = c - len;
+            g.step_()[nxt] = u & 0xffffff00u;
+            if (len == 1) atomicAdd(&s.freq[in[bbase + nxt]], 1u);
+            else { atomicAdd(&s.freq[256 | run_decade(len)], 1u); atomicAdd(&s.freq[288 + ((u >> 8) & 0xff)], 1u); }
         }
-        exit_to = UNI(exit_to);
+        if (hi < 64 || pos > hi) break;                        // vertex 0 was in this batch
+        if (pos < 64) break;                                   // (cannot happen: a hop of length 0 above vertex 0)
+        const uint32_t nhi = hi - pos;
         // vertices the leaving hop jumped over are not on the path
-        if (lo > 0) for (uint32_t c = exit_to + 1 + lane; c < lo; c += 64) g.pathb[c] = 0;
-        cur = lo == 0 ? 0 : exit_to;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        for (uint32_t cc = nhi + 1 + (uint32_t)lane; cc + 64 <= hi; cc += 64) g.pathb_()[cc] = 0;
+        hi = nhi;
     }
     if (lane == 0) s.freq[256] = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -764,7 +918,7 @@ __device__ __attribute__((noinline)) Bits full_block(Bits b, const FullArrays g,
 {
     DLds &s = g_lds;
     for (int i = generic ? -iterations : 0;;) {
-        if (count) { full_forward(g, in, bbase, count, lane); full_backward(g, in, bbase, count, lane); }
+        if (count) { FPROF(2); full_forward(g, in, bbase, count, lane); FPROF(4); full_backward(g, in, bbase, count, lane); FPROF(5); }
         else {
             for (int k = lane; k < 320; k += 64) s.freq[k] = k == 256 ? 1u : 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -772,39 +926,32 @@ __device__ __attribute__((noinline)) Bits full_block(Bits b, const FullArrays g,
         build_tree(s.freq, 286, 15, s.ll, lane);
         build_tree(s.freq + 288, 30, 15, s.dl, lane);
         ++i;
+        FPROF(6);
         if (!(i < iterations)) break;
         full_depths_update(lane);
     }
     b = write_tables(b, final, lane);
-    // writeBlock(with:) (:661-707): walk the path
+    FPROF(7);
+    // writeBlock(with:) (:661-707): the path's terms, 64 vertices at a time
     for (uint32_t b0 = 0; b0 < count; b0 += 64) {
         const uint32_t v = b0 + lane;
-        const bool on = v < count && g.pathb[v] != 0;
-        const uint32_t st = on ? g.step[v] : 0u;
-        const uint32_t cnt = st >> 16, dd = (st >> 8) & 0xff;
-        const uint32_t lit = on ? in[bbase + v] : 0u;
-        const uint32_t off = (on && cnt > 1) ? g.slots[(uint64_t)v * 30 + dd] >> 16 : 0u;
-        unsigned long long m = __ballot(on);
-        while (m) {
-            const int k = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, k);
-            if (c == 1) {
-                const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)lit, k);
-                put(s, b, s.lcode[l], s.ll[l], lane);
-            } else {
-                const uint32_t rd = run_decade(c), d2 = (uint32_t)__builtin_amdgcn_readlane((int)dd, k);
-                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, k);
-                put(s, b, s.lcode[256 | rd], s.ll[256 | rd], lane);
-                put(s, b, run_extra_value(c, rd), run_extra_bits(rd), lane);
-                put(s, b, s.dcode[d2], s.dl[d2], lane);
-                put(s, b, dist_extra_value(o, d2), dist_extra_bits(d2), lane);
+        const bool on = v < count && g.pathb_()[v] != 0;
+        uint64_t bits = 0; uint32_t nb = 0;
+        if (on) {
+            const uint32_t st = g.step_()[v];
+            const uint32_t cnt = st >> 16, dd = (st >> 8) & 0xff;
+            if (cnt == 1) bits = literal_bits(s, in[bbase + v], nb);
+            else {
+                const uint32_t off = g.slots_()[(uint64_t)v * 30 + dd] >> 16, rd = run_decade(cnt);
+                bits = match_bits(s, rd, run_extra_value(cnt, rd), dd, dist_extra_value(off, dd), nb);
             }
         }
+        bulk_put(s, b, bits, nb, lane);
         maybe_drain(s, b, lane);
     }
     put(s, b, s.lcode[256], s.ll[256], lane);
     maybe_drain(s, b, lane);
+    FPROF(8);
     // resetGraph -> Depths.generalize (Depths.swift:88-98)
     for (uint32_t i = lane; i < 542; i += 64) {
         const uint32_t x = s.depths[i], d = depth_default(i);
@@ -824,11 +971,13 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
     gword *ring = (gword *)uni64((uint64_t)jp->ring);
     struct { gbyte *dst; uint64_t dst_cap; int32_t format, level; uint32_t image; } job = {
         (gbyte *)uni64((uint64_t)jp->dst), uni64(jp->dst_cap), (int32_t)UNI(jp->format), (int32_t)UNI(jp->level), UNI(jp->image) };
+#ifdef SPNG_DEFLATE_PROF
+    if (lane < 12) g_prof[lane] = lane == 11 ? __builtin_readcyclecounter() : 0;
+#endif
     const uint32_t vcap = UNI(jp->graph_vertices);             // vertices the scratch arrays hold
     FullArrays g;
     {
-        gword *base = (gword *)uni64((uint64_t)jp->graph);
-        g.slots = base; g.up = base + (uint64_t)vcap * 30; g.step = g.up + vcap + 1; g.pathb = (gbyte *)(g.step + vcap + 1);
+        g.base = (gword *)uni64((uint64_t)jp->graph); g.vcap = vcap;
     }
     // DeflatorSearch.init(level:) (:13-35), full rows
     const int lv = job.level > 13 ? 13 : job.level;
@@ -837,6 +986,8 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
     const int iterations = lv - 7;
     const uint32_t wmask = (1u << UNI(jp->exponent)) - 1;
 
+    for (int i = lane; i < OUTB / 4; i += 64) s.out32[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     Bits b = {0, 0, 0, 0, job.dst, job.dst_cap, false};
     if (job.format == SPNG_FORMAT_ZLIB) {
         // StreamHeader.write (StreamHeader.swift:56-62)
@@ -871,42 +1022,15 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
         uint64_t inserted = 0, w = 0;
         auto insert_upto = [&](uint64_t target) {
             while (inserted < target && inserted < n) {
-                const uint64_t p = inserted + lane;
-                const bool live = p + 4 <= n;
-                uint32_t key = 0;
-                if (live) key = load32(in + p);
-                else for (int k = 0; k < 4; ++k) if (p + k < n) key |= (uint32_t)in[p + k] << (8 * k);
-                if (p < n) {
-                    const uint32_t byte = key & 0xff;
-                    accS += byte;
-                    accI = (accI + (uint32_t)(p % 65521) * byte) % 65521;
-                }
-                const uint32_t mix = key * 0x9E3779B1u;
-                const uint32_t h = live ? mix >> (32 - HBITS) : 0xffffffffu - lane;
-                const uint32_t tag = (mix >> 3) & 0xffffu;
-                uint32_t prev = live ? s.head[h & ((1 << HBITS) - 1)] : NONE;
-                bool later = false;
-#pragma unroll
-                for (int j = 0; j < 64; ++j) {
-                    const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
-                    const bool same = hj == h;
-                    prev = (same && j < lane) ? (uint32_t)(inserted + j) : prev;
-                    later |= same && j > lane;
-                }
-                uint32_t dist = 0;
-                if (live && prev != NONE) {
-                    const uint64_t d = (uint32_t)((uint32_t)p - prev);
-                    dist = d <= 32767 ? (uint32_t)d : 0;
-                }
-                if (p < n) ring[p & 65535] = dist | tag << 16;
-                s.head[live && !later ? h & ((1 << HBITS) - 1) : 1 << HBITS] = (uint32_t)p;
+                insert_batch(s, in, n, ring, inserted, accS, accI, lane);
                 inserted = uni64(inserted + 64);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             }
         };
         while (w < last_main) {
+            FPROF(2);
             insert_upto(w + 128);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FPROF(0);
             // ---- every candidate of position w + lane becomes an edge (DeflatorWindow.match, :132-212)
             const uint64_t p = w + lane;
 #pragma unroll
@@ -937,17 +1061,29 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            FPROF(1);
             // ---- which positions are vertices with edges (Stream.compress full, :344-400)
             uint32_t t = 0;
+            if (!__ballot(extent > 100) && w + 64 <= last_main && unfilled() >= 64) {
+                // nothing to skip, no block to close: all 64 at once
+                if (count == 0) bbase = w;
+                const bool has = extent > 1;                   // (a candidate matched: at least the four key bytes)
+                g.flag_()[count + lane] = has ? 1 : 0;
+                if (__ballot(has))
+                    for (uint32_t i = lane; i < 64 * 30; i += 64) { const uint32_t vtx = i / 30, d = i - vtx * 30; g.slots_()[(uint64_t)count * 30 + i] = s.cslot[d * 64 + vtx]; }
+                count += 64;
+                t = 64;
+            }
             while (t < 64 && w + t < last_main) {
                 if (!(unfilled() > 0)) close_block(false);
                 if (count == 0) bbase = w + t;
-                if (lane < 30) g.slots[(uint64_t)count * 30 + lane] = s.cslot[lane * 64 + t];
-                count += 1;
                 const int ext = __builtin_amdgcn_readlane((int)extent, (int)t);
+                if (ext > 1) { if (lane < 30) g.slots_()[(uint64_t)count * 30 + lane] = s.cslot[lane * 64 + t]; }
+                if (lane == 0) g.flag_()[count] = ext > 1 ? 1 : 0;
+                count += 1;
                 int skip = ext - 100 < unfilled() ? ext - 100 : unfilled();
                 if (skip > 0) {
-                    for (uint32_t i = lane; i < (uint32_t)skip * 30; i += 64) g.slots[(uint64_t)count * 30 + i] = 0;
+                    for (uint32_t i = lane; i < (uint32_t)skip; i += 64) g.flag_()[count + i] = 0;
                     count += (uint32_t)skip;
                 } else skip = 0;
                 t += 1 + (uint32_t)skip;
@@ -959,7 +1095,7 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
         for (uint64_t p = w; p < n; ++p) {
             if (!(unfilled() > 0)) close_block(false);
             if (count == 0) bbase = p;
-            if (lane < 30) g.slots[(uint64_t)count * 30 + lane] = 0;
+            if (lane == 0) g.flag_()[count] = 0;
             count += 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -979,6 +1115,11 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
     }
     if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
     drain(s, b, b.total, lane);
+#ifdef SPNG_DEFLATE_PROF
+    if (lane == 0 && blockIdx.x == 0)
+        printf("deflate_full prof Mcycles: insert %llu search %llu register %llu forward %llu backward %llu trees %llu tables %llu emit %llu\n",
+               g_prof[0] >> 20, g_prof[1] >> 20, g_prof[2] >> 20, g_prof[4] >> 20, g_prof[5] >> 20, g_prof[6] >> 20, g_prof[7] >> 20, g_prof[8] >> 20);
+#endif
     if (lane == 0) {
         spng_result &res = results[job.image];
         res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_DONE; res.reserved = 0;
@@ -994,7 +1135,7 @@ uint64_t deflate_graph_vertices(uint64_t n)
 }
 uint64_t deflate_graph_bytes(uint64_t vertices)
 {
-    return ((vertices + 1) * (30 * 4 + 4 + 4 + 1) + 1024 + 255) & ~(uint64_t)255;
+    return ((vertices + 1) * (30 * 4 + 4 + 4 + 1 + 1) + 1024 + 255) & ~(uint64_t)255;
 }
 
 hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream)

@@ -81,6 +81,18 @@ __device__ __forceinline__ uint32_t row_scan(uint32_t v)
     return v;
 }
 
+// exclusive prefix sum over the wave; every lane gets the grand total too
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total, int lane)
+{
+    uint32_t incl = row_scan(v);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+    const uint32_t r1 = r0 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+    const uint32_t r2 = r1 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 47);
+    incl += lane < 16 ? 0u : lane < 32 ? r0 : lane < 48 ? r1 : r2;
+    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    return incl - v;
+}
+
 // Builds LUT + canonical fallback for `n` code lengths (lens[], LDS).  KIND: 0 lit/len, 1 distance,
 // 2 code-length code.  Returns false when the code is not complete (HuffmanTree.size, :80-108).
 // `normalizing` restates validate(symbols:normalizing:) (:112-135): 0 or 1 used symbol of length 1

@@ -161,17 +161,6 @@ struct Hdr {
     uint32_t literals, distances;      // dynamic blocks: HLIT + 257, HDIST + 1 (their code lengths are in s.lens)
 };
 
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total, int lane)
-{
-    uint32_t incl = row_scan(v);
-    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
-    const uint32_t r1 = r0 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
-    const uint32_t r2 = r1 + (uint32_t)__builtin_amdgcn_readlane((int)incl, 47);
-    incl += lane < 16 ? 0u : lane < 32 ? r0 : lane < 48 ? r1 : r2;
-    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    return incl - v;
-}
-
 // The run-length coded code lengths of a dynamic block header (readBlockTables,
 // InflatorBuffers.Stream.swift:144-263), decoded by the whole wave instead of symbol after symbol: the
 // same self-synchronisation scheme as the block data (see count_chunk), on 32-bit subsequences of a
@@ -650,8 +639,16 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
         }
     };
     advance(start + 1);
+    // the log: my own space and that of the segments behind me in which no start was found (nobody else
+    // writes there; a stream whose stored or fixed blocks hide every later start needs it)
     uint32_t *log = (uint32_t *)(logs + uni64(sg.log_off));
-    const uint32_t log_cap = UNI((uint32_t)(uni64(sg.log_cap) / 4));
+    uint32_t log_cap;
+    {
+        const PSeg &upto = segs[seg_first + (nk < seg_count ? nk : seg_count - 1)];
+        const uint64_t end = uni64(upto.log_off) + (nk < seg_count ? 0 : uni64(upto.log_cap));
+        const uint64_t room = (end - uni64(sg.log_off)) / 4;
+        log_cap = room > 0xffffff00ull ? 0xffffff00u : (uint32_t)room;
+    }
     uint32_t cur = 0;
     uint64_t pos = start, ntok = 0;
     int32_t status = PSEG_FAIL;

@@ -491,6 +491,27 @@ def test_deflate_full_search_block_growth(gpu):
         assert s.deflate(data, 9) == ph.orc_deflate(data, 9), n
 
 
+def test_deflate_full_search_sparse_matches(gpu):
+    """Levels >= 8 on (nearly) incompressible input, BASELINE configs[3]'s kind: batches of 64 vertices without a
+    single edge take the device's scan-only forward pass and literal-only back-trace; a sprinkling of repeated
+    snippets (some with runs > 100: the skip rule) mixes those with the batches that have edges.  Blocks up to
+    131071 vertices."""
+    s = gpu.load()
+    rng = np.random.default_rng(77)
+    noise = rng.integers(0, 256, 300000, dtype=np.uint8)
+    sprinkled = noise.copy()
+    for _ in range(400):
+        n = int(rng.choice([4, 5, 8, 16, 40, 130, 300]))
+        src = int(rng.integers(0, 300000 - 400)); dst = int(rng.integers(src + 1, min(src + 40000, 300000 - n)))
+        sprinkled[dst:dst + n] = sprinkled[src:src + n]
+    few = rng.integers(0, 4, 120000, dtype=np.uint8)            # 2-bit alphabet: short matches everywhere, Huffman-heavy
+    for kind, data in (("noise", noise.tobytes()), ("sprinkled", sprinkled.tobytes()), ("few", few.tobytes())):
+        for level in (8, 9, 13):
+            got = s.deflate(data, level)
+            assert got == ph.orc_deflate(data, level), (kind, level)
+        assert zlib.decompress(got) == data
+
+
 @pytest.mark.parametrize("exponent", [8, 11, 15])
 def test_deflate_window_exponent(gpu, exponent):
     """LZ77.Deflator(format:level:exponent:hint:) with a small window (LZ77Tests/Compression.swift:12 uses 8):
