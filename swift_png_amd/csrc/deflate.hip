@@ -74,7 +74,7 @@ struct DLds {
     uint32_t head[(1 << HBITS) + 1];             // most recent position per bucket (low 32 bits); + a slot nobody reads
     union {
         uint32_t terms[2048];                    // greedy / lazy: the queued terms
-        uint32_t cslot[30 * 64];                 // full: per lane, the best run of every distance decade (distance << 16 | run)
+        uint32_t cslot[2][30 * 64];              // full: per lane and half, the best run of every distance decade (distance << 16 | run)
     };
     // full search (levels >= 8), forward pass: the best way into each of the next vertices found so far, as
     // one 64-bit key (depth << 32 | writer order: see full_forward), and the edge slots of the 64 vertices at hand
@@ -452,11 +452,19 @@ __device__ __attribute__((noinline)) Bits write_block(Bits b, int count, bool fi
 
 __device__ __forceinline__ uint32_t load32(const gbyte *p) { return ((const gU32u *)p)->v; }
 
-// bytes of position q.. and p.. agree for how many bytes (<= limit)?  Dword-wise from the input.
+// bytes of position q.. and p.. agree for how many bytes (<= limit)?  Eight at a time from the input.
+struct __attribute__((packed)) U64u { uint64_t v; };
+typedef U64u __attribute__((address_space(1))) gU64u;
+__device__ __forceinline__ uint64_t load64(const gbyte *p) { return ((const gU64u *)p)->v; }
 __device__ __forceinline__ uint32_t common_prefix(const gbyte *in, uint64_t q, uint64_t p, uint32_t limit)
 {
     uint32_t i = 0;
-    while (i + 4 <= limit) {
+    while (i + 8 <= limit) {
+        const uint64_t x = load64(in + q + i) ^ load64(in + p + i);
+        if (x) return i + ((uint32_t)__builtin_ctzll(x) >> 3);
+        i += 8;
+    }
+    if (i + 4 <= limit) {
         const uint32_t x = load32(in + q + i) ^ load32(in + p + i);
         if (x) return i + (__builtin_ctz(x) >> 3);
         i += 4;
@@ -465,18 +473,64 @@ __device__ __forceinline__ uint32_t common_prefix(const gbyte *in, uint64_t q, u
     return i;
 }
 
+// LZ77.DeflatorWindow.match (:132-212) for TWO positions per lane at once (pA, pB: the lane's position in
+// each half of a 128-position batch): both chains hop together, so the latency of a hop -- the link and,
+// speculatively, the candidate's first four bytes -- is paid once for the pair.  hit(which, distance, run)
+// sees every candidate whose tag and key match, in chain order, and the reference's stop rules apply per
+// chain: `attempts` candidates, a run >= `goal`, the window 2^exponent.
+template <class F>
+__device__ __forceinline__ void chain_walk2(const gbyte *in, const gword *ring, uint64_t n, uint64_t pA, uint64_t pB,
+                                            bool liveA, bool liveB, uint32_t keyA, uint32_t keyB, uint32_t wmask,
+                                            int attempts, int goal, F &&hit)
+{
+    uint32_t tagA = 0, tagB = 0, dA = 0, dB = 0, accA = 0, accB = 0;
+    int remA = attempts, remB = attempts;
+    bool firstA = true, firstB = true;
+    if (liveA) { const uint32_t m = ring[pA & 65535]; tagA = m >> 16; dA = m & 0xffff; }
+    if (liveB) { const uint32_t m = ring[pB & 65535]; tagB = m >> 16; dB = m & 0xffff; }
+    const uint32_t limA = n - pA < 258 ? (uint32_t)(n - pA) : 258u, limB = n - pB < 258 ? (uint32_t)(n - pB) : 258u;
+    while (dA | dB) {
+        bool goA = dA != 0, goB = dB != 0;
+        if (goA) { accA += dA; if (accA > wmask || (!firstA && accA >= wmask)) goA = false; }
+        if (goB) { accB += dB; if (accB > wmask || (!firstB && accB >= wmask)) goB = false; }
+        uint32_t eA = 0, eB = 0, kA = 0, kB = 0;
+        if (goA) { eA = ring[(pA - accA) & 65535]; kA = load32(in + pA - accA); }
+        if (goB) { eB = ring[(pB - accB) & 65535]; kB = load32(in + pB - accB); }
+        if (goA && (eA >> 16) == tagA && kA == keyA) {
+            const uint32_t run = common_prefix(in, pA - accA, pA, limA);
+            hit(0, accA, run);
+            firstA = false; remA -= 1;
+            if (!(remA > 0 && goal > (int)run)) goA = false;
+        }
+        if (goB && (eB >> 16) == tagB && kB == keyB) {
+            const uint32_t run = common_prefix(in, pB - accB, pB, limB);
+            hit(1, accB, run);
+            firstB = false; remB -= 1;
+            if (!(remB > 0 && goal > (int)run)) goB = false;
+        }
+        dA = goA ? eA & 0xffff : 0u;
+        dB = goB ? eB & 0xffff : 0u;
+    }
+}
+
+// the 4-byte key of position p (zero-extended at the end of the input)
+__device__ __forceinline__ uint32_t load_key(const gbyte *in, uint64_t n, uint64_t p)
+{
+    if (p + 4 <= n) return load32(in + p);
+    uint32_t key = 0;
+    for (int k = 0; k < 4; ++k) if (p + k < n) key |= (uint32_t)in[p + k] << (8 * k);
+    return key;
+}
+
 // Hash insertion of the 64 positions inserted .. inserted + 63 (LZ77.DeflatorWindow.update, :78-128): every
 // lane hashes its 4-byte key; a position's link is the distance to the previous position of its bucket --
 // the nearest lower lane with the same bucket (radix match over the hash bits: one ballot per bit), else
 // the bucket head -- and the last lane of every bucket becomes the new head.  Adler-32 sums ride along.
-__device__ __forceinline__ void insert_batch(DLds &s, const gbyte *in, uint64_t n, gword *ring, uint64_t inserted,
+__device__ __forceinline__ void insert_batch(DLds &s, const gbyte *in, uint64_t n, gword *ring, uint64_t inserted, uint32_t key,
                                              uint32_t &accS, uint32_t &accI, int lane)
 {
     const uint64_t p = inserted + lane;
     const bool live = p + 4 <= n;                              // the last three positions never start a match
-    uint32_t key = 0;
-    if (live) key = load32(in + p);
-    else for (int k = 0; k < 4; ++k) if (p + k < n) key |= (uint32_t)in[p + k] << (8 * k);
     if (p < n) {                                               // Adler-32 accumulators
         const uint32_t byte = key & 0xff;
         accS += byte;
@@ -570,9 +624,12 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         const uint64_t last_main = n - 4 + 1;                  // positions 0 .. n-4 are searched
         uint64_t inserted = 0;                                 // positions < inserted are in the window
         uint64_t w = 0;                                        // parse position
+        uint32_t key_next = load_key(in, n, (uint64_t)lane);      // (keys travel one batch ahead of their insertion)
         auto insert_upto = [&](uint64_t target) {
             while (inserted < target && inserted < n) {
-                insert_batch(s, in, n, ring, inserted, accS, accI, lane);
+                const uint32_t key = key_next;
+                key_next = load_key(in, n, inserted + 64 + lane);
+                insert_batch(s, in, n, ring, inserted, key, accS, accI, lane);
                 inserted = uni64(inserted + 64);
             }
         };
@@ -581,58 +638,47 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
             // keep the window filled well ahead of the 64 positions searched now (+258 of look-ahead
             // is irrelevant for insertion: links only point backwards)
             DPROF_BEGIN();
-            insert_upto(w + 128);
+            insert_upto(w + 192);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // our own ring stores, before we read them back
             DPROF_END(0); DPROF_BEGIN();
-            // ---- match search: lane i answers window.match(from: w + i)
-            const uint64_t p = w + lane;
-            uint32_t best_run = 5, best_dist = 1;
-            if (p < last_main) {
-                const uint32_t limit = n - p < 258 ? (uint32_t)(n - p) : 258u;
-                const uint32_t mine = ring[p & 65535];
-                const uint32_t tag = mine >> 16;
-                uint32_t d = mine & 0xffff, acc = 0;
-                int remaining = attempts;
-                bool first = true;
-                while (d) {
-                    acc += d;
-                    if (acc > wmask || (!first && acc >= wmask)) break;
-                    const uint32_t e = ring[(p - acc) & 65535];
-                    if ((e >> 16) == tag && load32(in + p - acc) == load32(in + p)) {
-                        // LZ77.DeflatorWindow.match (:145-208): run, then the stop rules
-                        const uint32_t run = common_prefix(in, p - acc, p, limit);
-                        if (best_run < run) { best_run = run; best_dist = acc; }
-                        first = false;
-                        remaining -= 1;
-                        if (!(remaining > 0 && goal > (int)run)) break;
-                    }
-                    d = e & 0xffff;
-                }
-            }
-            const uint32_t mrun = best_run > 5 ? best_run : 0;   // 0: no match (run must exceed 5, :129)
-            const uint32_t mylit = p < n ? in[p] : 0u;
+            // ---- match search: lane i answers window.match(from: w + i) and (from: w + 64 + i)
+            const uint64_t pA = w + lane, pB = pA + 64;
+            const bool liveA = pA < last_main, liveB = pB < last_main;
+            const uint32_t keyA = liveA ? load32(in + pA) : 0u, keyB = liveB ? load32(in + pB) : 0u;
+            uint32_t brA = 5, bdA = 1, brB = 5, bdB = 1;
+            chain_walk2(in, ring, n, pA, pB, liveA, liveB, keyA, keyB, wmask, attempts, goal,
+                        [&](int which, uint32_t dist, uint32_t run) {
+                            // the first strictly longest run wins (:145-208)
+                            if (which == 0) { if (brA < run) { brA = run; bdA = dist; } }
+                            else            { if (brB < run) { brB = run; bdB = dist; } }
+                        });
+            const uint32_t mrunA = brA > 5 ? brA : 0, mrunB = brB > 5 ? brB : 0;   // 0: no match (run must exceed 5, :129)
+            const uint32_t litA = keyA & 0xff, litB = keyB & 0xff;
+            auto at = [&](uint32_t xa, uint32_t xb, uint32_t t) -> uint32_t {
+                return t < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)xa, (int)t) : (uint32_t)__builtin_amdgcn_readlane((int)xb, (int)(t - 64));
+            };
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             DPROF_END(1); DPROF_BEGIN();
 
-            // ---- the parse: Stream.compress greedy (:209-252) / lazy (:268-323) over these 64 answers
+            // ---- the parse: Stream.compress greedy (:209-252) / lazy (:268-323) over these 128 answers
             uint32_t t = 0;
             bool stop = false;
-            while (t < 64 && w + t < last_main && !stop) {
+            while (t < 128 && w + t < last_main && !stop) {
                 if (!(unfilled() > (lazy ? 1 : 0))) { DPROF_END(2); DPROF_BEGIN(); b = write_block(b, count, false, lane); count = 0; DPROF_END(3); DPROF_BEGIN(); }
-                const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)mrun, (int)t);
-                const uint32_t lit = (uint32_t)__builtin_amdgcn_readlane((int)mylit, (int)t);
+                const uint32_t run = at(mrunA, mrunB, t);
+                const uint32_t lit = at(litA, litB, t);
                 if (!run) { s.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
-                uint32_t use_run = run, use_dist = (uint32_t)__builtin_amdgcn_readlane((int)best_dist, (int)t);
+                uint32_t use_run = run, use_dist = at(bdA, bdB, t);
                 uint32_t adv = run;
                 if (lazy) {
                     // the answer for position w+t+1 is needed: restart the search there if it is not in this batch
-                    if (t + 1 >= 64) { stop = true; break; }
+                    if (t + 1 >= 128) { stop = true; break; }
                     // lazy match at a+1 (:293-299); it exists only if that position is still searched
-                    const uint32_t lrun = (w + t + 1 < last_main) ? (uint32_t)__builtin_amdgcn_readlane((int)mrun, (int)(t + 1)) : 0u;
+                    const uint32_t lrun = (w + t + 1 < last_main) ? at(mrunA, mrunB, t + 1) : 0u;
                     if (lrun > run) {
                         s.terms[count] = 0xf8000000u | lit;
                         ++count;
-                        use_run = lrun; use_dist = (uint32_t)__builtin_amdgcn_readlane((int)best_dist, (int)(t + 1));
+                        use_run = lrun; use_dist = at(bdA, bdB, t + 1);
                         adv = 1 + lrun;
                     }
                 }
@@ -781,18 +827,28 @@ __device__ __attribute__((noinline)) void full_forward(const FullArrays g, const
     for (int j = 0; j < 4; ++j) { const uint32_t L = 3u + (uint32_t)lane + 64u * j; rc[j] = L <= 258 ? s.depths[253 + L] : 0u; }
     if (lane == 0) s.win[0] = 0;                               // vertex 0: depth 0
     uint32_t inited = 1, carry = DINF;                         // carry: depth of the vertex in front of the batch
+    // (edge flag and literal byte of a batch are fetched while the batch before it is worked on: with one
+    //  wave per stream nothing else hides the latency of a load)
+    uint32_t fl_next = (uint32_t)lane < count ? g.flag_()[lane] : 0u;
+    uint32_t lb_next = (lane >= 1 && (uint32_t)lane <= count) ? in[bbase + lane - 1] : 0u;
     for (uint32_t b0 = 0; b0 <= count; b0 += 64) {
+        const uint32_t fl = fl_next, lb = lb_next;
+        {
+            const uint32_t vn = b0 + 64 + (uint32_t)lane;
+            fl_next = vn < count ? g.flag_()[vn] : 0u;
+            lb_next = vn <= count ? in[bbase + vn - 1] : 0u;
+        }
         const uint32_t need = (b0 + 64 + 258 < count ? b0 + 64 + 258 : count) + 1;
         for (uint32_t j = inited + lane; j < need; j += 64) s.win[j & 511] = ~0ull;
         inited = inited > need ? inited : need;
         const uint32_t nv = count + 1 - b0 < 64 ? count + 1 - b0 : 64;      // vertices b0 .. b0 + nv - 1 (the last one: `count`, the end)
         const uint32_t v = b0 + (uint32_t)lane;
-        const unsigned long long em = __ballot(v < count && g.flag_()[v] != 0);
+        const unsigned long long em = __ballot(fl != 0);
         if (em) {
             const uint32_t ns = count - b0 < 64 ? count - b0 : 64;
             for (uint32_t i = lane; i < ns * 30; i += 64) s.batch[i] = g.slots_()[(uint64_t)b0 * 30 + i];
         }
-        const uint32_t cin = (v >= 1 && v <= count) ? s.depths[in[bbase + v - 1]] : 0u;   // the literal edge INTO v
+        const uint32_t cin = (v >= 1 && v <= count) ? s.depths[lb] : 0u;                   // the literal edge INTO v
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         uint64_t W; uint32_t Wd, D;
         uint32_t k = 0;
@@ -851,10 +907,15 @@ __device__ __attribute__((noinline)) void full_backward(const FullArrays g, cons
     for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     uint32_t hi = count;
+    // (the ways into the next 64 vertices are fetched ahead on the guess that the path leaves this batch
+    //  exactly at its end, as it does through literals; a longer hop refetches)
+    uint32_t u_next = ((uint32_t)lane < hi) ? g.up_()[hi - (uint32_t)lane] : 0u, hi_next = hi;
     for (;;) {
         const bool valid = (uint32_t)lane <= hi;
         const uint32_t c = valid ? hi - (uint32_t)lane : 0u;
-        const uint32_t u = (valid && c > 0) ? g.up_()[c] : 0u;
+        uint32_t u = u_next;
+        if (hi_next != hi) u = (valid && c > 0) ? g.up_()[c] : 0u;
+        if (hi >= 64) { hi_next = hi - 64; u_next = ((uint32_t)lane < hi_next) ? g.up_()[hi_next - (uint32_t)lane] : 0u; }
         const uint32_t len = u >> 16;                          // 0: vertex 0 (or nothing)
         unsigned long long pm = 0;
         uint32_t pos = 0;
@@ -933,14 +994,21 @@ __device__ __attribute__((noinline)) Bits full_block(Bits b, const FullArrays g,
     b = write_tables(b, final, lane);
     FPROF(7);
     // writeBlock(with:) (:661-707): the path's terms, 64 vertices at a time
+    uint32_t pb_next = (uint32_t)lane < count ? g.pathb_()[lane] : 0u, st_next = (uint32_t)lane < count ? g.step_()[lane] : 0u,
+             lt_next = (uint32_t)lane < count ? in[bbase + lane] : 0u;
     for (uint32_t b0 = 0; b0 < count; b0 += 64) {
         const uint32_t v = b0 + lane;
-        const bool on = v < count && g.pathb_()[v] != 0;
+        const bool on = v < count && pb_next != 0;
+        const uint32_t st = st_next, lt = lt_next;
+        {
+            const uint32_t vn = v + 64;
+            const bool inn = vn < count;
+            pb_next = inn ? g.pathb_()[vn] : 0u; st_next = inn ? g.step_()[vn] : 0u; lt_next = inn ? in[bbase + vn] : 0u;
+        }
         uint64_t bits = 0; uint32_t nb = 0;
         if (on) {
-            const uint32_t st = g.step_()[v];
             const uint32_t cnt = st >> 16, dd = (st >> 8) & 0xff;
-            if (cnt == 1) bits = literal_bits(s, in[bbase + v], nb);
+            if (cnt == 1) bits = literal_bits(s, lt, nb);
             else {
                 const uint32_t off = g.slots_()[(uint64_t)v * 30 + dd] >> 16, rd = run_decade(cnt);
                 bits = match_bits(s, rd, run_extra_value(cnt, rd), dd, dist_extra_value(off, dd), nb);
@@ -1020,65 +1088,57 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
     } else {
         const uint64_t last_main = n - 4 + 1;
         uint64_t inserted = 0, w = 0;
+        uint32_t key_next = load_key(in, n, (uint64_t)lane);      // (keys travel one batch ahead of their insertion)
         auto insert_upto = [&](uint64_t target) {
             while (inserted < target && inserted < n) {
-                insert_batch(s, in, n, ring, inserted, accS, accI, lane);
+                const uint32_t key = key_next;
+                key_next = load_key(in, n, inserted + 64 + lane);
+                insert_batch(s, in, n, ring, inserted, key, accS, accI, lane);
                 inserted = uni64(inserted + 64);
             }
         };
         while (w < last_main) {
             FPROF(2);
-            insert_upto(w + 128);
+            insert_upto(w + 192);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FPROF(0);
-            // ---- every candidate of position w + lane becomes an edge (DeflatorWindow.match, :132-212)
-            const uint64_t p = w + lane;
+            // ---- every candidate of positions w + lane and w + 64 + lane becomes an edge (DeflatorWindow.match, :132-212)
+            const uint64_t pA = w + lane, pB = pA + 64;
+            const bool liveA = pA < last_main, liveB = pB < last_main;
+            const uint32_t keyA = liveA ? load32(in + pA) : 0u, keyB = liveB ? load32(in + pB) : 0u;
 #pragma unroll
-            for (int d = 0; d < 30; ++d) s.cslot[d * 64 + lane] = 0;
-            uint32_t extent = 1;
-            if (p < last_main) {
-                const uint32_t limit_run = n - p < 258 ? (uint32_t)(n - p) : 258u;
-                const uint32_t mine = ring[p & 65535];
-                const uint32_t tag = mine >> 16;
-                uint32_t d = mine & 0xffff, acc = 0;
-                int remaining = attempts;
-                bool first = true;
-                while (d) {
-                    acc += d;
-                    if (acc > wmask || (!first && acc >= wmask)) break;
-                    const uint32_t e = ring[(p - acc) & 65535];
-                    if ((e >> 16) == tag && load32(in + p - acc) == load32(in + p)) {
-                        const uint32_t run = common_prefix(in, p - acc, p, limit_run);
-                        extent = run > extent ? run : extent;
-                        const uint32_t at = dist_decade(acc) * 64 + lane;
-                        if (run > (s.cslot[at] & 0xffff)) s.cslot[at] = acc << 16 | run;
-                        first = false;
-                        remaining -= 1;
-                        if (!(remaining > 0 && goal > (int)run)) break;
-                    }
-                    d = e & 0xffff;
-                }
-            }
+            for (int d = 0; d < 30; ++d) { s.cslot[0][d * 64 + lane] = 0; s.cslot[1][d * 64 + lane] = 0; }
+            uint32_t extA = 1, extB = 1;
+            chain_walk2(in, ring, n, pA, pB, liveA, liveB, keyA, keyB, wmask, attempts, goal,
+                        [&](int which, uint32_t dist, uint32_t run) {
+                            uint32_t &ext = which ? extB : extA;
+                            ext = run > ext ? run : ext;
+                            uint32_t *slot = &s.cslot[which][dist_decade(dist) * 64 + lane];
+                            if (run > (*slot & 0xffff)) *slot = dist << 16 | run;
+                        });
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             FPROF(1);
             // ---- which positions are vertices with edges (Stream.compress full, :344-400)
             uint32_t t = 0;
-            if (!__ballot(extent > 100) && w + 64 <= last_main && unfilled() >= 64) {
-                // nothing to skip, no block to close: all 64 at once
-                if (count == 0) bbase = w;
-                const bool has = extent > 1;                   // (a candidate matched: at least the four key bytes)
-                g.flag_()[count + lane] = has ? 1 : 0;
-                if (__ballot(has))
-                    for (uint32_t i = lane; i < 64 * 30; i += 64) { const uint32_t vtx = i / 30, d = i - vtx * 30; g.slots_()[(uint64_t)count * 30 + i] = s.cslot[d * 64 + vtx]; }
-                count += 64;
-                t = 64;
-            }
-            while (t < 64 && w + t < last_main) {
+            while (t < 128 && w + t < last_main) {
+                const uint32_t hf = t >> 6, tl = t & 63;
+                const uint32_t extent = hf ? extB : extA;
+                if (tl == 0 && !__ballot(extent > 100) && w + t + 64 <= last_main && unfilled() >= 64) {
+                    // a whole half with nothing to skip and no block to close: 64 vertices at once
+                    if (count == 0) bbase = w + t;
+                    const bool has = extent > 1;               // (a candidate matched: at least the four key bytes)
+                    g.flag_()[count + lane] = has ? 1 : 0;
+                    if (__ballot(has))
+                        for (uint32_t i = lane; i < 64 * 30; i += 64) { const uint32_t vtx = i / 30, d = i - vtx * 30; g.slots_()[(uint64_t)count * 30 + i] = s.cslot[hf][d * 64 + vtx]; }
+                    count += 64;
+                    t += 64;
+                    continue;
+                }
                 if (!(unfilled() > 0)) close_block(false);
                 if (count == 0) bbase = w + t;
-                const int ext = __builtin_amdgcn_readlane((int)extent, (int)t);
-                if (ext > 1) { if (lane < 30) g.slots_()[(uint64_t)count * 30 + lane] = s.cslot[lane * 64 + t]; }
+                const int ext = __builtin_amdgcn_readlane((int)extent, (int)tl);
+                if (ext > 1) { if (lane < 30) g.slots_()[(uint64_t)count * 30 + lane] = s.cslot[hf][lane * 64 + tl]; }
                 if (lane == 0) g.flag_()[count] = ext > 1 ? 1 : 0;
                 count += 1;
                 int skip = ext - 100 < unfilled() ? ext - 100 : unfilled();
