@@ -43,6 +43,11 @@ enum {
     SPNG_E_CODELENGTH_SEQUENCE = 37,  /* invalidHuffmanCodelengthSequence */
     SPNG_E_HUFFMAN_TABLE = 38,        /* invalidHuffmanTable */
     SPNG_E_STRING_REFERENCE = 39,     /* invalidStringReference */
+    /* Gzip.StreamHeaderError, Sources/LZ77/Gzip/Gzip.StreamHeaderError.swift:4-11 (SPNG_FORMAT_GZIP) */
+    SPNG_E_GZIP_SIGIL = 24,           /* invalidSigil */
+    SPNG_E_GZIP_METHOD = 25,          /* invalidCompressionMethod(aux0) */
+    SPNG_E_GZIP_FLAG_BITS = 26,       /* invalidFlagBits(aux0) */
+    SPNG_E_GZIP_HEADER_CHECKSUM = 27, /* _headerChecksumUnsupported (FHCRC set) */
     /* PNG.DecodingError, Sources/PNG/Decoding/PNG.DecodingError.swift:5-44 */
     SPNG_E_EXTRANEOUS_IMAGE_DATA = 48,         /* extraneousImageData */
     SPNG_E_EXTRANEOUS_COMPRESSED_DATA = 49,    /* extraneousImageDataCompressedData (host side) */
@@ -63,7 +68,10 @@ enum {
 };
 
 enum { SPNG_FORMAT_ZLIB = 0,          /* LZ77.Format.zlib  (PNG.Standard.common) */
-       SPNG_FORMAT_IOS = 1 };         /* LZ77.Format.ios   (raw DEFLATE, CgBI)   */
+       SPNG_FORMAT_IOS = 1,           /* LZ77.Format.ios   (raw DEFLATE, CgBI)   */
+       SPNG_FORMAT_GZIP = 2 };        /* Gzip.Format.gzip  (Gzip.Inflator / Gzip.Deflator, Sources/LZ77/Gzip; one member:
+                                         header with FEXTRA / FNAME / FCOMMENT skipped, CRC-32 checked, ISIZE read;
+                                         spng_inflate_batch / spng_deflate_batch and their host-pointer forms only) */
 
 typedef struct spng_ctx spng_ctx;     /* owns one device, one HIP stream, its workspaces; re-entrant per handle */
 

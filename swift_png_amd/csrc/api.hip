@@ -176,6 +176,10 @@ const char *spng_status_string(int32_t s)
     case SPNG_E_ARGUMENT: return "invalid argument";
     case SPNG_E_DEVICE: return "device error";
     case SPNG_E_REFERENCE_UNDEFINED: return "stream uses a distance code the reference leaves undefined";
+    case SPNG_E_GZIP_SIGIL: return "invalid gzip sigil";
+    case SPNG_E_GZIP_METHOD: return "invalid gzip compression method";
+    case SPNG_E_GZIP_FLAG_BITS: return "invalid gzip flag bits";
+    case SPNG_E_GZIP_HEADER_CHECKSUM: return "gzip header checksum unsupported";
     default: return "unknown status";
     }
 }
@@ -438,10 +442,12 @@ struct InflatePlan {
     uint64_t tok_cap = 0;            // tokens
     uint32_t passes = 0;
     bool parallel = false;
-    size_t jobs_at = 0, streams_at = 0, segs_at = 0, done_at = 0;
+    bool gzip = false;               // some stream is SPNG_FORMAT_GZIP: header kernel in front, CRC-32 check behind
+    size_t jobs_at = 0, streams_at = 0, segs_at = 0, done_at = 0, gz_at = 0, gzparts_at = 0;
     size_t bytes() const
     {
-        return jobs.size() * (sizeof(InflateJob) + sizeof(PStream) + 4) + segs.size() * sizeof(PSeg) + 2048;
+        return jobs.size() * (sizeof(InflateJob) + sizeof(PStream) + 4 + (gzip ? 8 + 4 * (size_t)gzip_pieces() : 0)) +
+               segs.size() * sizeof(PSeg) + 4096;
     }
 };
 
@@ -452,6 +458,7 @@ struct InflatePlan {
 static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
 {
     p.parallel = c->cfg[SPNG_CFG_INFLATE_MODE] != SPNG_INFLATE_SERIAL && !p.jobs.empty();
+    for (auto &j : p.jobs) p.gzip = p.gzip || j.format == SPNG_FORMAT_GZIP;
     if (!p.parallel) return SPNG_DONE;
     uint64_t total = 0;
     for (auto &j : p.jobs) total += j.src_len;
@@ -533,9 +540,11 @@ static void stage_inflate(InflatePlan &p, Arena &a)
     if (p.parallel) {
         p.streams_at = a.take(n * sizeof(PStream));
         p.segs_at = a.take(p.segs.size() * sizeof(PSeg));
-        p.done_at = a.take(n * 4);
         memcpy(a.host<PStream>(p.streams_at), p.streams.data(), n * sizeof(PStream));
         memcpy(a.host<PSeg>(p.segs_at), p.segs.data(), p.segs.size() * sizeof(PSeg));
+    }
+    if (p.parallel || p.gzip) {
+        p.done_at = a.take(n * 4);
         memset(a.host<int32_t>(p.done_at), 0, n * 4);
         for (size_t i = 0; i < n; ++i) p.jobs[i].skip = a.dev<int32_t>(p.done_at) + i;
     }
@@ -545,6 +554,9 @@ static void stage_inflate(InflatePlan &p, Arena &a)
 static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_result *dr)
 {
     const uint32_t n = (uint32_t)p.jobs.size();
+    if (p.gzip)   // (slots behind the uploaded part of the arena: the header kernel fills them)
+        HIP_TRY(launch_gzip_pre(a.dev<InflateJob>(p.jobs_at), p.parallel ? a.dev<PStream>(p.streams_at) : nullptr, dr,
+                                a.dev<uint64_t>(p.gz_at), a.dev<int32_t>(p.done_at), n, c->stream));
     if (p.parallel) {
         Timed whole(c, SPNG_K_PINFLATE);
         PStream *ds = a.dev<PStream>(p.streams_at);
@@ -579,8 +591,13 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
             }
         }
     }
-    Timed t(c, SPNG_K_INFLATE);
-    HIP_TRY(launch_inflate(a.dev<InflateJob>(p.jobs_at), n, dr, c->stream));
+    {
+        Timed t(c, SPNG_K_INFLATE);
+        HIP_TRY(launch_inflate(a.dev<InflateJob>(p.jobs_at), n, dr, c->stream));
+    }
+    if (p.gzip)
+        HIP_TRY(launch_gzip_inflate_post(a.dev<InflateJob>(p.jobs_at), dr, a.dev<uint64_t>(p.gz_at), a.dev<uint32_t>(p.gzparts_at), n,
+                                         c->stream));
     return SPNG_DONE;
 }
 
@@ -607,7 +624,8 @@ int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t 
     InflatePlan plan;
     plan.jobs.resize(count);
     for (uint32_t i = 0; i < count; ++i) {
-        if ((!descs[i].d_src && descs[i].src_len) || (!descs[i].d_dst && descs[i].dst_cap)) return SPNG_E_ARGUMENT;
+        if ((!descs[i].d_src && descs[i].src_len) || (!descs[i].d_dst && descs[i].dst_cap) || descs[i].format < SPNG_FORMAT_ZLIB ||
+            descs[i].format > SPNG_FORMAT_GZIP) return SPNG_E_ARGUMENT;
         plan.jobs[i] = InflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst,
                                   descs[i].src_len, descs[i].dst_cap, descs[i].format, i, nullptr};
     }
@@ -617,6 +635,7 @@ int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t 
     stage_inflate(plan, a);
     const size_t upload = a.off;
     const size_t res = a.take(count * sizeof(spng_result));
+    if (plan.gzip) { plan.gz_at = a.take(count * 8); plan.gzparts_at = a.take((size_t)count * 4 * gzip_pieces()); }
     if (int32_t st = c->upload(0, upload)) return st;
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
     poison_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, count);
@@ -680,7 +699,7 @@ int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
     ip.jobs.resize(count);
     for (uint32_t i = 0; i < count; ++i) {
         const spng_image_desc &d = descs[i];
-        if (!d.d_idat && d.idat_len) return SPNG_E_ARGUMENT;
+        if ((!d.d_idat && d.idat_len) || (d.format != SPNG_FORMAT_ZLIB && d.format != SPNG_FORMAT_IOS)) return SPNG_E_ARGUMENT;
         ip.jobs[i] = InflateJob{(const uint8_t *)d.d_idat, (uint8_t *)d.d_rows, d.idat_len, d.rows_cap, d.format, i, nullptr};
     }
     if (int32_t st = plan_inflate(c, ip)) return st;
@@ -1019,12 +1038,13 @@ int32_t spng_unpack(spng_ctx *c, const void *storage, uint32_t w, uint32_t h, in
     return SPNG_DONE;
 }
 
-uint64_t spng_deflate_bound(uint64_t n) { return n + n / 4 + 4096; }
+uint64_t spng_deflate_bound(uint64_t n) { return n + n / 4 + 4096; }   // (covers the 18 bytes of a gzip wrapper too)
 
 // shared by spng_deflate_batch / spng_encode_batch.  Per-stream link rings live in a context-owned slab; so
 // does the match graph of the levels >= 8 (129 bytes per vertex, up to 2^21 vertices per stream): those
 // streams are launched in groups that fit the slab, one group after the other on the stream.
-static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_result *dr, Arena &a, size_t jslot)
+static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_result *dr, Arena &a, size_t jslot,
+                              size_t gzparts = (size_t)-1)
 {
     const size_t ring_bytes = (size_t)jobs.size() * 65536 * 4;
     if (ring_bytes > c->ring_cap) {
@@ -1078,10 +1098,15 @@ static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_r
     }
     memcpy(a.host<DeflateJob>(jslot), sorted.data(), sorted.size() * sizeof(DeflateJob));
     if (int32_t st = c->upload(jslot, jslot + sorted.size() * sizeof(DeflateJob))) return st;
-    Timed t(c, SPNG_K_DEFLATE);
-    if (nfast) HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)nfast, dr, c->stream));
-    for (auto &gr : groups)
-        HIP_TRY(launch_deflate_full(a.dev<DeflateJob>(jslot) + gr.first, (uint32_t)(gr.second - gr.first), dr, c->stream));
+    {
+        Timed t(c, SPNG_K_DEFLATE);
+        if (nfast) HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)nfast, dr, c->stream));
+        for (auto &gr : groups)
+            HIP_TRY(launch_deflate_full(a.dev<DeflateJob>(jslot) + gr.first, (uint32_t)(gr.second - gr.first), dr, c->stream));
+    }
+    // gzip members: CRC-32 and byte count of the input behind the stream (DeflatorBuffers.swift:96-135)
+    if (gzparts != (size_t)-1)
+        HIP_TRY(launch_gzip_deflate_post(a.dev<DeflateJob>(jslot), dr, a.dev<uint32_t>(gzparts), (uint32_t)sorted.size(), c->stream));
     return SPNG_DONE;
 }
 
@@ -1093,20 +1118,24 @@ int32_t spng_deflate_batch(spng_ctx *c, const spng_stream_desc *descs, const int
     HIP_TRY(hipSetDevice(c->device));
     std::lock_guard<std::mutex> g(c->mu);
     std::vector<DeflateJob> jobs(count);
+    bool gzip = false;
     for (uint32_t i = 0; i < count; ++i) {
         // spng_stream_desc.reserved: window exponent 8 ... 15 (0 = 15, as PNG always uses)
         const int32_t e = descs[i].reserved ? descs[i].reserved : 15;
-        if ((!descs[i].d_src && descs[i].src_len) || !descs[i].d_dst || e < 8 || e > 15) return SPNG_E_ARGUMENT;
+        if ((!descs[i].d_src && descs[i].src_len) || !descs[i].d_dst || e < 8 || e > 15 || descs[i].format < SPNG_FORMAT_ZLIB ||
+            descs[i].format > SPNG_FORMAT_GZIP) return SPNG_E_ARGUMENT;
+        gzip = gzip || descs[i].format == SPNG_FORMAT_GZIP;
         jobs[i] = DeflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst, descs[i].src_len,
                              descs[i].dst_cap, nullptr, descs[i].format, levels[i], i,
                              descs[i].format == SPNG_FORMAT_IOS ? 15u : (uint32_t)e, nullptr, 0, 0};
     }
-    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result)) + 1024)) return st;
+    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 2048)) return st;
     Arena a{c};
     const size_t jslot = a.take(count * sizeof(DeflateJob));
     const size_t res = a.take(count * sizeof(spng_result));
+    const size_t gzparts = gzip ? a.take((size_t)count * 4 * gzip_pieces()) : (size_t)-1;
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
-    if (int32_t st = deflate_launch(c, jobs, dr, a, jslot)) return st;
+    if (int32_t st = deflate_launch(c, jobs, dr, a, jslot, gzparts)) return st;
     if (h_results) {
         HIP_TRY(hipMemcpyAsync(h_results, dr, count * sizeof(spng_result), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

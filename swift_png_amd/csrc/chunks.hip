@@ -15,66 +15,9 @@
 // crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / P (the raw, zero-initialised CRC is linear), the
 // per-level shift factor being the previous one squared; the < 64 leftover bytes go through the table.
 #include "common.hpp"
+#include "crc32.hpp"
 
 namespace spng {
-
-typedef uint8_t __attribute__((address_space(1))) gbyte;
-#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)UNI(v >> 32) << 32 | UNI((uint32_t)v); }
-#define LSYNC() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
-
-static constexpr uint32_t POLY = 0xedb88320u;
-
-// a * b mod P, reflected bit order (bit 31 = x^0)
-__host__ __device__ inline uint32_t multmodp(uint32_t a, uint32_t b)
-{
-    uint32_t m = 1u << 31, p = 0;
-    for (;;) {
-        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
-        m >>= 1;
-        b = b & 1 ? (b >> 1) ^ POLY : b >> 1;
-    }
-    return p;
-}
-// x^(8 n) mod P
-__host__ __device__ inline uint32_t xpow8(uint64_t n)
-{
-    uint32_t r = 1u << 31, base = 1u << 23;                    // x^0, x^8
-    while (n) { if (n & 1) r = multmodp(base, r); base = multmodp(base, base); n >>= 1; }
-    return r;
-}
-
-__device__ __forceinline__ void crc_table(uint32_t *tab, int lane)
-{
-    for (int i = lane; i < 256; i += 64) {
-        uint32_t c = (uint32_t)i;
-        for (int k = 0; k < 8; ++k) c = c & 1 ? (c >> 1) ^ POLY : c >> 1;
-        tab[i] = c;
-    }
-    LSYNC();
-}
-
-// standard CRC-32 of p[0 .. n), continuing from `crc` (a finished CRC-32 value; 0 for a fresh one); wave-uniform result
-__device__ __forceinline__ uint32_t wave_crc32(const uint32_t *tab, const gbyte *p, uint64_t n, uint32_t crc, int lane)
-{
-    const uint64_t L = n / 64;
-    uint32_t c = 0;
-    if (L) {
-        const gbyte *q = p + (uint64_t)lane * L;
-        for (uint64_t i = 0; i < L; ++i) c = tab[(c ^ q[i]) & 0xff] ^ (c >> 8);
-        uint32_t pw = xpow8(L);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const uint32_t other = (uint32_t)__shfl_down((int)c, 1 << k, 64);
-            if ((lane & ((2 << k) - 1)) == 0) c = multmodp(pw, c) ^ other;
-            pw = multmodp(pw, pw);
-        }
-        c = UNI(c);
-    }
-    for (uint64_t i = 64 * L; i < n; ++i) c = tab[(c ^ UNI(p[i])) & 0xff] ^ (c >> 8);
-    // the raw CRC of the bytes; now the initial value (the running CRC, un-finalised) shifted past them
-    return c ^ multmodp(xpow8(n), crc ^ 0xffffffffu) ^ 0xffffffffu;
-}
 
 __device__ __forceinline__ uint32_t be32(const gbyte *p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 

@@ -135,6 +135,15 @@ hipError_t launch_pinf_emit(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, ui
 hipError_t launch_pinf_resolve(PStream *d_streams, uint32_t nstreams, uint32_t *d_tokens, spng_result *d_results, int32_t *d_done,
                                uint32_t pass, hipStream_t stream);
 hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
+// gzip.hip
+static constexpr uint64_t GZ_NONE = ~0ull;
+uint32_t   gzip_pieces();
+hipError_t launch_gzip_pre(InflateJob *d_jobs, PStream *d_streams, spng_result *d_results, uint64_t *d_gz, int32_t *d_done,
+                           uint32_t count, hipStream_t stream);
+hipError_t launch_gzip_inflate_post(const InflateJob *d_jobs, spng_result *d_results, const uint64_t *d_gz, uint32_t *d_parts,
+                                    uint32_t count, hipStream_t stream);
+hipError_t launch_gzip_deflate_post(const DeflateJob *d_jobs, spng_result *d_results, uint32_t *d_parts, uint32_t count,
+                                    hipStream_t stream);
 hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 uint64_t deflate_graph_vertices(uint64_t n);
 uint64_t deflate_graph_bytes(uint64_t vertices);

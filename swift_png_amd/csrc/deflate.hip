@@ -603,6 +603,10 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         const uint32_t unpaired = (UNI(jp->exponent) - 8) << 4 | 0x08;
         const uint32_t check = ~(((unpaired << 8 | unpaired >> 8) & 0xffff) % 31) & 31;
         put(s, b, check << 8 | unpaired, 16, lane);
+    } else if (job.format == SPNG_FORMAT_GZIP) {
+        // Gzip.StreamHeader.write (Gzip.StreamHeader.swift:84-96): sigil, method 8, no flags, MTIME 0, XFL 0, OS 255;
+        // the trailer (CRC-32, byte count) is appended by gzip.hip
+        put(s, b, 0x8b1f, 16, lane); put(s, b, 0x0008, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0xff00, 16, lane);
     }
     for (int i = lane; i <= (1 << HBITS); i += 64) s.head[i] = NONE;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -866,20 +870,30 @@ __device__ __attribute__((noinline)) void full_forward(const FullArrays g, const
                 const uint32_t Dk = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kq);
                 const uint32_t run = lane < 30 ? s.batch[kq * 30 + lane] & 0xffffu : 0u;
                 unsigned long long m = __ballot(run > 0);
+                // Of the decades that reach a length, only the cheapest (first among equals: the lowest) can be
+                // the way into that target from this vertex: one key per length instead of one per decade.
+                uint32_t bc[4] = {~0u, ~0u, ~0u, ~0u}, bd[4] = {0, 0, 0, 0}, reach = 0;
                 while (m) {
                     const int dec = __ffsll((long long)m) - 1;
                     m &= m - 1;
                     const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)run, dec);
                     const uint32_t maxlen = r < rem ? r : rem;
-                    const uint32_t base = Dk + (uint32_t)__builtin_amdgcn_readlane((int)dcost, dec);
+                    const uint32_t dc = (uint32_t)__builtin_amdgcn_readlane((int)dcost, dec);
+                    reach = maxlen > reach ? maxlen : reach;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (3u + 64u * j > maxlen) break;
                         const uint32_t L = 3u + (uint32_t)lane + 64u * j;
-                        if (L <= maxlen) {
-                            const uint64_t key = (uint64_t)(base + rc[j]) << 32 | (258u - L) << 8 | ((uint32_t)dec + 1u);
-                            __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
+                        if (L <= maxlen && dc < bc[j]) { bc[j] = dc; bd[j] = (uint32_t)dec; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (3u + 64u * j > reach) break;
+                    const uint32_t L = 3u + (uint32_t)lane + 64u * j;
+                    if (bc[j] != ~0u) {
+                        const uint64_t key = (uint64_t)(Dk + bc[j] + rc[j]) << 32 | (258u - L) << 8 | (bd[j] + 1u);
+                        __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
@@ -1062,6 +1076,10 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
         const uint32_t unpaired = (UNI(jp->exponent) - 8) << 4 | 0x08;
         const uint32_t check = ~(((unpaired << 8 | unpaired >> 8) & 0xffff) % 31) & 31;
         put(s, b, check << 8 | unpaired, 16, lane);
+    } else if (job.format == SPNG_FORMAT_GZIP) {
+        // Gzip.StreamHeader.write (Gzip.StreamHeader.swift:84-96): sigil, method 8, no flags, MTIME 0, XFL 0, OS 255;
+        // the trailer (CRC-32, byte count) is appended by gzip.hip
+        put(s, b, 0x8b1f, 16, lane); put(s, b, 0x0008, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0xff00, 16, lane);
     }
     for (int i = lane; i <= (1 << HBITS); i += 64) s.head[i] = NONE;
     for (uint32_t i = lane; i < 542; i += 64) s.depths[i] = (uint8_t)depth_default(i);

@@ -1209,17 +1209,11 @@ __global__ __launch_bounds__(RT, 4) void pinf_resolve_kernel(const PStream *__re
     }
 }
 
-__global__ void pinf_clear_kernel(int32_t *done, uint32_t count)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) done[i] = 0;
-}
-
 // ---- host ------------------------------------------------------------------------------------------
 // The pipeline stage by stage (api.hip times each launch separately): find -> count -> scan -> per pass {emit, resolve}.
 hipError_t launch_pinf_find(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t nsegs, int32_t *d_done, hipStream_t stream)
 {
-    pinf_clear_kernel<<<(nstreams + 255) / 256, 256, 0, stream>>>(d_done, nstreams);
+    (void)d_done; (void)nstreams;                               // (the flags arrive zeroed with the staged plan; the gzip header kernel may have set some)
     pinf_find_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs);
     return hipGetLastError();
 }
