@@ -24,13 +24,14 @@ LIB_PATH = Path(os.environ.get("SPNG_LIB", _HERE / "libspng_mi355.so"))   # SPNG
 # ---- status vocabulary (include/spng_mi355.h) -------------------------------------------------
 DONE, NEED_MORE_INPUT = 0, 1
 E_COMPRESSION_METHOD, E_WINDOW_SIZE, E_CHECK_BITS, E_DICTIONARY = 16, 17, 18, 19
+E_GZIP_SIGIL, E_GZIP_METHOD, E_GZIP_FLAG_BITS, E_GZIP_HEADER_CHECKSUM = 24, 25, 26, 27
 (E_STREAM_CHECKSUM, E_BLOCK_TYPE, E_BLOCK_COUNT_PARITY, E_RUNLITERAL_COUNT, E_CODELENGTH_TABLE,
  E_CODELENGTH_SEQUENCE, E_HUFFMAN_TABLE, E_STRING_REFERENCE) = range(32, 40)
 E_EXTRANEOUS_IMAGE_DATA, E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM = 48, 49, 50
 E_OUTPUT_CAPACITY, E_ARGUMENT, E_DEVICE, E_REFERENCE_UNDEFINED = 64, 65, 66, 67
 (E_TRUNCATED_SIGNATURE, E_SIGNATURE, E_TRUNCATED_CHUNK_HEADER, E_TRUNCATED_CHUNK_BODY, E_CHUNK_TYPE,
  E_CHUNK_CHECKSUM) = range(80, 86)
-FORMAT_ZLIB, FORMAT_IOS = 0, 1
+FORMAT_ZLIB, FORMAT_IOS, FORMAT_GZIP = 0, 1, 2
 K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER, K_PINFLATE = 0, 1, 2, 3, 4, 5, 6
 K_UNPACK = 7
 K_PINF_FIND, K_PINF_COUNT, K_PINF_EMIT, K_PINF_RESOLVE = 8, 9, 10, 11
@@ -94,6 +95,10 @@ class StreamHeaderError(SpngError):      # LZ77.StreamHeaderError
     pass
 
 
+class GzipStreamHeaderError(SpngError):  # Gzip.StreamHeaderError
+    pass
+
+
 class DecompressionError(SpngError):     # LZ77.DecompressionError
     pass
 
@@ -108,6 +113,7 @@ class LexingError(SpngError):            # PNG.LexingError
 
 _NAMES = {
     16: "invalidCompressionMethod", 17: "invalidWindowSize", 18: "invalidCheckBits", 19: "unexpectedDictionary",
+    24: "invalidSigil", 25: "invalidCompressionMethod", 26: "invalidFlagBits", 27: "_headerChecksumUnsupported",
     32: "invalidStreamChecksum", 33: "invalidBlockTypeCode", 34: "invalidBlockElementCountParity",
     35: "invalidHuffmanRunLiteralSymbolCount", 36: "invalidHuffmanCodelengthHuffmanTable",
     37: "invalidHuffmanCodelengthSequence", 38: "invalidHuffmanTable", 39: "invalidStringReference",
@@ -122,6 +128,8 @@ _NAMES = {
 def raise_for(status, aux=(0, 0)):
     if status in (DONE, NEED_MORE_INPUT):
         return
+    if 24 <= status < 28:
+        raise GzipStreamHeaderError(status, aux)
     if 16 <= status < 32:
         raise StreamHeaderError(status, aux)
     if 32 <= status < 48:

@@ -8,7 +8,7 @@ construction; the streaming cost model is not -- see DESIGN.md "Out of scope").
 """
 from __future__ import annotations
 
-from . import (DONE, FORMAT_IOS, FORMAT_ZLIB, NEED_MORE_INPUT, DecodingError,
+from . import (DONE, FORMAT_GZIP, FORMAT_IOS, FORMAT_ZLIB, NEED_MORE_INPUT, DecodingError,
                E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM, E_OUTPUT_CAPACITY)
 
 _DELAY_FORMATS = {1: (8, 1), 2: (8, 2), 3: (8, 3), 4: (8, 4), 6: (16, 3), 8: (16, 4)}
@@ -106,6 +106,41 @@ class LZ77:
                 return None
             data, self._cursor = self._out[self._cursor:], len(self._out)
             return data
+
+
+class Gzip:
+    """Gzip (Sources/LZ77/Gzip/Gzip.swift:1-47): the LZ77 codec behind a gzip member -- header with FEXTRA / FNAME /
+    FCOMMENT skipped, CRC-32 checked, ISIZE read (Gzip.StreamHeader.swift:17-97, LZ77.InflatorBuffers.swift:139-230);
+    on the way out the fixed ten-byte header and the CRC-32 / byte-count trailer (LZ77.DeflatorBuffers.swift:96-135)."""
+
+    class Inflator(LZ77.Inflator):
+        """Gzip.Inflator (Gzip.Inflator.swift:1-58): init(), push(_:), pull(_:), pull()."""
+
+        def __init__(self, session=None):
+            super().__init__(FORMAT_GZIP, session)
+
+    class Deflator(LZ77.Deflator):
+        """Gzip.Deflator (Gzip.Deflator.swift:1-40): init(level:exponent:hint:), push(_:last:), pull(), pop()."""
+
+        def __init__(self, level, exponent=15, hint=1 << 12, session=None):
+            super().__init__(FORMAT_GZIP, level, exponent, hint, session)
+
+    @staticmethod
+    def extract(data, session=None) -> bytes:
+        """Gzip.extract(from:) (Gzip.swift:5-11)"""
+        inflator = Gzip.Inflator(session)
+        inflator.push(data)
+        return inflator.pull()
+
+    @staticmethod
+    def archive(data, level=7, hint=128 << 10, session=None) -> bytes:
+        """Gzip.archive(bytes:level:hint:) (Gzip.swift:32-46)"""
+        deflator = Gzip.Deflator(level, hint=hint, session=session)
+        deflator.push(data, last=True)
+        out = b""
+        while (part := deflator.pull()) is not None:
+            out += part
+        return out
 
 
 class PNG:
