@@ -154,6 +154,19 @@ int32_t spng_profile_get(spng_ctx *ctx, int kernel, double *total_ms, uint64_t *
 int32_t spng_inflate_batch(spng_ctx *ctx, const spng_stream_desc *descs, uint32_t count,
                            spng_result *d_results, spng_result *h_results);
 
+/* LZ77.Inflator.push for streams that arrive in pieces (LZ77.Inflator.swift:30-61; PNG.Context.push(data:), one call per
+ * IDAT chunk, PNG.Context.swift:88-102): the device-side counterpart of the reference's resumable state machine
+ * (LZ77.InflatorState / BlockState), at block granularity.  d_src / src_len: ALL compressed bytes received so far
+ * (the caller appends to its device buffer); d_dst: the output so far, kept between calls.  h_state: two words per
+ * stream, {first bit of the first block that was not complete yet, inflated bytes in front of it}, as the previous call
+ * returned them in spng_result.aux of a SPNG_NEED_MORE_INPUT result ({0, 0} or a NULL array: nothing seen yet).
+ * Blocks the input now holds completely are decoded by the parallel pipeline exactly once; only the block the input
+ * ends in is decoded again by the next call.  Results as spng_inflate_batch (written / consumed count from the start
+ * of the stream; the zlib checksum is verified over the whole output by the call that reports SPNG_DONE); formats
+ * SPNG_FORMAT_ZLIB and SPNG_FORMAT_IOS. */
+int32_t spng_inflate_resume_batch(spng_ctx *ctx, const spng_stream_desc *descs, const uint64_t *h_state, uint32_t count,
+                                  spng_result *d_results, spng_result *h_results);
+
 /* replaces the row walker PNG.Decoder.push (PNG.Decoder.swift:59-148), PNG.Decoder.defilter
  * (:152-196) and PNG.Image.assign (PNG.Image.swift:186-285).  d_rows_len: device array of the
  * number of valid bytes in each d_rows (NULL = U for every image). */

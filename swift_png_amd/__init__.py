@@ -41,7 +41,7 @@ INFLATE_AUTO, INFLATE_SERIAL = 0, 1
 EXPORTS = [
     "spng_version", "spng_status_string", "spng_last_error_string", "spng_inflated_size",
     "spng_storage_size", "spng_create", "spng_destroy", "spng_stream", "spng_sync", "spng_profile",
-    "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_unfilter_batch", "spng_decode_batch",
+    "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_inflate_resume_batch", "spng_unfilter_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
     "spng_lex_batch", "spng_write_idat_batch", "spng_crc32", "spng_unpack_batch", "spng_unpack", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
 ]
@@ -181,6 +181,7 @@ def load_library():
     lib.spng_profile.argtypes = [vp, ctypes.c_int]
     lib.spng_profile_get.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
     lib.spng_inflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), u32, vp, rp]
+    lib.spng_inflate_resume_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), ctypes.POINTER(ctypes.c_uint64), u32, vp, rp]
     lib.spng_unfilter_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, vp, rp]
     lib.spng_decode_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, rp]
     lib.spng_filter_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, rp]
@@ -299,6 +300,17 @@ class Session:
         res = (Result * n)()
         _check(self.lib, self.lib.spng_inflate_batch(self.ctx, descs, n, None, res))
         return outs, list(res)
+
+    def inflate_resume(self, src, src_len, dst, fmt=FORMAT_ZLIB, state=(0, 0)):
+        """One push of a stream that arrives in pieces (spng_inflate_resume_batch): src / dst are device tensors that
+        hold ALL compressed bytes so far (src_len of them) / the output so far; state is what the previous call
+        returned.  -> (Result, next state)"""
+        desc = (StreamDesc * 1)(StreamDesc(self._ptr(src), int(src_len), self._ptr(dst), dst.numel(), fmt, 0))
+        st = (ctypes.c_uint64 * 2)(int(state[0]), int(state[1]))
+        res = (Result * 1)()
+        _check(self.lib, self.lib.spng_inflate_resume_batch(self.ctx, desc, st, 1, None, res))
+        r = res[0]
+        return r, ((r.aux[0], r.aux[1]) if r.status == NEED_MORE_INPUT else tuple(state))
 
     def image_desc(self, idat, rows, storage, w, h, depth, channels, interlaced, fmt=FORMAT_ZLIB, rows_cap=None):
         return ImageDesc(self._ptr(idat), idat.numel() if idat is not None else 0, self._ptr(rows),

@@ -443,11 +443,13 @@ struct InflatePlan {
     uint32_t passes = 0;
     bool parallel = false;
     bool gzip = false;               // some stream is SPNG_FORMAT_GZIP: header kernel in front, CRC-32 check behind
-    size_t jobs_at = 0, streams_at = 0, segs_at = 0, done_at = 0, gz_at = 0, gzparts_at = 0;
+    std::vector<uint64_t> state;     // spng_inflate_resume_batch: {bit, written} per stream (else empty)
+    size_t jobs_at = 0, streams_at = 0, segs_at = 0, done_at = 0, gz_at = 0, gzparts_at = 0, state_at = 0, sumparts_at = 0;
     size_t bytes() const
     {
-        return jobs.size() * (sizeof(InflateJob) + sizeof(PStream) + 4 + (gzip ? 8 + 4 * (size_t)gzip_pieces() : 0)) +
-               segs.size() * sizeof(PSeg) + 4096;
+        return jobs.size() * (sizeof(InflateJob) + sizeof(PStream) + 4 + (gzip ? 8 + 4 * (size_t)gzip_pieces() : 0) +
+                              (state.empty() ? 0 : 16 + 8 * (size_t)gzip_pieces())) +
+               segs.size() * sizeof(PSeg) + 8192;
     }
 };
 
@@ -476,6 +478,7 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         memset(&st, 0, sizeof st);
         st.src = j.src; st.dst = j.dst; st.src_len = j.src_len; st.dst_cap = j.dst_cap;
         st.format = j.format; st.image = j.image;
+        if (!p.state.empty()) { st.start_bit = p.state[2 * i]; st.out_pos = p.state[2 * i + 1]; }
         st.seg_first = (uint32_t)p.segs.size();
         uint64_t k = (j.src_len + seg_bytes - 1) / seg_bytes;
         if (k < 1) k = 1;
@@ -537,6 +540,14 @@ static void stage_inflate(InflatePlan &p, Arena &a)
 {
     const size_t n = p.jobs.size();
     p.jobs_at = a.take(n * sizeof(InflateJob));
+    if (!p.state.empty()) {
+        p.state_at = a.take(n * 16);
+        memcpy(a.host<uint64_t>(p.state_at), p.state.data(), n * 16);
+        for (size_t i = 0; i < n; ++i) {
+            p.jobs[i].state = a.dev<uint64_t>(p.state_at) + 2 * i;
+            if (p.parallel) p.streams[i].state = p.jobs[i].state;
+        }
+    }
     if (p.parallel) {
         p.streams_at = a.take(n * sizeof(PStream));
         p.segs_at = a.take(p.segs.size() * sizeof(PSeg));
@@ -598,6 +609,8 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
     if (p.gzip)
         HIP_TRY(launch_gzip_inflate_post(a.dev<InflateJob>(p.jobs_at), dr, a.dev<uint64_t>(p.gz_at), a.dev<uint32_t>(p.gzparts_at), n,
                                          c->stream));
+    if (!p.state.empty())   // the zlib checksum of a stream that finished in this call, over all of its bytes
+        HIP_TRY(launch_resume_post(a.dev<InflateJob>(p.jobs_at), dr, a.dev<uint64_t>(p.sumparts_at), n, c->stream));
     return SPNG_DONE;
 }
 
@@ -614,8 +627,8 @@ static const uint64_t *rows_len_in_array(void *user, uint32_t i)
 
 extern "C" {
 
-int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t count,
-                           spng_result *d_results, spng_result *h_results)
+static int32_t inflate_batch(spng_ctx *c, const spng_stream_desc *descs, const uint64_t *h_state, bool resume, uint32_t count,
+                             spng_result *d_results, spng_result *h_results)
 {
     if (!c || (!descs && count) || (!d_results && !h_results && count)) return SPNG_E_ARGUMENT;
     if (!count) return SPNG_DONE;
@@ -623,11 +636,17 @@ int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t 
     std::lock_guard<std::mutex> g(c->mu);
     InflatePlan plan;
     plan.jobs.resize(count);
+    if (resume) plan.state.assign((size_t)count * 2, 0);
     for (uint32_t i = 0; i < count; ++i) {
         if ((!descs[i].d_src && descs[i].src_len) || (!descs[i].d_dst && descs[i].dst_cap) || descs[i].format < SPNG_FORMAT_ZLIB ||
-            descs[i].format > SPNG_FORMAT_GZIP) return SPNG_E_ARGUMENT;
+            descs[i].format > (resume ? SPNG_FORMAT_IOS : SPNG_FORMAT_GZIP)) return SPNG_E_ARGUMENT;
         plan.jobs[i] = InflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst,
-                                  descs[i].src_len, descs[i].dst_cap, descs[i].format, i, nullptr};
+                                  descs[i].src_len, descs[i].dst_cap, descs[i].format, i, nullptr, nullptr};
+        if (resume && h_state) {
+            plan.state[2 * i] = h_state[2 * i]; plan.state[2 * i + 1] = h_state[2 * i + 1];
+            // (a state is only ever what an earlier call handed out: inside the input and the output)
+            if (plan.state[2 * i] > descs[i].src_len * 8 || plan.state[2 * i + 1] > descs[i].dst_cap) return SPNG_E_ARGUMENT;
+        }
     }
     if (int32_t st = plan_inflate(c, plan)) return st;
     if (int32_t st = c->reserve(plan.bytes() + count * sizeof(spng_result) + 1024)) return st;
@@ -636,6 +655,7 @@ int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t 
     const size_t upload = a.off;
     const size_t res = a.take(count * sizeof(spng_result));
     if (plan.gzip) { plan.gz_at = a.take(count * 8); plan.gzparts_at = a.take((size_t)count * 4 * gzip_pieces()); }
+    if (resume) plan.sumparts_at = a.take((size_t)count * 8 * gzip_pieces());
     if (int32_t st = c->upload(0, upload)) return st;
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
     poison_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, count);
@@ -646,6 +666,18 @@ int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t 
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return SPNG_DONE;
+}
+
+int32_t spng_inflate_batch(spng_ctx *c, const spng_stream_desc *descs, uint32_t count,
+                           spng_result *d_results, spng_result *h_results)
+{
+    return inflate_batch(c, descs, nullptr, false, count, d_results, h_results);
+}
+
+int32_t spng_inflate_resume_batch(spng_ctx *c, const spng_stream_desc *descs, const uint64_t *h_state, uint32_t count,
+                                  spng_result *d_results, spng_result *h_results)
+{
+    return inflate_batch(c, descs, h_state, true, count, d_results, h_results);
 }
 
 int32_t spng_unfilter_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t count,
@@ -700,7 +732,7 @@ int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
     for (uint32_t i = 0; i < count; ++i) {
         const spng_image_desc &d = descs[i];
         if ((!d.d_idat && d.idat_len) || (d.format != SPNG_FORMAT_ZLIB && d.format != SPNG_FORMAT_IOS)) return SPNG_E_ARGUMENT;
-        ip.jobs[i] = InflateJob{(const uint8_t *)d.d_idat, (uint8_t *)d.d_rows, d.idat_len, d.rows_cap, d.format, i, nullptr};
+        ip.jobs[i] = InflateJob{(const uint8_t *)d.d_idat, (uint8_t *)d.d_rows, d.idat_len, d.rows_cap, d.format, i, nullptr, nullptr};
     }
     if (int32_t st = plan_inflate(c, ip)) return st;
     // two-phase: we need the device address of the results before planning

@@ -70,6 +70,9 @@ struct InflateJob {
     int32_t        format;
     uint32_t       image;
     const int32_t *skip;          // device flag: non-zero = the parallel pipeline already produced this stream
+    // spng_inflate_resume_batch: {first bit of the first block not decoded completely yet, inflated bytes in front
+    // of it}; the pipeline moves it forward, the serial kernel starts there.  Null: a whole stream from bit 0.
+    uint64_t      *state;
 };
 
 // ---- the parallel inflate pipeline (pinflate.hip) -----------------------------------------------
@@ -85,10 +88,14 @@ struct PStream {
     // device side
     uint64_t       tok_base, ntok;         // its tokens in the token buffer (of its pass)
     uint64_t       end_bit;                // first bit after the final block
-    int32_t        ok;                     // the segment chain holds from the first bit to a final block
+    int32_t        ok;                     // 1: the segment chain holds from the first bit to a final block; 2 (resumable
+                                           // streams): up to the first block the input does not hold completely
     uint32_t       pass;
+    // resumable streams (spng_inflate_resume_batch): where to start, and where to note how far the chain got
+    uint64_t       start_bit, out_pos;
+    uint64_t      *state;
 };
-enum { PSEG_FAIL = 0, PSEG_CONT = 1, PSEG_FINAL = 2 };
+enum { PSEG_FAIL = 0, PSEG_CONT = 1, PSEG_FINAL = 2, PSEG_PARTIAL = 3 };
 // One segment: the blocks that start in [index * seg_bytes, (index + 1) * seg_bytes).
 struct PSeg {
     uint32_t stream, index;
@@ -144,6 +151,7 @@ hipError_t launch_gzip_inflate_post(const InflateJob *d_jobs, spng_result *d_res
                                     uint32_t count, hipStream_t stream);
 hipError_t launch_gzip_deflate_post(const DeflateJob *d_jobs, spng_result *d_results, uint32_t *d_parts, uint32_t count,
                                     hipStream_t stream);
+hipError_t launch_resume_post(const InflateJob *d_jobs, spng_result *d_results, uint64_t *d_parts, uint32_t count, hipStream_t stream);
 hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 uint64_t deflate_graph_vertices(uint64_t n);
 uint64_t deflate_graph_bytes(uint64_t vertices);

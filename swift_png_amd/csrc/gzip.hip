@@ -22,6 +22,12 @@
 namespace spng {
 
 static constexpr uint32_t GZ_PIECES = 256;
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
+    return v;
+}
 
 __device__ __forceinline__ uint32_t le32(const gbyte *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
 
@@ -88,12 +94,13 @@ __device__ __forceinline__ void piece_crc(const uint32_t *tab, const gbyte *p, u
 __device__ __forceinline__ uint32_t fold_pieces(const uint32_t *part, uint64_t n)
 {
     const uint64_t len = piece_len(n);
+    const uint32_t whole = xpow8(len);                        // (every piece but the last has this length)
     uint32_t acc = 0;
     for (uint32_t k = 0; k < GZ_PIECES; ++k) {
         const uint64_t from = (uint64_t)k * len;
         if (from >= n) break;
         const uint64_t m = n - from < len ? n - from : len;
-        acc = multmodp(xpow8(m), acc) ^ part[k];
+        acc = multmodp(m == len ? whole : xpow8(m), acc) ^ part[k];
     }
     return acc ^ multmodp(xpow8(n), 0xffffffffu) ^ 0xffffffffu;   // initial value 0xffffffff shifted past n bytes, final xor
 }
@@ -157,6 +164,58 @@ __global__ void gzip_deflate_post_kernel(const DeflateJob *__restrict__ jobs, sp
     gbyte *q = (gbyte *)j.dst + r.written;
     for (int k = 0; k < 4; ++k) { q[k] = (uint8_t)(crc >> (8 * k)); q[4 + k] = (uint8_t)(size >> (8 * k)); }
     r.written += 8;
+}
+
+// ---- resumable streams (spng_inflate_resume_batch) ------------------------------------------------------
+// A stream inflated push by push ends in a call that saw only its tail: the zlib trailer -- Adler-32 over ALL
+// inflated bytes (MRC32.swift:26-50; .checksum, InflatorBuffers.swift:112-130) -- is checked here, once, when a
+// call reports SPNG_DONE: S = sum b_i and I = sum i * b_i (mod 65521) over 256 pieces, one wave each (the same
+// closed form as the inflate kernels: s1 = 1 + S, s2 = N + N S - I).
+__global__ __launch_bounds__(64) void resume_adler_kernel(const InflateJob *__restrict__ jobs, const spng_result *__restrict__ results,
+                                                          uint64_t *__restrict__ parts)
+{
+    const int lane = threadIdx.x;
+    const uint32_t i = blockIdx.y;
+    const InflateJob &j = jobs[i];
+    if (!uni64((uint64_t)j.state) || (int32_t)UNI(j.format) != SPNG_FORMAT_ZLIB) return;
+    const spng_result &r = results[UNI(j.image)];
+    if ((int32_t)UNI(r.status) != SPNG_DONE) return;
+    const gbyte *p = (const gbyte *)uni64((uint64_t)j.dst);
+    const uint64_t n = uni64(r.written), len = piece_len(n), from = (uint64_t)blockIdx.x * len;
+    const uint64_t m = from >= n ? 0 : (n - from < len ? n - from : len);
+    uint32_t S = 0, I = 0, g = (uint32_t)((from + (uint64_t)lane) % 65521);      // position mod 65521, kept incrementally
+    for (uint64_t k = lane; k < m; k += 64) {
+        const uint32_t b = p[from + k];
+        S += b;                                                // < 2^32: a piece is far below 2^24 bytes
+        I = (I + g * b) % 65521;
+        g += 64; g = g >= 65521 ? g - 65521 : g;
+    }
+    S = wave_sum32(S % 65521) % 65521; I = wave_sum32(I) % 65521;
+    if (lane == 0) parts[(uint64_t)i * GZ_PIECES + blockIdx.x] = (uint64_t)S << 32 | I;
+}
+__global__ void resume_post_kernel(const InflateJob *__restrict__ jobs, spng_result *__restrict__ results,
+                                   const uint64_t *__restrict__ parts, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const InflateJob &j = jobs[i];
+    if (!j.state || j.format != SPNG_FORMAT_ZLIB) return;
+    spng_result &r = results[j.image];
+    if (r.status != SPNG_DONE) return;
+    uint64_t S = 0, I = 0;
+    for (uint32_t k = 0; k < GZ_PIECES; ++k) { const uint64_t v = parts[(uint64_t)i * GZ_PIECES + k]; S += v >> 32; I += (uint32_t)v; }
+    S %= 65521; I %= 65521;
+    const uint64_t N = r.written % 65521;
+    const uint32_t computed = (uint32_t)((N + N * S % 65521 + 65521 - I) % 65521) << 16 | (uint32_t)((1 + S) % 65521);
+    const gbyte *t = (const gbyte *)j.src + r.consumed - 4;
+    const uint32_t declared = (uint32_t)t[0] << 24 | (uint32_t)t[1] << 16 | (uint32_t)t[2] << 8 | t[3];
+    if (declared != computed) { r.status = SPNG_E_STREAM_CHECKSUM; r.aux[0] = declared; r.aux[1] = computed; }
+}
+hipError_t launch_resume_post(const InflateJob *d_jobs, spng_result *d_results, uint64_t *d_parts, uint32_t count, hipStream_t stream)
+{
+    resume_adler_kernel<<<dim3(GZ_PIECES, count), 64, 0, stream>>>(d_jobs, d_results, d_parts);
+    resume_post_kernel<<<(count + 63) / 64, 64, 0, stream>>>(d_jobs, d_results, d_parts, count);
+    return hipGetLastError();
 }
 
 hipError_t launch_gzip_pre(InflateJob *d_jobs, PStream *d_streams, spng_result *d_results, uint64_t *d_gz, int32_t *d_done,

@@ -332,14 +332,17 @@ __device__ __forceinline__ void copy_match(Lds &s, const Out &o, uint64_t pos, u
 // ------------------------------------------------------------------------------------------------
 // wave 1: the resolver
 // ------------------------------------------------------------------------------------------------
-__device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint64_t dst_cap, uint64_t src_len,
-                                                        spng_result *__restrict__ result, int lane)
+__device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint64_t dst_cap, uint64_t src_len, bool resumed,
+                                                        uint64_t start_bit, uint64_t out_pos, spng_result *__restrict__ result, int lane)
 {
 #ifndef SPNG_B_PRIO
 #define SPNG_B_PRIO 2
 #endif
     __builtin_amdgcn_s_setprio(SPNG_B_PRIO);               // walker 3 > resolver 2 > scout 0 (the scout has slack)
-    Out o = { dst, dst_cap, 0, 0, 0, 0, 0 };
+    // resumed: the window is what earlier calls left in the output.  (Flushing starts on the 16-byte piece the
+    // position lies in -- flush reads the ring in aligned pieces -- so up to 15 bytes are written once more.)
+    Out o = { dst, dst_cap, out_pos, out_pos & ~(uint64_t)15, 0, 0, (uint32_t)((out_pos & ~(uint64_t)15) % 65521) };
+    for (uint64_t p = (out_pos > (uint64_t)RING ? out_pos - RING : 0) + lane; p < out_pos; p += 64) s.ring[p & (RING - 1)] = dst[p];
     uint32_t head = 0, spins = 0;
 #ifdef SPNG_INFLATE_PROF
     uint64_t p_empty = 0, p_batches = 0, p_t0 = __builtin_readcyclecounter();
@@ -470,6 +473,7 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint
         res.written = o.pos;
         res.consumed = (bits + 7) / 8 > src_len ? src_len : (bits + 7) / 8;
         res.aux[0] = aux0; res.aux[1] = aux1;
+        if (resumed && status == SPNG_NEED_MORE_INPUT) { res.aux[0] = start_bit; res.aux[1] = out_pos; }   // where the next call starts
     }
 }
 
@@ -696,7 +700,8 @@ __device__ __forceinline__ void push(Lds &s, Queue &q, unsigned long long who, u
 #define FAIL(code, a0, a1) do { status = (code); aux0 = (a0); aux1 = (a1); goto done; } while (0)
 #define PUSH(who, tok) push(s, q, (who), (tok), lane)
 
-__device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src, uint64_t n, int32_t format, int lane)
+__device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src, uint64_t n, int32_t format, bool resumed,
+                                                       uint64_t start_bit, int lane)
 {
     const uint64_t total = n * 8;
 #ifndef SPNG_NO_PRIO
@@ -714,8 +719,10 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
     Reader r;
     seek(s, r, src, n, 0, lane);
 
+    // a resumed stream (spng_inflate_resume_batch) starts on the block header an earlier call stopped in front of
+    if (start_bit) seek_bits(s, r, src, n, start_bit, lane);
     // .initial (InflatorBuffers.swift:92-104, StreamHeader.swift:16-54)
-    if (format != SPNG_FORMAT_IOS) {
+    else if (format != SPNG_FORMAT_IOS) {
         if (16 > total) goto done;
         const uint32_t cm = TAKE(4);
         if (cm != 8) FAIL(SPNG_E_COMPRESSION_METHOD, cm, 0);
@@ -985,7 +992,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
         if (boundary + 32 > total) goto done;
         TAKE((uint32_t)(boundary - bitpos(r)));
         for (int k = 0; k < 4; ++k) declared = declared << 8 | TAKE(8);
-        check = 1;
+        check = resumed ? 0 : 1;                               // (resumed: the sum over ALL bytes is taken afterwards, gzip.hip)
     }
     status = SPNG_DONE;
 done:
@@ -1022,6 +1029,10 @@ __global__ __launch_bounds__(256) void inflate_kernel(const InflateJob *__restri
     const uint64_t src_len = uni64(job->src_len), dst_cap = uni64(job->dst_cap);
     const int32_t format = (int32_t)UNI(job->format);
     const uint32_t image = UNI(job->image);
+    typedef uint64_t __attribute__((address_space(1))) gstate;
+    const gstate *state = (const gstate *)uni64((uint64_t)job->state);
+    const bool resumed = state != nullptr;
+    const uint64_t start_bit = resumed ? uni64(state[0]) : 0, out_pos = resumed ? uni64(state[1]) : 0;
     if (threadIdx.x == 0) {
         s.c.tail = 0; s.c.head = 0; s.c.a_done = 0; s.c.b_fail = 0; s.c.a_wait = 0;
         s.c.w_gen = 0; s.c.w_stop = 0; s.c.w_idle = 0; s.c.w_quit = 0; s.c.w_prod = 0; s.c.w_cons = 0;
@@ -1029,8 +1040,8 @@ __global__ __launch_bounds__(256) void inflate_kernel(const InflateJob *__restri
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t role = UNI(threadIdx.x >> 6);
-    if (role == 0)      decoder(s, src, src_len, format, lane);
-    else if (role == 1) resolver(s, dst, dst_cap, src_len, results + image, lane);
+    if (role == 0)      decoder(s, src, src_len, format, resumed, start_bit, lane);
+    else if (role == 1) resolver(s, dst, dst_cap, src_len, resumed, start_bit, out_pos, results + image, lane);
     else if (role == 2) scout(s, src, src_len, lane);
     // (wave 3 has nothing to do.  It is there because the dispatcher places 256-thread workgroups
     //  evenly -- exactly four per CU, all 1024 streams of a batch resident at once -- and 192-thread

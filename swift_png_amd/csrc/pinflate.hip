@@ -418,17 +418,20 @@ __global__ __launch_bounds__(64) void pinf_find_kernel(const PStream *__restrict
     const uint64_t n = uni64(st.src_len), total = n * 8;
     const uint32_t j = UNI(sg.index);
     uint64_t found = NONE;
+    const uint64_t resume_bit = uni64(st.start_bit);       // resumable streams: nothing in front of it is looked at again
     if (j == 0) {
         // .initial (InflatorBuffers.swift:92-104, StreamHeader.swift:16-54)
-        if (UNI(st.format) == SPNG_FORMAT_IOS) found = 0;
+        if (resume_bit) found = resume_bit;
+        else if (UNI(st.format) == SPNG_FORMAT_IOS) found = 0;
         else if (n >= 2) {
             const uint32_t cmf = src[0], flg = src[1];
             if ((cmf & 15) == 8 && (cmf >> 4) < 8 && ((cmf << 8) + flg) % 31 == 0 && !(flg & 0x20)) found = 16;
         }
     } else {
         const uint64_t sb = uni64(st.seg_bytes) * 8;
-        const uint64_t lo_bit = (uint64_t)j * sb;
-        const uint64_t hi_bit = lo_bit + sb < total ? lo_bit + sb : total;
+        const uint64_t lo_nom = (uint64_t)j * sb;
+        const uint64_t lo_bit = lo_nom > resume_bit ? lo_nom : ((resume_bit + 1 + 63) & ~(uint64_t)63);   // (window loads want whole bytes)
+        const uint64_t hi_bit = lo_nom + sb < total ? lo_nom + sb : total;
         uint32_t *win = s.vmap;                                 // 2 KiB + slack
         for (uint64_t wb = lo_bit; wb < hi_bit && found == NONE; wb += 16384) {
             stage_bytes(win, src, n, wb >> 3, 512, lane);
@@ -652,6 +655,11 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
     uint32_t cur = 0;
     uint64_t pos = start, ntok = 0;
     int32_t status = PSEG_FAIL;
+    // A resumable stream stops in front of the first block that cannot be taken as it stands -- cut off by the end
+    // of the input so far, or not acceptable: the serial kernel, started there, tells which -- and keeps the
+    // blocks before it.
+    const bool resumable = uni64((uint64_t)st.state) != 0;
+    uint64_t ntok_block = 0;
 #ifdef SPNG_COUNT_PROF
     uint64_t cp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, hpv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     cp[15] = __builtin_readcyclecounter();
@@ -664,6 +672,7 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
         }
         Hdr h;
         CP(5);
+        ntok_block = ntok;
 #ifdef SPNG_COUNT_PROF
         hpv[7] = __builtin_readcyclecounter();
         const bool hok = UB(parse_header(s, src, n, pos, h, lane, hpv));
@@ -714,6 +723,7 @@ __global__ __launch_bounds__(64) void pinf_count_kernel(const PStream *__restric
         }
         if (h.bfinal) { status = PSEG_FINAL; break; }
     }
+    if (status == PSEG_FAIL && resumable) { status = PSEG_PARTIAL; ntok = ntok_block; }   // (pos is still the block's first bit)
     if (lane == 0) { sg.end_bit = pos; sg.ntok = ntok; sg.status = status; sg.next = nk; }
 #ifdef SPNG_COUNT_PROF
     if (blockIdx.x == 1 && lane == 0)
@@ -811,7 +821,7 @@ __global__ __launch_bounds__(64) void pinf_scan_kernel(PStream *__restrict__ str
     const int lane = threadIdx.x;
     PStream &st = streams[blockIdx.x];
     const uint32_t first = UNI(st.seg_first), count = UNI(st.seg_count);
-    bool ok = false;
+    bool ok = false, partial = false;
     uint64_t tok = 0, end_bit = 0;
     uint32_t k = 0;
     for (uint32_t hops = 0; hops < count; ++hops) {
@@ -822,12 +832,13 @@ __global__ __launch_bounds__(64) void pinf_scan_kernel(PStream *__restrict__ str
         if (lane == 0) { sg->tok_base = tok; sg->used = 1; }
         tok += uni64(sg->ntok);
         if (status == PSEG_FINAL) { ok = true; end_bit = end; break; }
+        if (status == PSEG_PARTIAL) { ok = true; partial = true; end_bit = end; break; }
         const uint32_t nx = UNI(sg->next);
         if (nx <= k || nx >= count) break;
         if (uni64(segs[first + nx].start_bit) != end) break;
         k = nx;
     }
-    if (lane == 0) { st.ok = ok ? 1 : 0; st.ntok = tok; st.end_bit = end_bit; st.pass = 0; st.tok_base = 0; }
+    if (lane == 0) { st.ok = ok ? (partial ? 2 : 1) : 0; st.ntok = tok; st.end_bit = end_bit; st.pass = 0; st.tok_base = 0; }
 }
 
 // single wave: global token offsets and passes.  capacity = tokens the token buffer holds.
@@ -979,10 +990,16 @@ __global__ __launch_bounds__(RT, 4) void pinf_resolve_kernel(const PStream *__re
     const uint64_t cap = uni64(st.dst_cap);
     const gbyte *src = (const gbyte *)uni64((uint64_t)st.src);
     const uint64_t n = uni64(st.src_len);
-    uint64_t pos = 0, ti = 0;
+    uint64_t pos = uni64(st.out_pos), ti = 0;      // (resumable streams: the bytes earlier calls produced are in dst)
     uint32_t accS = 0, accI = 0;                     // Adler-32 partial sums (inflate.hip: struct Out)
     bool bad = false;
     const uint32_t j0 = (uint32_t)tid * 16;
+    uint64_t *state = (uint64_t *)uni64((uint64_t)st.state);
+    if (pos) {
+        // the window so far
+        for (uint64_t p = (pos > WINDOW ? pos - WINDOW : 0) + (uint32_t)tid; p < pos; p += RT) s.ring[p & (WINDOW - 1)] = dst[p];
+        __syncthreads();
+    }
     RP_DECL
     uint32_t tokr[TPT];
 #pragma unroll
@@ -1182,7 +1199,21 @@ __global__ __launch_bounds__(RT, 4) void pinf_resolve_kernel(const PStream *__re
         uint32_t S = 0, I = 0;
         for (int w = 0; w < (int)(RT / 64); ++w) { S += s.part[w]; I += s.part[8 + w]; }
         S %= 65521; I %= 65521;
-        if (tid == 0) {
+        if (tid == 0 && st.ok == 2) {
+            // resumable, and the chain stopped in front of a block the input does not hold (or that is not
+            // acceptable): the serial kernel goes on from there
+            state[0] = st.end_bit; state[1] = pos;
+        } else if (tid == 0 && state) {
+            // resumable and complete: the trailer must be there; the sum over ALL bytes is compared afterwards (gzip.hip)
+            const uint64_t endb = (st.end_bit + 7) / 8, consumed = endb + (st.format == SPNG_FORMAT_ZLIB ? 4 : 0);
+            spng_result &res = results[st.image];
+            if (consumed <= n) {
+                res.status = SPNG_DONE; res.reserved = 1;
+                res.written = pos; res.consumed = consumed;
+                res.aux[0] = res.aux[1] = 0;
+                done[blockIdx.x] = 1;
+            }   // (else: the serial kernel, from where this call started, reports "need more input")
+        } else if (tid == 0) {
             const uint64_t endb = (st.end_bit + 7) / 8;
             bool good = true;
             uint64_t consumed = endb;

@@ -2,9 +2,9 @@
 
 Names, argument meaning and error behaviour follow the Swift originals so that the parity tests
 read like the reference's tests.  State that the reference keeps as a resumable state machine
-(LZ77.InflatorState, PNG.Decoder.row/pass) is kept here as "bytes pushed so far": the device path
-decodes whole streams, so every push re-runs the stream from its start (results are identical by
-construction; the streaming cost model is not -- see DESIGN.md "Out of scope").
+(LZ77.InflatorState, PNG.Decoder.row/pass) is kept on the device between pushes: the compressed bytes and the
+inflated bytes so far, and the point (a block boundary) from which the next push goes on
+(spng_inflate_resume_batch).
 """
 from __future__ import annotations
 
@@ -20,41 +20,83 @@ class LZ77:
         ios = FORMAT_IOS
 
     class Inflator:
-        """LZ77.Inflator (Sources/LZ77/Inflator/LZ77.Inflator.swift:8-62)."""
+        """LZ77.Inflator (Sources/LZ77/Inflator/LZ77.Inflator.swift:8-62).
+
+        Streaming like the original: the compressed bytes pushed so far and the bytes inflated so far stay on the
+        device, and a push goes on where the previous one stopped (spng_inflate_resume_batch: blocks the input now
+        holds completely are decoded once, by the parallel pipeline; only the block the input ends in is decoded
+        again by the next push).  gzip members (Gzip.Inflator) still re-run from their header."""
 
         def __init__(self, format=FORMAT_ZLIB, session=None):
             from . import load
             self._s = session or load()
             self._format = format
-            self._in = bytearray()
+            self._streaming = format != FORMAT_GZIP
+            self._in = bytearray()                # gzip only
+            self._d_in, self._n_in = None, 0      # device: all compressed bytes so far
+            self._d_out = None                    # device: all inflated bytes so far
+            self._state = (0, 0)
             self._out = b""
+            self._avail = 0
             self._cursor = 0
             self._terminal = False
+
+        def _append(self, data):
+            s, t = self._s, self._s.torch
+            need = self._n_in + len(data)
+            if self._d_in is None or self._d_in.numel() < need:
+                grown = s.empty(max(2 * need, 1 << 16))
+                if self._n_in:
+                    grown[:self._n_in] = self._d_in[:self._n_in]
+                self._d_in = grown
+            if data:
+                self._d_in[self._n_in:need] = s.to_device(bytes(data))
+            self._n_in = need
 
         def push(self, data) -> object:
             """Returns None once a complete stream has been received, () while it wants more."""
             from . import raise_for
             if self._terminal:
                 return None                      # .terminal: remaining input is ignored (:38-40)
-            self._in += bytes(data)
-            cap = max(1 << 16, 1100 * len(self._in))
+            if not self._streaming:
+                self._in += bytes(data)
+                cap = max(1 << 16, 1100 * len(self._in))
+                while True:
+                    status, out, _, aux = self._s.inflate(bytes(self._in), self._format, cap)
+                    if status != E_OUTPUT_CAPACITY:
+                        break
+                    cap *= 4                     # the reference's output buffer is unbounded
+                raise_for(status, aux)
+                self._out, self._avail = out, len(out)
+                self._terminal = status == DONE
+                return None if self._terminal else ()
+            self._append(data)
+            if self._d_out is None:
+                self._d_out = self._s.empty(max(1 << 16, 8 * self._n_in))
             while True:
-                status, out, _, aux = self._s.inflate(bytes(self._in), self._format, cap)
-                if status != E_OUTPUT_CAPACITY:
+                res, state = self._s.inflate_resume(self._d_in, self._n_in, self._d_out, self._format, self._state)
+                if res.status != E_OUTPUT_CAPACITY:
                     break
-                cap *= 4                         # the reference's output buffer is unbounded
-            raise_for(status, aux)
-            self._out = out
-            self._terminal = status == DONE
+                grown = self._s.empty(4 * self._d_out.numel())          # the reference's output buffer is unbounded
+                grown[:self._d_out.numel()] = self._d_out
+                self._d_out = grown
+            raise_for(res.status, (res.aux[0], res.aux[1]))
+            self._state, self._avail = state, res.written
+            self._terminal = res.status == DONE
             return None if self._terminal else ()
+
+        def _bytes(self, a, b):
+            if not self._streaming:
+                return self._out[a:b]
+            return bytes(self._d_out[a:b].cpu().numpy()) if b > a else b""
 
         def pull(self, count=None):
             if count is None:                    # pull() -> everything available (:58-61)
-                data, self._cursor = self._out[self._cursor:], len(self._out)
+                data, self._cursor = self._bytes(self._cursor, self._avail), self._avail
                 return data
-            if len(self._out) - self._cursor < count:
+            if self._avail - self._cursor < count:
                 return None                      # pull(_:) -> nil (:53-56)
-            data = self._out[self._cursor:self._cursor + count]
+            data = self._bytes(self._cursor, self._cursor + count)
             self._cursor += count
             return data
 
@@ -205,25 +247,51 @@ class PNG:
         fields that cross the boundary: size, pixel depth/channels, interlacing, standard."""
 
         def __init__(self, size, depth, channels, interlaced=False, standard=FORMAT_ZLIB, session=None):
-            from . import load, storage_size
+            from . import load, storage_size, inflated_size
             self._s = session or load()
             self.size, self.depth, self.channels = tuple(size), depth, channels
             self.interlaced, self.standard = bool(interlaced), standard
             self.storage = bytes(storage_size(size[0], size[1], depth, channels))
-            self._idat = bytearray()
             self._continue = True                # PNG.Decoder.continue (:22-23)
+            # device state kept between pushes: the IDAT bytes so far, the inflated scanlines so far, the raster
+            s = self._s
+            self._U = inflated_size(size[0], size[1], depth, channels, self.interlaced)
+            self._d_idat, self._n_idat = None, 0
+            self._d_rows = s.empty(self._U + 64)     # (64 bytes of slack: a little too much data shows as `written > U`)
+            self._d_storage = s.to_device(self.storage) if len(self.storage) else s.empty(1)
+            self._state = (0, 0)
 
         def push(self, data: bytes):
-            """push(data:) (:88-102): one call per IDAT chunk."""
-            from . import raise_for
+            """push(data:) (:88-102): one call per IDAT chunk.  The inflate goes on where the previous chunk stopped
+            (spng_inflate_resume_batch); the rows available so far are defiltered into the raster."""
+            from . import raise_for, E_EXTRANEOUS_IMAGE_DATA
             if not self._continue:
                 raise DecodingError(E_EXTRANEOUS_COMPRESSED_DATA)     # PNG.Decoder.swift:51-55
-            self._idat += bytes(data)
+            s = self._s
+            need = self._n_idat + len(data)
+            if self._d_idat is None or self._d_idat.numel() < need:
+                grown = s.empty(max(2 * need, 1 << 16))
+                if self._n_idat:
+                    grown[:self._n_idat] = self._d_idat[:self._n_idat]
+                self._d_idat = grown
+            if data:
+                self._d_idat[self._n_idat:need] = s.to_device(bytes(data))
+            self._n_idat = need
+            res, state = s.inflate_resume(self._d_idat, self._n_idat, self._d_rows, self.standard, self._state)
+            status = res.status
+            # PNG.Decoder.swift:142-147: anything left in the inflator after the last row
+            if status == E_OUTPUT_CAPACITY or (status in (DONE, NEED_MORE_INPUT) and res.written > self._U):
+                status = E_EXTRANEOUS_IMAGE_DATA
+            raise_for(status, (res.aux[0], res.aux[1]))
+            self._state = state
             w, h = self.size
-            status, storage, aux = self._s.decode(bytes(self._idat), w, h, self.depth, self.channels,
-                                                  self.interlaced, self.standard, self.storage)
-            raise_for(status, aux)
-            self.storage = storage
+            # (on a copy: the defilter may reconstruct in place, and the inflated bytes are the next push's window)
+            scratch = self._d_rows.clone()
+            desc = s.image_desc(None, scratch, self._d_storage, w, h, self.depth, self.channels, self.interlaced,
+                                self.standard, rows_cap=scratch.numel())
+            ures = s.unfilter_batch([desc], [res.written])
+            raise_for(ures[0].status, (ures[0].aux[0], ures[0].aux[1]))
+            self.storage = bytes(self._d_storage[:len(self.storage)].cpu().numpy())
             self._continue = status == NEED_MORE_INPUT
 
         def push_ancillary_iend(self):

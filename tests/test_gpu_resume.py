@@ -1,0 +1,151 @@
+"""spng_inflate_resume_batch: a stream pushed piece by piece (LZ77.Inflator.push, LZ77.Inflator.swift:30-61).
+After EVERY push the device reports what the oracle reports for the same prefix of the stream -- status, number of
+inflated bytes available, the bytes, error payloads -- while decoding nothing twice but the block a push ends in
+(complete blocks go through the parallel pipeline once; the state handed from call to call is a block boundary)."""
+import zlib
+
+import numpy as np
+import pytest
+
+import pnghelp as ph
+import swift_png_amd as spng
+from test_gpu_pinflate import make, scanlines
+
+pytestmark = pytest.mark.gpu
+
+
+class Pusher:
+    def __init__(self, s, fmt=spng.FORMAT_ZLIB, cap=1 << 16):
+        self.s, self.fmt = s, fmt
+        self.d_in, self.n = s.empty(1 << 16), 0
+        self.d_out = s.empty(cap)
+        self.state = (0, 0)
+        self.states = [self.state]
+
+    def push(self, piece):
+        s = self.s
+        need = self.n + len(piece)
+        if self.d_in.numel() < need:
+            grown = s.empty(2 * need); grown[:self.n] = self.d_in[:self.n]; self.d_in = grown
+        if piece:
+            self.d_in[self.n:need] = s.to_device(piece)
+        self.n = need
+        while True:
+            res, state = s.inflate_resume(self.d_in, self.n, self.d_out, self.fmt, self.state)
+            if res.status != spng.E_OUTPUT_CAPACITY:
+                break
+            grown = s.empty(4 * self.d_out.numel()); grown[:self.d_out.numel()] = self.d_out; self.d_out = grown
+        self.state = state
+        self.states.append(state)
+        return res
+
+    def out(self, n):
+        return bytes(self.d_out[:n].cpu().numpy())
+
+
+def pieces(z, sizes):
+    at, k = 0, 0
+    while at < len(z):
+        n = sizes[k % len(sizes)]; k += 1
+        yield z[at:at + n]
+        at += n
+
+
+def check_prefixes(s, z, sizes, fmt=spng.FORMAT_ZLIB, every=1):
+    p = Pusher(s, fmt)
+    seen = b""
+    last = None
+    for k, piece in enumerate(pieces(z, sizes)):
+        res = p.push(piece)
+        seen += piece
+        if k % every == 0 or len(seen) == len(z):
+            st, out, consumed, aux = ph.orc_inflate(seen, fmt, cap=max(1 << 16, 1100 * len(seen)))
+            assert res.status == st, (k, len(seen), res.status, st)
+            assert res.written == len(out) and p.out(res.written) == out, (k, len(seen))
+            if st not in (0, 1):
+                assert (res.aux[0], res.aux[1]) == tuple(aux)
+            if st == 0:
+                assert res.consumed == consumed
+        last = res
+        if res.status not in (0, 1):
+            break
+    # the resume point only ever moves forward, in both coordinates
+    for a, b in zip(p.states, p.states[1:]):
+        assert b[0] >= a[0] and b[1] >= a[1]
+    return last, p
+
+
+@pytest.mark.parametrize("kind", ["zlib1", "zlib6", "zlib9", "noise", "huffonly", "fixed", "flushes", "stored_mix", "zeros"])
+def test_resume_matches_oracle_after_every_push(gpu, kind):
+    s = gpu.load()
+    z = make(kind, 73 * 4096)
+    want = zlib.decompress(z)
+    last, p = check_prefixes(s, z, [1, 7, 4096, 33333, 100, 65536], every=1)
+    assert last.status == 0 and last.written == len(want) and p.out(len(want)) == want
+    last, p = check_prefixes(s, z, [997], every=25)
+    assert last.status == 0 and p.out(len(want)) == want
+
+
+def test_resume_swiftpng_made_stream_and_ios_format(gpu):
+    s = gpu.load()
+    d = scanlines(6, 98 * 4096)
+    z = s.deflate(d, 6)
+    last, p = check_prefixes(s, z, [5000, 1, 20000], every=1)
+    assert last.status == 0 and p.out(len(d)) == d
+    raw = s.deflate(d, 4, spng.FORMAT_IOS)
+    last, p = check_prefixes(s, raw, [3000], spng.FORMAT_IOS, every=7)
+    assert last.status == 0 and p.out(len(d)) == d
+
+
+def test_resume_errors_surface_at_the_push_that_brings_them(gpu):
+    s = gpu.load()
+    d = scanlines(7, 49 * 4096)
+    z = bytearray(zlib.compress(d, 6))
+    z[len(z) // 2] ^= 0x5a                                   # somewhere inside a block
+    last, _ = check_prefixes(s, bytes(z), [4096], every=1)
+    assert last.status not in (0, 1)
+    z = bytearray(zlib.compress(d, 6)); z[-2] ^= 1           # the checksum: only the last push can tell
+    last, p = check_prefixes(s, bytes(z), [50000], every=1)
+    assert last.status == spng.E_STREAM_CHECKSUM
+    assert (last.aux[0], last.aux[1]) == (int.from_bytes(z[-4:], "big"), zlib.adler32(d))
+    z = zlib.compress(d, 6)
+    last, p = check_prefixes(s, z[:-3], [30000], every=1)    # trailer incomplete: wants more, everything is there
+    assert last.status == 1 and last.written == len(d)
+    res = p.push(z[-3:])
+    assert res.status == 0 and res.consumed == len(z)
+    bad = bytearray(z); bad[0] = 0x79                        # header errors at the first push
+    assert check_prefixes(s, bytes(bad), [10], every=1)[0].status == spng.E_COMPRESSION_METHOD
+
+
+def test_resume_large_stream_in_idat_sized_pieces(gpu):
+    """16 MiB of scanlines in 64 KiB pieces (an encoder's IDAT chunks): every complete block goes through the pipeline
+    exactly once -- the resume point follows the input closely -- and the whole thing takes seconds, not the minutes
+    of decoding the stream from its first byte on every push."""
+    import time
+    s = gpu.load()
+    d = scanlines(8, 16 << 20)
+    z = zlib.compress(d, 6)
+    p = Pusher(s, cap=len(d) + 4096)
+    t0 = time.perf_counter()
+    res = None
+    for piece in pieces(z, [65536]):
+        res = p.push(piece)
+        assert res.status in (0, 1)
+        if res.status == 1:
+            assert p.n * 8 - p.state[0] < 8 * 200000         # at most a block or two behind the input
+    dt = time.perf_counter() - t0
+    assert res.status == 0 and res.written == len(d) and res.consumed == len(z) and p.out(len(d)) == d
+    print(f"resume: {len(z) // 65536 + 1} pushes, {dt:.2f} s")
+    assert dt < 30
+
+
+def test_resume_argument_checks(gpu):
+    s = gpu.load()
+    z = zlib.compress(b"abc" * 100)
+    d_in, d_out = s.to_device(z), s.empty(4096)
+    with pytest.raises(spng.SpngError):
+        s.inflate_resume(d_in, len(z), d_out, spng.FORMAT_ZLIB, (len(z) * 8 + 1, 0))
+    with pytest.raises(spng.SpngError):
+        s.inflate_resume(d_in, len(z), d_out, spng.FORMAT_GZIP, (0, 0))
+    res, _ = s.inflate_resume(d_in, len(z), d_out, spng.FORMAT_ZLIB, (0, 0))
+    assert res.status == 0 and bytes(d_out[:300].cpu().numpy()) == b"abc" * 100
