@@ -153,7 +153,7 @@ __device__ __forceinline__ void reconstruct_generic(uint8_t *tile, int rowb, int
     }
 }
 
-// ---- reconstruction of one tile: 4 bytes per unit, two packed-u16 halves per dword -----------
+// ---- reconstruction of one tile: 4 or 8 bytes per unit, two packed-u16 halves per dword ------
 // even bytes live in `lo` (x & 0x00ff00ff), odd bytes in `hi` ((x >> 8) & 0x00ff00ff); sums of two
 // bytes cannot carry across the 16-bit lanes, signed differences use the packed-i16 VALU ops.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -172,41 +172,47 @@ __device__ __forceinline__ uint32_t paeth_pk(uint32_t a, uint32_t b, uint32_t c)
     return (bc & nota) | (a & ~nota);
 }
 
-template <int P, bool FIRST, bool PAETH>
-__device__ __forceinline__ void reconstruct4(uint8_t *tile, int rowb, int lane, uint32_t ft, int64_t ux0,
-                                             uint32_t &o, uint32_t &bprev)
+// DW dwords per unit: 1 (RGBA8, VA16, ...: bpp 4) or 2 (RGBA16: bpp 8).  The row above is one unit ahead, so what
+// this lane needs from it -- the unit it finished in the previous step -- still sits in its registers, dword by dword.
+template <int P, int DW, bool FIRST, bool PAETH>
+__device__ __forceinline__ void reconstruct_pk(uint8_t *tile, int rowb, int lane, uint32_t ft, int64_t ux0,
+                                               uint32_t *o, uint32_t *bprev)
 {
     constexpr uint32_t M = 0x00ff00ffu;
     const uint32_t m_sub = ft == 1 ? M : 0u, m_up = ft == 2 ? M : 0u, m_avg = ft == 3 ? M : 0u,
                    m_pae = ft == 4 ? M : 0u;
     u32x4 *mine = (u32x4 *)(tile + (1 + lane) * rowb);
     const u32x4 *top = (const u32x4 *)tile;
-    uint32_t a_lo = o & M, a_hi = (o >> 8) & M, c_lo = bprev & M, c_hi = (bprev >> 8) & M;
+    uint32_t a_lo[DW], a_hi[DW], c_lo[DW], c_hi[DW];
+#pragma unroll
+    for (int d = 0; d < DW; ++d) { a_lo[d] = o[d] & M; a_hi[d] = (o[d] >> 8) & M; c_lo[d] = bprev[d] & M; c_hi[d] = (bprev[d] >> 8) & M; }
 #pragma unroll 2
-    for (int t4 = 0; t4 < P / 4; ++t4) {
+    for (int t4 = 0; t4 < P * DW / 4; ++t4) {
         const u32x4 raw = mine[t4], tp = top[t4];
         uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
         const uint32_t tq[4] = {tp.x, tp.y, tp.z, tp.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t b = from_lane_above(o, tq[k]);
+            constexpr int dmask = DW - 1;
+            const int d = k & dmask;                           // which dword of its unit (DW divides 4)
+            const uint32_t b = from_lane_above(o[d], tq[k]);
             const uint32_t b_lo = b & M, b_hi = (b >> 8) & M;
-            uint32_t p_lo = (a_lo & m_sub) | (b_lo & m_up) | (((a_lo + b_lo) >> 1) & m_avg);
-            uint32_t p_hi = (a_hi & m_sub) | (b_hi & m_up) | (((a_hi + b_hi) >> 1) & m_avg);
+            uint32_t p_lo = (a_lo[d] & m_sub) | (b_lo & m_up) | (((a_lo[d] + b_lo) >> 1) & m_avg);
+            uint32_t p_hi = (a_hi[d] & m_sub) | (b_hi & m_up) | (((a_hi[d] + b_hi) >> 1) & m_avg);
             if (PAETH) {
-                p_lo |= paeth_pk(a_lo, b_lo, c_lo) & m_pae;
-                p_hi |= paeth_pk(a_hi, b_hi, c_hi) & m_pae;
+                p_lo |= paeth_pk(a_lo[d], b_lo, c_lo[d]) & m_pae;
+                p_hi |= paeth_pk(a_hi[d], b_hi, c_hi[d]) & m_pae;
             }
             uint32_t x_lo = ((r[k] & M) + p_lo) & M, x_hi = (((r[k] >> 8) & M) + p_hi) & M;
             if (FIRST) {
                 // units left of the row start produce zeros, so that unit 0 sees a = c = 0
-                const uint32_t live = (ux0 + t4 * 4 + k >= 0) ? M : 0u;
+                const uint32_t live = (ux0 + (t4 * 4 + k) / DW >= 0) ? M : 0u;
                 x_lo &= live; x_hi &= live;
             }
-            o = x_lo | x_hi << 8;
-            r[k] = o;
-            c_lo = b_lo; c_hi = b_hi; a_lo = x_lo; a_hi = x_hi;
-            bprev = b;
+            o[d] = x_lo | x_hi << 8;
+            r[k] = o[d];
+            c_lo[d] = b_lo; c_hi[d] = b_hi; a_lo[d] = x_lo; a_hi[d] = x_hi;
+            bprev[d] = b;
         }
         u32x4 w; w.x = r[0]; w.y = r[1]; w.z = r[2]; w.w = r[3];
         mine[t4] = w;
@@ -351,10 +357,11 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
 
             const int64_t ux0 = (int64_t)T * C::P - lane;
 #ifndef SPNG_UNF_NOCOMPUTE        // tuning builds only: measure the memory pipeline alone
-            if constexpr (BPP == 4) {
-                if (T == 0)       reconstruct4<C::P, true, true>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
-                else if (any_pae) reconstruct4<C::P, false, true>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
-                else              reconstruct4<C::P, false, false>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
+            if constexpr (BPP == 4 || BPP == 8) {
+                // (o / bprev hold the unit as packed dwords here, byte-wise in the generic form)
+                if (T == 0)       reconstruct_pk<C::P, BPP / 4, true, true>(tile, C::ROWB, lane, ft, ux0, o, bprev);
+                else if (any_pae) reconstruct_pk<C::P, BPP / 4, false, true>(tile, C::ROWB, lane, ft, ux0, o, bprev);
+                else              reconstruct_pk<C::P, BPP / 4, false, false>(tile, C::ROWB, lane, ft, ux0, o, bprev);
             } else {
                 reconstruct_generic<BPP, C::P>(tile, C::ROWB, lane, ft, ux0, o, bprev);
             }
@@ -437,8 +444,18 @@ __global__ __launch_bounds__(256) void scatter_kernel(const ScatterJob *__restri
             const uint32_t sh = (~i & (per - 1)) * job.depth;
             job.storage[d] = (uint8_t)((scan[i / per] >> sh) & mask);
         } else {
+            // one load and one store per pixel where the pixel is a power-of-two bytes (the scanline side is
+            // never aligned: rows are pitch + 1 apart)
             const uint32_t bpp = volume >> 3;
-            for (uint32_t k = 0; k < bpp; ++k) job.storage[d * bpp + k] = scan[(uint64_t)i * bpp + k];
+            const uint8_t *from = scan + (uint64_t)i * bpp;
+            uint8_t *to = job.storage + d * bpp;
+            struct __attribute__((packed)) P16 { uint16_t v; };
+            struct __attribute__((packed)) P32 { uint32_t v; };
+            struct __attribute__((packed)) P64 { uint64_t v; };
+            if (bpp == 8) ((P64 *)to)->v = ((const P64 *)from)->v;
+            else if (bpp == 4) ((P32 *)to)->v = ((const P32 *)from)->v;
+            else if (bpp == 2) ((P16 *)to)->v = ((const P16 *)from)->v;
+            else for (uint32_t k = 0; k < bpp; ++k) to[k] = from[k];
         }
     }
 }
