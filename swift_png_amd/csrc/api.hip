@@ -1113,19 +1113,41 @@ static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_r
             c->graph_cap = want;
         }
     }
+    // Which full-search streams get helper waves: the ones whose input repeats itself (deflate_density_kernel).  The sparse
+    // ones go first, so every launch group is of one kind.
+    const size_t nfull = sorted.size() - nfast;
+    std::vector<uint32_t> dense(nfull, 0);
+    if (nfull) {
+        memcpy(a.host<DeflateJob>(jslot), sorted.data(), sorted.size() * sizeof(DeflateJob));
+        if (int32_t st = c->upload(jslot, jslot + sorted.size() * sizeof(DeflateJob))) return st;
+        const size_t dslot = a.take(nfull * 4);
+        HIP_TRY(launch_deflate_density(a.dev<DeflateJob>(jslot) + nfast, (uint32_t)nfull, a.dev<uint32_t>(dslot), c->stream));
+        HIP_TRY(hipMemcpyAsync(dense.data(), a.dev<uint32_t>(dslot), nfull * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        std::vector<DeflateJob> part;
+        part.reserve(nfull);
+        for (int kind = 0; kind < 2; ++kind)
+            for (size_t i = 0; i < nfull; ++i) if ((int)dense[i] == kind) part.push_back(sorted[nfast + i]);
+        size_t ndense = 0;
+        for (uint32_t d : dense) ndense += d;
+        std::copy(part.begin(), part.end(), sorted.begin() + nfast);
+        for (size_t i = 0; i < nfull; ++i) dense[i] = i >= nfull - ndense;
+    }
     for (size_t i = 0; i < sorted.size(); ++i) sorted[i].ring = (uint32_t *)c->d_ring + i * 65536;
-    // groups of full-search streams that fit the slab together
-    std::vector<std::pair<size_t, size_t>> groups;
+    // groups of full-search streams of one kind that fit the slab together
+    struct Group { size_t first, last; bool helpers; };
+    std::vector<Group> groups;
     for (size_t i = nfast; i < sorted.size();) {
         uint64_t used = 0;
         size_t k = i;
-        while (k < sorted.size()) {
+        const bool kind = dense[i - nfast] != 0;
+        while (k < sorted.size() && (dense[k - nfast] != 0) == kind) {
             const uint64_t bytes = deflate_graph_bytes(sorted[k].graph_vertices);
             if (used + bytes > c->graph_cap && k > i) break;
             sorted[k].graph = (uint32_t *)((char *)c->d_graph + used);
             used += bytes; ++k;
         }
-        groups.push_back({i, k});
+        groups.push_back({i, k, kind});
         i = k;
     }
     memcpy(a.host<DeflateJob>(jslot), sorted.data(), sorted.size() * sizeof(DeflateJob));
@@ -1134,7 +1156,7 @@ static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_r
         Timed t(c, SPNG_K_DEFLATE);
         if (nfast) HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)nfast, dr, c->stream));
         for (auto &gr : groups)
-            HIP_TRY(launch_deflate_full(a.dev<DeflateJob>(jslot) + gr.first, (uint32_t)(gr.second - gr.first), dr, c->stream));
+            HIP_TRY(launch_deflate_full(a.dev<DeflateJob>(jslot) + gr.first, (uint32_t)(gr.last - gr.first), gr.helpers, dr, c->stream));
     }
     // gzip members: CRC-32 and byte count of the input behind the stream (DeflatorBuffers.swift:96-135)
     if (gzparts != (size_t)-1)
@@ -1161,7 +1183,7 @@ int32_t spng_deflate_batch(spng_ctx *c, const spng_stream_desc *descs, const int
                              descs[i].dst_cap, nullptr, descs[i].format, levels[i], i,
                              descs[i].format == SPNG_FORMAT_IOS ? 15u : (uint32_t)e, nullptr, 0, 0};
     }
-    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 2048)) return st;
+    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + 8 + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 4096)) return st;
     Arena a{c};
     const size_t jslot = a.take(count * sizeof(DeflateJob));
     const size_t res = a.take(count * sizeof(spng_result));

@@ -152,7 +152,8 @@ hipError_t launch_gzip_inflate_post(const InflateJob *d_jobs, spng_result *d_res
 hipError_t launch_gzip_deflate_post(const DeflateJob *d_jobs, spng_result *d_results, uint32_t *d_parts, uint32_t count,
                                     hipStream_t stream);
 hipError_t launch_resume_post(const InflateJob *d_jobs, spng_result *d_results, uint64_t *d_parts, uint32_t count, hipStream_t stream);
-hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
+hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, bool helpers, spng_result *d_results, hipStream_t stream);
+hipError_t launch_deflate_density(const DeflateJob *d_jobs, uint32_t count, uint32_t *d_dense, hipStream_t stream);
 uint64_t deflate_graph_vertices(uint64_t n);
 uint64_t deflate_graph_bytes(uint64_t vertices);
 hipError_t launch_unpack(const UnpackJob *d_jobs, uint32_t count, uint32_t blocks_x, int target, hipStream_t stream);

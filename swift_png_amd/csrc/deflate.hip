@@ -80,6 +80,11 @@ struct DLds {
     // one 64-bit key (depth << 32 | writer order: see full_forward), and the edge slots of the 64 vertices at hand
     uint64_t win[512];
     uint32_t batch[64 * 30];
+    // the full kernel's helper waves (forward pass): what wave 0 hands them per pass and per batch of 64 vertices
+    // (per-batch words twice: a helper may still be reading one batch's while wave 0 sets up the next)
+    uint64_t fw_bbase, fw_ems[2][16];            // which vertices of the next sixteen batches have edges
+    uint32_t fw_cmd, fw_count, fw_carry[2];
+    uint32_t fw_cin[2][64];
     uint8_t  depths[544];                        // LZ77.DeflatorMatches.Depths: cost of every symbol in quarter bits
     uint32_t freq[320];                          // 0..287 lit/len, 288..319 distance
     union { uint8_t out[OUTB]; uint32_t out32[OUTB / 4]; };   // output staging ring; bytes not written yet are zero
@@ -821,7 +826,20 @@ __device__ __forceinline__ uint32_t minplus_scan(uint32_t a, uint32_t b, uint32_
     return xin + a < b ? xin + a : b;
 }
 
-__device__ __attribute__((noinline)) void full_forward(const FullArrays g, const gbyte *in, uint64_t bbase, uint32_t count, int lane)
+// One forward pass, run by all four waves of the workgroup.  Wave 0 owns the pass: it fetches, keeps the ring
+// initialised, scans alone through batches without edges and finalises every batch.  In a batch with edges the
+// three vertices of a group (their depths are final together, see above) are relaxed by waves 0, 1 and 2 at the
+// same time -- each wave scans for itself (same ring, same result), so the only things exchanged are the ring and
+// one workgroup barrier per group; wave 3 only keeps the barrier count (256-thread workgroups place evenly).
+enum { FW_PASS = 1, FW_EXIT = 2 };
+// (WAVES == 1: the same pass on the one wave of a 64-thread workgroup -- no helpers, no barriers)
+template <int WAVES> __device__ __forceinline__ void wg_sync()
+{
+    if (WAVES > 1) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+}
+template <int WAVES>
+__device__ __attribute__((noinline)) void forward_body(const FullArrays g, const gbyte *in, uint64_t bbase, uint32_t count, int lane, int wave)
 {
     DLds &s = g_lds;
     // costs in registers: distance decade `lane`; run lengths 3 + lane + 64 j
@@ -829,31 +847,66 @@ __device__ __attribute__((noinline)) void full_forward(const FullArrays g, const
     uint32_t rc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const uint32_t L = 3u + (uint32_t)lane + 64u * j; rc[j] = L <= 258 ? s.depths[253 + L] : 0u; }
-    if (lane == 0) s.win[0] = 0;                               // vertex 0: depth 0
+    if (wave == 0 && lane == 0) s.win[0] = 0;                  // vertex 0: depth 0
     uint32_t inited = 1, carry = DINF;                         // carry: depth of the vertex in front of the batch
-    // (edge flag and literal byte of a batch are fetched while the batch before it is worked on: with one
-    //  wave per stream nothing else hides the latency of a load)
-    uint32_t fl_next = (uint32_t)lane < count ? g.flag_()[lane] : 0u;
-    uint32_t lb_next = (lane >= 1 && (uint32_t)lane <= count) ? in[bbase + lane - 1] : 0u;
-    for (uint32_t b0 = 0; b0 <= count; b0 += 64) {
-        const uint32_t fl = fl_next, lb = lb_next;
-        {
-            const uint32_t vn = b0 + 64 + (uint32_t)lane;
-            fl_next = vn < count ? g.flag_()[vn] : 0u;
-            lb_next = vn <= count ? in[bbase + vn - 1] : 0u;
+    // (the literal byte of a batch is fetched while the batch before it is worked on)
+    uint32_t lb_next = 0, fl_next = 0;
+    if (wave == 0) {
+        lb_next = (lane >= 1 && (uint32_t)lane <= count) ? in[bbase + lane - 1] : 0u;
+        fl_next = (uint32_t)lane < count ? g.flag_()[lane] : 0u;
+    }
+    for (uint32_t sb0 = 0; sb0 <= count; sb0 += 1024) {
+        // sixteen batches at a time, wave 0 tells the helpers which vertices have edges: through incompressible
+        // data they then sleep from one of these barriers to the next, one per 1024 vertices
+        const uint32_t spar = (sb0 >> 10) & 1;
+        if (WAVES > 1 && wave == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint32_t vq = sb0 + 64u * q + (uint32_t)lane;
+                const unsigned long long e = __ballot(vq < count && g.flag_()[vq] != 0);
+                if (lane == 0) s.fw_ems[spar][q] = e;
+            }
         }
-        const uint32_t need = (b0 + 64 + 258 < count ? b0 + 64 + 258 : count) + 1;
-        for (uint32_t j = inited + lane; j < need; j += 64) s.win[j & 511] = ~0ull;
-        inited = inited > need ? inited : need;
+        if (WAVES > 1) __syncthreads();
+    for (uint32_t b0 = sb0; b0 <= count && b0 < sb0 + 1024; b0 += 64) {
         const uint32_t nv = count + 1 - b0 < 64 ? count + 1 - b0 : 64;      // vertices b0 .. b0 + nv - 1 (the last one: `count`, the end)
         const uint32_t v = b0 + (uint32_t)lane;
-        const unsigned long long em = __ballot(fl != 0);
-        if (em) {
-            const uint32_t ns = count - b0 < 64 ? count - b0 : 64;
-            for (uint32_t i = lane; i < ns * 30; i += 64) s.batch[i] = g.slots_()[(uint64_t)b0 * 30 + i];
+        const uint32_t par = (b0 >> 6) & 1;
+        // (wave 0 has its own copy of the flags, fetched a batch ahead: no LDS round trip on its way through
+        //  edge-less batches)
+        unsigned long long em;
+        if (wave == 0) {
+            em = __ballot(fl_next != 0);
+            const uint32_t vn = b0 + 64 + (uint32_t)lane;
+            fl_next = vn < count ? g.flag_()[vn] : 0u;
+        } else {
+            em = uni64(s.fw_ems[spar][(b0 - sb0) >> 6]);
+            if (!em) continue;                                 // (wave 0 scans through it alone)
         }
-        const uint32_t cin = (v >= 1 && v <= count) ? s.depths[lb] : 0u;                   // the literal edge INTO v
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        uint32_t cin = 0;
+        if (wave == 0) {
+            const uint32_t lb = lb_next;
+            {
+                const uint32_t vn = b0 + 64 + (uint32_t)lane;
+                lb_next = vn <= count ? in[bbase + vn - 1] : 0u;
+            }
+            const uint32_t need = (b0 + 64 + 258 < count ? b0 + 64 + 258 : count) + 1;
+            for (uint32_t j = inited + lane; j < need; j += 64) s.win[j & 511] = ~0ull;
+            inited = inited > need ? inited : need;
+            if (em) {
+                const uint32_t ns = count - b0 < 64 ? count - b0 : 64;
+                for (uint32_t i = lane; i < ns * 30; i += 64) s.batch[i] = g.slots_()[(uint64_t)b0 * 30 + i];
+            }
+            cin = (v >= 1 && v <= count) ? s.depths[lb] : 0u;   // the literal edge INTO v
+            if (WAVES > 1 && em) {
+                s.fw_cin[par][lane] = cin;
+                if (lane == 0) s.fw_carry[par] = carry;
+            }
+        }
+        if (WAVES > 1 && em) {
+            __syncthreads();                                   // the batch is set up
+            if (wave != 0) { cin = s.fw_cin[par][lane]; carry = UNI(s.fw_carry[par]); }
+        } else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         uint64_t W; uint32_t Wd, D;
         uint32_t k = 0;
         for (;;) {
@@ -863,10 +916,10 @@ __device__ __attribute__((noinline)) void full_forward(const FullArrays g, const
             const unsigned long long rest = k < 64 ? (em >> k) << k : 0ull;
             if (!rest) break;
             const uint32_t kk = (uint32_t)__ffsll((long long)rest) - 1;
-            for (uint32_t kq = kk; kq < kk + 3 && kq < 64; ++kq) {
-                if (!((em >> kq) & 1)) continue;
+            // (four waves: this wave's vertex of the group; one wave: all three in turn)
+            for (uint32_t kq = kk + (WAVES > 1 ? (uint32_t)wave : 0u); kq < kk + (WAVES > 1 ? (uint32_t)wave + 1u : 3u); ++kq) {
+                if (!((WAVES == 1 || wave < 3) && kq < 64 && ((em >> kq) & 1) && count - (b0 + kq) >= 3)) continue;
                 const uint32_t vv = b0 + kq, rem = count - vv;
-                if (rem < 3) continue;
                 const uint32_t Dk = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kq);
                 const uint32_t run = lane < 30 ? s.batch[kq * 30 + lane] & 0xffffu : 0u;
                 unsigned long long m = __ballot(run > 0);
@@ -898,17 +951,32 @@ __device__ __attribute__((noinline)) void full_forward(const FullArrays g, const
                 }
             }
             k = kk + 3;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            wg_sync<WAVES>();                                  // the group's keys are in the ring
         }
+        if (wave != 0) continue;
         // the way in: the literal only when strictly cheaper than what the matches offer
         if ((uint32_t)lane < nv && v >= 1) {
             const uint32_t low = (uint32_t)W;
             g.up_()[v] = D < Wd ? 0x0001ff00u : (258u - (low >> 8)) << 16 | ((low & 0xff) - 1u) << 8;
         }
         carry = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)(nv - 1));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// (wave 0) one forward pass, with the helper waves if there are any
+template <int WAVES>
+__device__ __attribute__((noinline)) void full_forward(const FullArrays g, const gbyte *in, uint64_t bbase, uint32_t count, int lane)
+{
+    DLds &s = g_lds;
+    if (WAVES > 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the vertices' flags and slots are in memory
+        if (lane == 0) { s.fw_cmd = FW_PASS; s.fw_bbase = bbase; s.fw_count = count; }
+        __syncthreads();
+    }
+    forward_body<WAVES>(g, in, bbase, count, lane, 0);
+    if (WAVES > 1) __syncthreads();                            // (the helpers are back in their loop before anything else changes)
 }
 
 // minimize() backwards (:282-320): the path from the last vertex to the first, symbol frequencies into
@@ -988,12 +1056,13 @@ __device__ __forceinline__ void full_depths_update(int lane)
 }
 
 // Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), full form: trees(iterations:), header, the path's tokens
+template <int WAVES>
 __device__ __attribute__((noinline)) Bits full_block(Bits b, const FullArrays g, const gbyte *in, uint64_t bbase, uint32_t count,
                                                      bool final, int iterations, bool generic, int lane)
 {
     DLds &s = g_lds;
     for (int i = generic ? -iterations : 0;;) {
-        if (count) { FPROF(2); full_forward(g, in, bbase, count, lane); FPROF(4); full_backward(g, in, bbase, count, lane); FPROF(5); }
+        if (count) { FPROF(2); full_forward<WAVES>(g, in, bbase, count, lane); FPROF(4); full_backward(g, in, bbase, count, lane); FPROF(5); }
         else {
             for (int k = lane; k < 320; k += 64) s.freq[k] = k == 256 ? 1u : 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1043,11 +1112,27 @@ __device__ __attribute__((noinline)) Bits full_block(Bits b, const FullArrays g,
     return b;
 }
 
-__global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__restrict__ jobs, spng_result *__restrict__ results)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJob *__restrict__ jobs, spng_result *__restrict__ results)
 {
     DLds &s = g_lds;
     const DeflateJob *jp = jobs + blockIdx.x;
-    const int lane = threadIdx.x;
+    // Which of the four waves is the stream's main wave rotates with the workgroup: the waves of a workgroup go one to
+    // each SIMD, and the two workgroups a CU holds (placed 256 apart) should not keep their busy waves on the same one.
+    const int lane = threadIdx.x & 63;
+    const int wave = WAVES > 1 ? (int)UNI(((threadIdx.x >> 6) - (blockIdx.x + (blockIdx.x >> 8))) & 3) : 0;
+    if (WAVES > 1 && wave != 0) {
+        // helper waves: they serve the forward passes wave 0 announces (forward_body) until it says it is done
+        FullArrays gh;
+        gh.base = (gword *)uni64((uint64_t)jp->graph); gh.vcap = UNI(jp->graph_vertices);
+        const gbyte *inh = (const gbyte *)uni64((uint64_t)jp->src);
+        for (;;) {
+            __syncthreads();
+            if (UNI(s.fw_cmd) != FW_PASS) return;
+            forward_body<WAVES>(gh, inh, uni64(s.fw_bbase), UNI(s.fw_count), lane, wave);
+            __syncthreads();
+        }
+    }
     const gbyte *in = (const gbyte *)uni64((uint64_t)jp->src);
     const uint64_t n = uni64(jp->src_len);
     gword *ring = (gword *)uni64((uint64_t)jp->ring);
@@ -1092,7 +1177,7 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
     auto unfilled = [&]() { return (int)limit - 1 - (int)count; };
     auto close_block = [&](bool final) {
         const uint32_t doubled = 2 * limit < (1u << 21) ? 2 * limit : 1u << 21;     // trees(iterations:) :229
-        b = full_block(b, g, in, bbase, count, final, iterations, generic, lane);
+        b = full_block<WAVES>(b, g, in, bbase, count, final, iterations, generic, lane);
         generic = false; count = 0; limit = doubled < vcap + 1 ? doubled : vcap + 1;
     };
 
@@ -1193,6 +1278,10 @@ __global__ __launch_bounds__(64) void deflate_full_kernel(const DeflateJob *__re
     }
     if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
     drain(s, b, b.total, lane);
+    if (WAVES > 1) {
+        if (lane == 0) s.fw_cmd = FW_EXIT;                     // the helper waves leave
+        __syncthreads();
+    }
 #ifdef SPNG_DEFLATE_PROF
     if (lane == 0 && blockIdx.x == 0)
         printf("deflate_full prof Mcycles: insert %llu search %llu register %llu forward %llu backward %llu trees %llu tables %llu emit %llu\n",
@@ -1216,10 +1305,51 @@ uint64_t deflate_graph_bytes(uint64_t vertices)
     return ((vertices + 1) * (30 * 4 + 4 + 4 + 1 + 1) + 1024 + 255) & ~(uint64_t)255;
 }
 
-hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream)
+// How often does a 4-byte key repeat close by?  Sampled (four windows of 8192 positions, a 4096-entry table of the
+// last key per bucket): the full-search kernel is launched with helper waves only for streams whose vertices will
+// have edges to relax -- on incompressible input the four-wave form costs a few per cent and buys nothing.
+__global__ __launch_bounds__(64) void deflate_density_kernel(const DeflateJob *__restrict__ jobs, uint32_t *__restrict__ dense)
+{
+    __shared__ uint32_t tab[4096];
+    const int lane = threadIdx.x;
+    const DeflateJob *jp = jobs + blockIdx.x;
+    const gbyte *in = (const gbyte *)uni64((uint64_t)jp->src);
+    const uint64_t n = uni64(jp->src_len);
+    uint32_t hits = 0, seen = 0;
+    if (n >= 64) {
+        const uint64_t win = n / 4 < 8192 ? n / 4 : 8192;
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t from = (uint64_t)w * (n / 4);
+            for (int i = lane; i < 4096; i += 64) tab[i] = 0x9e3779b9u + (uint32_t)i;       // (no key hashes to its own filler)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            for (uint64_t p0 = 0; p0 + 4 <= win; p0 += 64) {
+                const uint64_t p = from + p0 + lane;
+                const bool live = p0 + lane + 4 <= win && p + 4 <= n;
+                const uint32_t key = live ? load32(in + p) : 0u;
+                const uint32_t h = (key * 0x9E3779B1u) >> 20;
+                const bool hit = live && tab[h] == key;
+                if (live) tab[h] = key;
+                hits += (uint32_t)__popcll(__ballot(hit));
+                seen += (uint32_t)__popcll(__ballot(live));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            }
+        }
+    }
+    if (lane == 0) dense[blockIdx.x] = (seen && hits * 20u >= seen) ? 1u : 0u;             // >= 5 % of the positions
+}
+
+hipError_t launch_deflate_density(const DeflateJob *d_jobs, uint32_t count, uint32_t *d_dense, hipStream_t stream)
 {
     if (!count) return hipSuccess;
-    deflate_full_kernel<<<count, 64, 0, stream>>>(d_jobs, d_results);
+    deflate_density_kernel<<<count, 64, 0, stream>>>(d_jobs, d_dense);
+    return hipGetLastError();
+}
+
+hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, bool helpers, spng_result *d_results, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    if (helpers) deflate_full_kernel<4><<<count, 256, 0, stream>>>(d_jobs, d_results);
+    else deflate_full_kernel<1><<<count, 64, 0, stream>>>(d_jobs, d_results);
     return hipGetLastError();
 }
 
