@@ -25,13 +25,15 @@
 //                             compressed data and decode from a GUESSED start (Huffman codes
 //                             self-synchronise: a decoder started at the wrong bit falls into step
 //                             with the true token boundaries after a few tokens).  Every lane records
-//                             the token starts it visited in an LDS bitmap; then the true start of
-//                             subsequence i+1 (the exit of subsequence i) is handed down the wave, a
-//                             lane re-decodes from it only until it lands on a bit its first chain
-//                             already visited, and the process repeats until no exit changes (two
-//                             or three rounds).  `count` does this and logs, per lane, the true
-//                             start and the number of tokens; `emit` replays exactly those tokens
-//                             into a 32-bit token stream in HBM (literal byte, or run/distance).
+//                             the token starts it visited in an LDS bitmap, then runs its chain on
+//                             through the subsequences behind it until it lands on a bit their owner
+//                             marked (from there on the two chains are one): a link.  Lane 0 started
+//                             on a true boundary, so the true chain is the set of lanes reachable from
+//                             it through the links (pointer doubling).  `count` does this and logs, per
+//                             subsequence, the bit at which the true chain enters it and the number of
+//                             tokens that start in it; `emit` replays exactly those tokens into a
+//                             32-bit token stream in HBM (literal byte, or run/distance), every lane
+//                             its own subsequence's.
 //   3. between Huffman decoding and LZ77 -- `resolve` (one workgroup per stream) turns tokens into
 //                             bytes an 8 KiB tile at a time with byte-parallel pointer jumping:
 //                             every output byte of the tile is a literal or points at an earlier
@@ -41,10 +43,16 @@
 //
 // Exactness.  The pipeline only ever reports SPNG_DONE, and only when every check of the reference
 // passed on the way (header rules, complete trees, references inside the output, capacity, Adler-32,
-// segment chain).  Anything else -- every error the reference would throw, truncated input, a
-// false-positive segment start, undefined references, log/token space exhausted -- leaves the stream
-// to inflate.hip, which re-decodes it from byte 0 with the reference's exact accept/reject behaviour
-// and error payloads.  spng_result.reserved tells which path produced a result (1 = this file).
+// segment chain).  Anything else -- every error the reference would throw, truncated input, undefined
+// references, log/token space exhausted -- leaves the stream to inflate.hip, which re-decodes it from
+// byte 0 with the reference's exact accept/reject behaviour and error payloads.  (A found segment start
+// that no chain member stops at -- a look-alike inside stored data -- is merely left off the chain.)
+// spng_result.reserved tells which path produced a result (1 = this file).
+//
+// Streams that arrive in pieces (spng_inflate_resume_batch).  The resume point of a stream is the first
+// segment start; a segment that meets a block it cannot take as it stands ends PARTIAL in front of it;
+// resolve begins with the window read back from the output, and the block boundary reached goes to the
+// serial kernel, which decodes the tail from there and so gives the reference's answer for the prefix.
 #include "common.hpp"
 #include "huffman.hpp"
 
