@@ -1,6 +1,6 @@
 // deflate.hip -- batched DEFLATE / zlib compression for gfx950, bit-exact with swift-png's
 // LZ77.Deflator at every level: greedy (0-3), lazy (4-7) and the shortest-path search (8 and up);
-// one wavefront per stream.
+// one wavefront per stream (plus three helper waves in the forward pass of the search on compressible input).
 //
 // Replaces (whole-stream form, i.e. LZ77.Deflator.push(all, last: true)):
 //   level table        Sources/LZ77/Deflator/LZ77.DeflatorSearch.swift:13-35
@@ -16,20 +16,22 @@
 // entered into the window, and the candidates of position p are the earlier positions with the
 // same 4-byte key, most recent first (first one at distance <= 32767, later ones < 32767), tried
 // until `attempts` run out or a run >= `goal` is seen; the first strictly longest run > 5 wins.
-// Only the parse (which positions are asked) is sequential.  So the wave works in three layers:
-//   * hash insertion, 64 positions per step: every lane hashes its key, reads the bucket head from
-//     LDS, an unrolled readlane sweep resolves same-bucket positions inside the batch, and each
-//     position's link (distance to the previous same-bucket position + a 16-bit key tag) goes to a
-//     64 K-entry ring in HBM.  Insertion runs ahead of the parse -- later positions never appear
-//     in an earlier position's chain, which only walks backwards;
-//   * match search, 64 positions per step: lane i walks the chain of position w+i (tag filter,
-//     then dword-wise comparison straight from the input), all lanes at once, so the HBM/L2
-//     latency of a chain hop is paid once per step instead of once per position;
-//   * the parse itself walks those 64 results on the scalar unit (readlane per token) with the
+// Only the parse (which positions are asked) is sequential.  So a stream's wave works in layers:
+//   * hash insertion, 64 positions per step: every lane hashes its key; its link is the distance to
+//     the nearest lower lane with the same bucket (radix match over the hash bits, one ballot per bit),
+//     else to the bucket head in LDS; links (+ a 16-bit key tag) go to a 64 K-entry ring in HBM.
+//     Insertion runs ahead of the parse -- later positions never appear in an earlier position's
+//     chain, which only walks backwards;
+//   * match search, 128 positions per step, two per lane (chain_walk2): both chains hop together and the
+//     candidate's first four bytes are fetched speculatively with the link, so the latency of a hop is
+//     paid once per pair;
+//   * the parse itself walks those answers on the scalar unit (readlane per token) with the
 //     reference's greedy / lazy rules, packing terms exactly like LZ77.DeflatorTerm.
 // When 2047 terms are queued (lazy: 2046/2047) the block is written: histogram with LDS atomics,
 // the reference's heap-based length-limited Huffman construction (ranked in parallel, merged on
-// one lane because its tie-breaking is order dependent), code-length RLE, and the token bits.
+// one lane because its tie-breaking is order dependent; depths by pointer jumping), canonical codes
+// by ballot, code-length RLE, and the bits of 64 terms at a time (prefix sum of their lengths, ds_or
+// into a zero-initialised staging ring).  Levels >= 8: see the second half of this file.
 #include "common.hpp"
 #include "huffman.hpp"      // UNI / uni64, WSYNC, DPP scans
 
@@ -743,20 +745,21 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
 // vertices (the limit doubles per block, 2048 ... 2^21) and finds the cheapest path through the block
 // with per-symbol costs in quarter bits that it re-derives from the trees of the previous pass
 // (trees(iterations:), :225-260; minimize / explore, :262-379; Depths, ...Depths.swift:31-98).
-// Here, per stream (one wave):
-//   * candidates: the 64-positions-at-a-time chain walk of the greedy / lazy kernel, every candidate
-//     recorded (per lane, thirty decade slots in LDS); the serial part is only deciding which
+// Here, per stream:
+//   * candidates: the 128-positions-at-a-time chain walk of the greedy / lazy kernel, every candidate
+//     recorded (per lane and half, thirty decade slots in LDS); the serial part is only deciding which
 //     positions are searched at all (behind a run > 100 the next run - 100 vertices get no edges,
-//     DeflatorBuffers.Stream.swift:376-380).  Vertices live in HBM: 30 slots each.
-//   * forward pass: vertices in order, 64 at a time through LDS; the best depth / incoming edge of the
-//     next 258 vertices sit in an LDS ring; one vertex relaxes its literal edge, then decade after
-//     decade (ascending, as the reference: ties go to the first writer) with the lanes spread over the
-//     run lengths 3 ... maxlen.
-//   * back-trace: 2048 vertices at a time from the end; which vertices lie on the path is found by
-//     pointer doubling over the chunk instead of a serial walk; path vertices tally the symbol
-//     frequencies and hand their edge to the vertex it starts from.
+//     DeflatorBuffers.Stream.swift:376-380).  Vertices live in HBM: a flag (has edges) and, for those
+//     that have, 30 slots.
+//   * forward pass (full_forward / forward_body): the best way into a vertex as the minimum of one 64-bit
+//     key over its incoming edges; along 64 vertices the depths are a min-plus prefix scan, match edges
+//     go through ds_min_u64 into an LDS ring, three vertices at a time; with helper waves on
+//     compressible input.
+//   * back-trace (full_backward): 64 vertices at a time from the end, the path hopping through the
+//     batch on the scalar unit; path vertices tally the symbol frequencies and hand their edge to the
+//     vertex it starts from.
 //   * trees, cost update, repeat (2 x iterations passes for the first block, iterations after);
-//     then the block is written walking the path forwards.
+//     then the block is written: the path's terms 64 at a time.
 struct FullArrays {      // (two registers' worth: passed to the non-inlined passes in SGPRs, not through scratch memory)
     gword *base; uint32_t vcap;
     // [vertex][30]: distance << 16 | longest run of that distance decade
