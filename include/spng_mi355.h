@@ -269,7 +269,10 @@ int32_t spng_filter(spng_ctx *ctx, const void *storage,
  * last row).  `hint` only sizes the reference's output chunks (platform dependent there): the host re-chunks
  * the concatenated stream into IDATs of any size.  d_dst capacity: spng_deflate_bound(src_len).  The window
  * exponent travels in spng_stream_desc.reserved (batch form) / the `exponent` argument; PNG always uses 15,
- * and LZ77.Format.ios ignores it (LZ77.DeflatorBuffers.swift:52-55). */
+ * and LZ77.Format.ios ignores it (LZ77.DeflatorBuffers.swift:52-55).  SPNG_FORMAT_GZIP: Gzip.Deflator (header, CRC-32 and
+ * byte count of the input appended on the device).  Levels >= 8: the call waits for a small probe kernel (how
+ * repetitive is each input: compressible streams get helper waves) before it enqueues the compression, so it is
+ * asynchronous only from there on. */
 uint64_t spng_deflate_bound(uint64_t n);
 int32_t spng_deflate_batch(spng_ctx *ctx, const spng_stream_desc *descs, const int32_t *levels, uint32_t count,
                            spng_result *d_results, spng_result *h_results);
