@@ -35,8 +35,9 @@ FORMAT_ZLIB, FORMAT_IOS, FORMAT_GZIP = 0, 1, 2
 K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER, K_PINFLATE = 0, 1, 2, 3, 4, 5, 6
 K_UNPACK = 7
 K_PINF_FIND, K_PINF_COUNT, K_PINF_EMIT, K_PINF_RESOLVE = 8, 9, 10, 11
+K_PINF_DECODE = 9
 CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES, CFG_UNFILTER_PIECE_ROWS = 0, 1, 2, 3
-INFLATE_AUTO, INFLATE_SERIAL = 0, 1
+INFLATE_AUTO, INFLATE_SERIAL, INFLATE_LEGACY = 0, 1, 2
 
 EXPORTS = [
     "spng_version", "spng_status_string", "spng_last_error_string", "spng_inflated_size",

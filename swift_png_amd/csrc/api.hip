@@ -77,6 +77,12 @@ struct spng_ctx {
     void *d_graph = nullptr; size_t graph_cap = 0;   // deflate levels >= 8: match graphs
     void *d_log = nullptr;  size_t log_cap = 0;
     void *d_tok = nullptr;  size_t tok_cap = 0;      // bytes
+    // token pool of the pipeline (pinflate2.hip): halfwords a compressed byte turned into in the last batch (learned,
+    // so that the next batch of the same kind takes one pass), and the pinned word the page counter is read back into
+    double   pool_ratio = 0;
+    uint32_t *h_pool_used = nullptr;
+    uint64_t pool_pages_planned = 0, pool_src_bytes = 0;
+    hipEvent_t pool_ev = nullptr; bool pool_pending = false;
     int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0, 0};
     // profiling
     bool profiling = false;
@@ -241,6 +247,8 @@ void spng_destroy(spng_ctx *c)
     if (c->d_graph) (void)hipFree(c->d_graph);
     if (c->d_log) (void)hipFree(c->d_log);
     if (c->d_tok) (void)hipFree(c->d_tok);
+    if (c->h_pool_used) (void)hipHostFree(c->h_pool_used);
+    if (c->pool_ev) (void)hipEventDestroy(c->pool_ev);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -442,6 +450,12 @@ struct InflatePlan {
     uint64_t tok_cap = 0;            // tokens
     uint32_t passes = 0;
     bool parallel = false;
+    bool legacy = false;             // SPNG_INFLATE_LEGACY: round 2's count / emit / resolve kernels (pinflate.hip)
+    // pinflate2: the token pool and the groups of streams that share it, one after the other
+    uint32_t pool_pages = 0;
+    struct Group { uint32_t s0, s1, g0, g1; };
+    std::vector<Group> groups;
+    size_t next_at = 0;
     bool gzip = false;               // some stream is SPNG_FORMAT_GZIP: header kernel in front, CRC-32 check behind
     std::vector<uint64_t> state;     // spng_inflate_resume_batch: {bit, written} per stream (else empty)
     size_t jobs_at = 0, streams_at = 0, segs_at = 0, done_at = 0, gz_at = 0, gzparts_at = 0, state_at = 0, sumparts_at = 0;
@@ -449,17 +463,24 @@ struct InflatePlan {
     {
         return jobs.size() * (sizeof(InflateJob) + sizeof(PStream) + 4 + (gzip ? 8 + 4 * (size_t)gzip_pieces() : 0) +
                               (state.empty() ? 0 : 16 + 8 * (size_t)gzip_pieces())) +
-               segs.size() * sizeof(PSeg) + 8192;
+               segs.size() * sizeof(PSeg) + 8192 + 512;
     }
 };
 
-// Cuts every stream into segments and makes sure the context owns a chunk-record slab and a token
-// buffer.  Segment length: long enough that the search for a block header (which costs more per bit
-// than decoding) stays a small part of a segment's work, short enough that the batch yields several
-// thousand segments, i.e. a few waves per SIMD.
+// Cuts every stream into segments and makes sure the context owns what the pipeline needs.  Segment length: long
+// enough that the search for a block header (which costs more per bit than decoding) stays a small part of a
+// segment's work, short enough that the batch yields several thousand segments, i.e. a few waves per SIMD.
+//
+// pinflate2 (the default): a page table per segment (c->d_log) and the token pool (c->d_tok, 64 KiB pages).  A
+// compressed byte becomes at most 8 token halfwords and a stream at most one per output byte; what a batch really
+// needs is far less (0.8 per byte for zlib-made PNG streams, 1.4 for swift-png's own), so the pool is sized by the
+// ratio the previous batch showed (3.2 bytes per byte before there is one), capped by SPNG_CFG_TOKEN_BYTES or half of
+// the free memory, and the streams take it in as many groups as that needs.  A segment that finds the pool empty
+// gives its stream to the serial kernel.
 static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
 {
     p.parallel = c->cfg[SPNG_CFG_INFLATE_MODE] != SPNG_INFLATE_SERIAL && !p.jobs.empty();
+    p.legacy = c->cfg[SPNG_CFG_INFLATE_MODE] == SPNG_INFLATE_LEGACY;
     for (auto &j : p.jobs) p.gzip = p.gzip || j.format == SPNG_FORMAT_GZIP;
     if (!p.parallel) return SPNG_DONE;
     uint64_t total = 0;
@@ -471,6 +492,15 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
     }
     seg_bytes = (seg_bytes + 255) & ~(uint64_t)255;
     p.streams.resize(p.jobs.size());
+    // what the last batch taught about token volume
+    if (!p.legacy && c->pool_pending && hipEventQuery(c->pool_ev) == hipSuccess) {
+        c->pool_pending = false;
+        const uint64_t used = c->h_pool_used[1];
+        if (c->h_pool_used[2]) c->pool_ratio = 0;                                   // it ran dry: back to the default
+        else if (c->pool_src_bytes > (1u << 20)) c->pool_ratio = (double)used * 65536.0 / (double)c->pool_src_bytes;
+    }
+    const double per_byte = p.legacy ? 0 : (c->pool_ratio > 0 ? (c->pool_ratio * 1.25 < 1.0 ? 1.0 : c->pool_ratio * 1.25) : 3.2);
+    std::vector<uint64_t> est(p.jobs.size(), 0);
     size_t log = 0;
     for (size_t i = 0; i < p.jobs.size(); ++i) {
         const InflateJob &j = p.jobs[i];
@@ -489,14 +519,27 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
             memset(&sg, 0, sizeof sg);
             sg.stream = (uint32_t)i; sg.index = (uint32_t)q;
             const uint64_t len = q + 1 < k ? seg_bytes : j.src_len - q * seg_bytes;
-            // chunk records: 272 bytes per 2304 bytes of Huffman data, one partial chunk and a 352-byte block
-            // record per block on top (swift-png's own level-6 streams: a block every ~3 KB)
-            sg.log_cap = ((len / 2 + 16384) + 15) & ~(uint64_t)15;
+            if (p.legacy) {
+                // chunk records: 272 bytes per 2304 bytes of Huffman data, one partial chunk and a 352-byte block
+                // record per block on top (swift-png's own level-6 streams: a block every ~3 KB)
+                sg.log_cap = ((len / 2 + 16384) + 15) & ~(uint64_t)15;
+            } else {
+                // page-table entries: 16 token bytes per compressed byte at most, and never more than two per output byte
+                uint64_t most = 16 * len;
+                if (most > 2 * (j.dst_cap + 64)) most = 2 * (j.dst_cap + 64);
+                sg.log_cap = (most >> 16) + 2;
+            }
             sg.log_off = log; log += sg.log_cap;
             sg.start_bit = ~0ull;
             p.segs.push_back(sg);
         }
+        if (!p.legacy) {
+            uint64_t e = (uint64_t)(per_byte * (double)j.src_len);
+            if (e > 2 * (j.dst_cap + 64)) e = 2 * (j.dst_cap + 64);
+            est[i] = e + k * 65536 + 65536;                                        // (every segment ends inside a page)
+        }
     }
+    if (!p.legacy) log *= 4;
     p.log_bytes = log;
     if (log > c->log_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -504,16 +547,20 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         HIP_TRY(hipMalloc(&c->d_log, log + log / 8));
         c->log_cap = log + log / 8;
     }
-    // Tokens: 0.6 per compressed byte from zlib on PNG scanlines, 1.3 from swift-png's own level-6
-    // streams (more literals).  Two per byte, but never more than one per output byte, is the planning
-    // figure; the budget caps the buffer and the batch then takes several passes over it.  The buffer
-    // must hold the largest stream whole.
     uint64_t want = 0, largest = 0;
-    for (auto &j : p.jobs) {
-        uint64_t t = 2 * j.src_len + 65536;
-        if (t > j.dst_cap + 64) t = j.dst_cap + 64;
-        want += t * 4;
-        if (t * 4 > largest) largest = t * 4;
+    if (p.legacy) {
+        // Tokens: 0.6 per compressed byte from zlib on PNG scanlines, 1.3 from swift-png's own level-6
+        // streams (more literals).  Two per byte, but never more than one per output byte, is the planning
+        // figure; the budget caps the buffer and the batch then takes several passes over it.  The buffer
+        // must hold the largest stream whole.
+        for (auto &j : p.jobs) {
+            uint64_t t = 2 * j.src_len + 65536;
+            if (t > j.dst_cap + 64) t = j.dst_cap + 64;
+            want += t * 4;
+            if (t * 4 > largest) largest = t * 4;
+        }
+    } else {
+        for (auto e : est) { want += e; if (e > largest) largest = e; }
     }
     uint64_t budget = (uint64_t)c->cfg[SPNG_CFG_TOKEN_BYTES];
     if (!budget) {
@@ -523,16 +570,47 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         if (budget < (64ull << 20)) budget = 64ull << 20;
     }
     if (budget < 2 * largest && !c->cfg[SPNG_CFG_TOKEN_BYTES]) budget = 2 * largest;
-    const uint64_t need = want < budget ? want : budget;
+    uint64_t need = want < budget ? want : budget;
+    if (!p.legacy && need < largest) need = largest;                               // (a stream is never split over groups)
+    need = (need + 65535) & ~(uint64_t)65535;
     if (need > c->tok_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_tok) { HIP_TRY(hipFree(c->d_tok)); c->d_tok = nullptr; c->tok_cap = 0; }
-        HIP_TRY(hipMalloc(&c->d_tok, need));
+        if (hipMalloc(&c->d_tok, need) != hipSuccess) {
+            // no room for the pipeline: the serial kernel takes the batch
+            (void)hipGetLastError();
+            c->d_tok = nullptr; c->tok_cap = 0;
+            p.parallel = false; p.streams.clear(); p.segs.clear();
+            return SPNG_DONE;
+        }
         c->tok_cap = need;
     }
-    p.tok_cap = c->tok_cap / 4;
-    uint64_t passes = (want + c->tok_cap - 1) / c->tok_cap + 1;
-    p.passes = (uint32_t)(passes > 8 ? 8 : passes);
+    if (p.legacy) {
+        p.tok_cap = c->tok_cap / 4;
+        uint64_t passes = (want + c->tok_cap - 1) / c->tok_cap + 1;
+        p.passes = (uint32_t)(passes > 8 ? 8 : passes);
+        return SPNG_DONE;
+    }
+    // groups of consecutive streams whose estimates fit the pool together
+    const uint64_t pool = c->tok_cap & ~(uint64_t)65535;
+    p.pool_pages = (uint32_t)(pool >> 16 > 0xfffffff0ull ? 0xfffffff0ull : pool >> 16);
+    uint64_t run = 0;
+    InflatePlan::Group g{0, 0, 0, 0};
+    for (size_t i = 0; i < p.jobs.size(); ++i) {
+        if (run + est[i] > pool && g.s1 > g.s0) {
+            p.groups.push_back(g);
+            g.s0 = g.s1; g.g0 = g.g1; run = 0;
+        }
+        run += est[i];
+        g.s1 = (uint32_t)i + 1; g.g1 = p.streams[i].seg_first + p.streams[i].seg_count;
+    }
+    p.groups.push_back(g);
+    c->pool_pages_planned = p.pool_pages;
+    c->pool_src_bytes = total;
+    if (!c->h_pool_used) {
+        HIP_TRY(hipHostMalloc((void **)&c->h_pool_used, 64, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&c->pool_ev, hipEventDisableTiming));
+    }
     return SPNG_DONE;
 }
 
@@ -554,6 +632,10 @@ static void stage_inflate(InflatePlan &p, Arena &a)
         memcpy(a.host<PStream>(p.streams_at), p.streams.data(), n * sizeof(PStream));
         memcpy(a.host<PSeg>(p.segs_at), p.segs.data(), p.segs.size() * sizeof(PSeg));
     }
+    if (p.parallel && !p.legacy) {
+        p.next_at = a.take(64);
+        memset(a.host<uint32_t>(p.next_at), 0, 64);
+    }
     if (p.parallel || p.gzip) {
         p.done_at = a.take(n * 4);
         memset(a.host<int32_t>(p.done_at), 0, n * 4);
@@ -568,7 +650,29 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
     if (p.gzip)   // (slots behind the uploaded part of the arena: the header kernel fills them)
         HIP_TRY(launch_gzip_pre(a.dev<InflateJob>(p.jobs_at), p.parallel ? a.dev<PStream>(p.streams_at) : nullptr, dr,
                                 a.dev<uint64_t>(p.gz_at), a.dev<int32_t>(p.done_at), n, c->stream));
-    if (p.parallel) {
+    if (p.parallel && !p.legacy) {
+        Timed whole(c, SPNG_K_PINFLATE);
+        PStream *ds = a.dev<PStream>(p.streams_at);
+        PSeg *dg = a.dev<PSeg>(p.segs_at);
+        int32_t *dd = a.dev<int32_t>(p.done_at);
+        uint32_t *dnext = a.dev<uint32_t>(p.next_at);
+        for (size_t gi = 0; gi < p.groups.size(); ++gi) {
+            const InflatePlan::Group &g = p.groups[gi];
+            if (gi) HIP_TRY(hipMemsetAsync(dnext, 0, 4, c->stream));
+            { Timed t(c, SPNG_K_PINF_FIND); HIP_TRY(launch_pinf2_find(ds, dg + g.g0, g.g1 - g.g0, c->stream)); }
+            { Timed t(c, SPNG_K_PINF_DECODE); HIP_TRY(launch_pinf2_decode(ds, dg + g.g0, g.g1 - g.g0, (uint32_t *)c->d_log, (uint8_t *)c->d_tok, dnext, p.pool_pages, c->stream)); }
+            HIP_TRY(launch_pinf2_scan(ds + g.s0, g.s1 - g.s0, dg, c->stream));
+            { Timed t(c, SPNG_K_PINF_RESOLVE); HIP_TRY(launch_pinf2_resolve(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, (uint8_t *)c->d_tok, p.pool_pages, dr, dd + g.s0, c->stream)); }
+            HIP_TRY(launch_pinf2_account(dnext, p.pool_pages, c->stream));
+        }
+        if (!c->pool_pending) {
+            // pages this batch took: read at the start of the next one (never waited for)
+            HIP_TRY(hipMemcpyAsync(c->h_pool_used, dnext, 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipEventRecord(c->pool_ev, c->stream));
+            c->pool_pending = true;
+        }
+    }
+    if (p.parallel && p.legacy) {
         Timed whole(c, SPNG_K_PINFLATE);
         PStream *ds = a.dev<PStream>(p.streams_at);
         PSeg *dg = a.dev<PSeg>(p.segs_at);

@@ -99,11 +99,11 @@ enum { PSEG_FAIL = 0, PSEG_CONT = 1, PSEG_FINAL = 2, PSEG_PARTIAL = 3 };
 // One segment: the blocks that start in [index * seg_bytes, (index + 1) * seg_bytes).
 struct PSeg {
     uint32_t stream, index;
-    uint64_t log_off, log_cap;             // its chunk records in the log slab (bytes)
+    uint64_t log_off, log_cap;             // pinflate2: its page table (first entry, entries); legacy: its chunk records in the log slab (bytes)
     // device side
     uint64_t start_bit;                    // find: first block header at or after the nominal start (~0: none)
     uint64_t end_bit;                      // count: where decoding stopped (start of the next block)
-    uint64_t ntok;                         // count
+    uint64_t ntok;                         // decode: token halfwords (legacy count: tokens)
     uint64_t tok_base;                     // scan: first token, relative to the stream's
     int32_t  status;                       // count: PSEG_*
     uint32_t used;                         // scan: part of the chain
@@ -141,6 +141,14 @@ hipError_t launch_pinf_emit(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, ui
                             hipStream_t stream);
 hipError_t launch_pinf_resolve(PStream *d_streams, uint32_t nstreams, uint32_t *d_tokens, spng_result *d_results, int32_t *d_done,
                                uint32_t pass, hipStream_t stream);
+// pinflate2.hip
+hipError_t launch_pinf2_find(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, hipStream_t stream);
+hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint32_t *d_pt, uint8_t *d_pool, uint32_t *d_next,
+                               uint32_t pages, hipStream_t stream);
+hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, hipStream_t stream);
+hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
+                                spng_result *d_results, int32_t *d_done, hipStream_t stream);
+hipError_t launch_pinf2_account(uint32_t *d_ctr, uint32_t pages, hipStream_t stream);
 hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 // gzip.hip
 static constexpr uint64_t GZ_NONE = ~0ull;

@@ -1,0 +1,1248 @@
+// pinflate2.hip -- the parallel inflate pipeline of spng_inflate_batch / spng_decode_batch (gfx950).
+//
+// Replaces, for streams the reference accepts, the same functions as inflate.hip:
+//   block readers      Sources/LZ77/Inflator/LZ77.InflatorBuffers.Stream.swift:59-429
+//   zlib header        Sources/LZ77/Inflator/LZ77.StreamHeader.swift:16-54
+//   tree validation    Sources/LZ77/HuffmanCoding/LZ77.HuffmanTree.swift:80-174
+//   output window      Sources/LZ77/Inflator/LZ77.InflatorOut.swift:124-139 (expand)
+//   Adler-32           Sources/LZ77/Wrappers/LZ77.MRC32.swift:26-50
+//
+// A DEFLATE stream is a serial chain at three levels; the pipeline breaks it three times:
+//
+//   find     a stream is cut into segments of seg_bytes; from every segment's nominal start a wave looks
+//            for the first bit at which a complete dynamic block header parses.  Segments decode
+//            concurrently; a segment must end exactly on the next segment's start (scan), so a false
+//            positive can only send the stream to the serial kernel, never produce wrong output.
+//   decode   one wave per segment, block after block, a chunk of 64 subsequences at a time: every lane
+//            decodes its subsequence from a GUESSED start (Huffman codes self-synchronise) and marks the
+//            token starts it visits (round 0), runs its chain on until it lands on a bit a later lane
+//            marked (round 1: a link), the true chain is the set of lanes reachable from lane 0 (pointer
+//            doubling), and -- tables and compressed bytes still in LDS -- every lane on it decodes
+//            exactly the tokens that start in its subsequence once more, now into a compact token
+//            stream: 16-bit halfwords (a literal is one, a back-reference two), staged in LDS and written
+//            to HBM in whole aligned 16-byte units.  Round 2's count + emit (two kernels, a log slab, the
+//            tables of every block built twice, 4-byte tokens written in pieces) are this one kernel.
+//            Token space comes from a page pool (64 KiB pages, one atomic per page), so nothing has to
+//            be counted before it is written.
+//   resolve  one 512-thread workgroup per stream turns tokens into bytes, a tile (<= 8 KiB) at a time.
+//            Thread t owns bytes t, t + 512, ...: consecutive lanes, consecutive bytes, so every LDS
+//            access of a wave is a contiguous row or a gather with few distinct addresses.  Literals go
+//            straight to their byte's state; back-references leave a record and one bit (their first
+//            byte) in a bitmap, and a byte finds the reference that covers it by a popcount over its
+//            row's bitmap word.  Sources before the tile come from the 32 KiB LDS ring; pointers inside
+//            the tile are halved by pointer jumping, rows that are complete cost nothing.  The tile
+//            leaves for HBM in whole 16-byte units of the output position, Adler-32 folded in.
+//
+// Exactness.  The pipeline only ever reports SPNG_DONE, and only when every check of the reference
+// passed on the way (header rules, complete trees, references inside the output, capacity, Adler-32,
+// segment chain).  Anything else is left to inflate.hip, which decodes with the reference's exact
+// accept/reject behaviour and error payloads.  spng_result.reserved tells which path produced a result.
+//
+// Streams that arrive in pieces (spng_inflate_resume_batch): the resume point is the first segment start; a
+// segment that meets a block it cannot take as it stands ends PARTIAL in front of it; resolve begins with
+// the window read back from the output, and the block boundary reached goes to the serial kernel.
+#include "common.hpp"
+#include "huffman.hpp"
+
+namespace spng {
+
+#ifdef SPNG_EMU
+#define AS_GLOBAL
+#else
+#define AS_GLOBAL __attribute__((address_space(1)))
+#endif
+typedef uint32_t v4u __attribute__((vector_size(16)));
+struct __attribute__((packed)) PV4 { v4u v; };
+typedef uint8_t AS_GLOBAL g8;
+typedef uint16_t AS_GLOBAL g16;
+typedef uint32_t AS_GLOBAL g32;
+typedef PV4 AS_GLOBAL gPV4;
+
+static constexpr int LB = 9, DB = 8, MB = 7;         // LUT index bits: lit/len, distance, code-length code
+static constexpr int SDW_MAX = 9;                      // dwords per lane subsequence (odd: conflict-free LDS stride)
+static constexpr int STAGE2_DW = 592;                  // staged compressed data: a chunk (2304 B) + alignment + a token's reach
+static constexpr uint32_t HWCAP = 2048;                // halfwords the LDS token buffer holds
+static constexpr uint32_t PAGE_SHIFT = 16;             // token pages: 64 KiB
+static constexpr uint32_t PAGE_UNITS = 1u << (PAGE_SHIFT - 4);
+static constexpr uint64_t NONE2 = ~0ull;
+static constexpr uint32_t TK_NULL = 0xffffu;           // padding halfword (a "second half" without a first: length 0)
+
+// token halfwords:  literal 0x0000 | byte;  reference 0x8000 | (distance - 1 & 63) << 8 | (run - 3), then
+// 0xC000 | (distance - 1) >> 6
+__device__ __forceinline__ uint32_t tk_m0(uint32_t run, uint32_t dist) { return 0x8000u | ((dist - 1) & 63) << 8 | (run - 3); }
+__device__ __forceinline__ uint32_t tk_m1(uint32_t dist) { return 0xC000u | (dist - 1) >> 6; }
+
+struct DPool { uint8_t *base; uint32_t *next; uint32_t pages, pad; };
+
+// ---- per-wave LDS of find / decode ----------------------------------------------------------------------
+struct DLds {
+    uint32_t lit[1 << LB];
+    uint32_t dist[1 << DB];
+    uint32_t ext_lit[288];             // LUT entries in canonical code order, for codes longer than the LUT index
+    uint32_t ext_dist[32];
+    Tree     tlit, tdist;
+    uint32_t stage[STAGE2_DW];
+    union {
+        struct {                       // while a header is parsed
+            uint8_t  lens[512];        //   code lengths (<= 318 + a run's overshoot)
+            uint32_t clut[1 << MB];    //   LUT of the code-length code
+            uint32_t hb[6][16];        //   per batch of 64 symbols: how many of each length (5 lit/len batches, distances)
+            uint32_t cl[32];
+        } h;
+        struct {                       // rounds 0 and 1 of a chunk
+            uint32_t vmap[SDW_MAX * 64];   // visited-token-start bitmaps, word w of lane l at [w * 64 + l]
+            uint16_t flag[64], mpos[64];   // lanes on the true chain; where it merges into their chains
+            uint32_t ent[64];              // where it enters each subsequence | halfwords it decodes there before merging << 16
+        } c;
+        uint16_t hw[HWCAP];            // the chunk's tokens on their way to HBM (find: the search window)
+    };
+};
+
+struct Lim2 { uint32_t lit[15 - LB], dist[15 - DB]; };
+
+// ---- staging ------------------------------------------------------------------------------------------
+__device__ __forceinline__ v4u ld16(const g8 *src, uint64_t n, uint64_t off)
+{
+    v4u v = {0, 0, 0, 0};
+    if (off + 16 <= n) v = ((const gPV4 *)(src + off))->v;
+    else if (off < n) {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int b = 0; b < 16; ++b) if (off + b < n) w[b >> 2] |= (uint32_t)src[off + b] << (8 * (b & 3));
+        v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+    }
+    return v;
+}
+// copies `dwords` dwords (a multiple of 4) of the stream starting at byte `from` into dst; bytes past the end read as zero
+__device__ __forceinline__ void stage_bytes2(uint32_t *dst, const g8 *src, uint64_t n, uint64_t from, int dwords, int lane)
+{
+    for (int k = 0; k * 256 < dwords; ++k)
+        if (k * 256 + lane * 4 < dwords) *(v4u *)(dst + k * 256 + lane * 4) = ld16(src, n, from + (uint64_t)k * 1024 + (uint64_t)lane * 16);
+    WSYNC();
+}
+struct SR2 { v4u v[(STAGE2_DW + 255) / 256]; };
+__device__ __forceinline__ void stage_fetch2(SR2 &r, const g8 *src, uint64_t n, uint64_t from, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < (STAGE2_DW + 255) / 256; ++k)
+        if (k * 256 + lane * 4 < STAGE2_DW) r.v[k] = ld16(src, n, from + (uint64_t)k * 1024 + (uint64_t)lane * 16);
+}
+__device__ __forceinline__ void stage_put2(uint32_t *dst, const SR2 &r, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < (STAGE2_DW + 255) / 256; ++k)
+        if (k * 256 + lane * 4 < STAGE2_DW) *(v4u *)(dst + k * 256 + lane * 4) = r.v[k];
+    WSYNC();
+}
+__device__ __forceinline__ void fetch2(const uint32_t *stage, uint32_t q, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t w = q >> 5;
+    const uint32_t d0 = stage[w], d1 = stage[w + 1], d2 = stage[w + 2];
+    lo = __builtin_amdgcn_alignbit(d1, d0, q);
+    hi = __builtin_amdgcn_alignbit(d2, d1, q);
+}
+__device__ __forceinline__ uint32_t upeek32_2(const uint32_t *stage, uint32_t q)
+{
+    uint32_t lo, hi;
+    fetch2(stage, q, lo, hi);
+    return UNI(lo);
+}
+__device__ __forceinline__ uint64_t upeek64_2(const uint32_t *stage, uint32_t q)
+{
+    uint32_t lo, hi;
+    fetch2(stage, q, lo, hi);
+    return (uint64_t)UNI(hi) << 32 | UNI(lo);
+}
+
+// ---- block headers ------------------------------------------------------------------------------------
+struct Hdr2 {
+    uint32_t type, bfinal;
+    uint64_t payload;                  // first bit of the compressed data / first BYTE of stored data * 8
+    uint32_t stored;                   // stored blocks: LEN
+    uint32_t minlen;                   // Huffman blocks: the shortest lit/len code
+};
+
+// The code-length code (readBlockTables, InflatorBuffers.Stream.swift:144-190): 19 lengths of <= 7 bits.  Lane
+// i < 19 holds the length of symbol i.  Builds the 2^7-entry LUT (entry = code length | symbol << 16).
+// false: not a complete code (HuffmanTree.swift:80-108).
+__device__ __forceinline__ bool build_clut(DLds &s, uint32_t mylen, int lane)
+{
+    // lane l < 8 gets the number of symbols of length l
+    uint32_t cnt = 0, before = 0;
+#pragma unroll
+    for (uint32_t l = 1; l <= 7; ++l) {
+        const unsigned long long m = __ballot(lane < 19 && mylen == l);
+        cnt = (uint32_t)lane == l ? (uint32_t)__popcll(m) : cnt;
+        before = mylen == l ? (uint32_t)__popcll(m & ((1ull << lane) - 1)) : before;   // rank among the symbols of my length
+    }
+    const uint32_t scaled = (lane >= 1 && lane <= 7) ? cnt << (7 - lane) : 0u;
+    if (UNI(wave_sum(scaled)) != 128u) return false;
+    const uint32_t first = ((row_scan(scaled) - scaled) >> (7 - (lane & 7))) & 127;      // canonical first code of length `lane`
+    if (lane < 16) s.h.cl[lane] = first;
+    WSYNC();
+    if (lane < 19 && mylen) {
+        const uint32_t code = s.h.cl[mylen] + before;
+        const uint32_t rev = __brev(code) >> (32 - mylen);
+        const uint32_t e = mylen | (uint32_t)lane << 16;
+        for (uint32_t j = rev; j < (1u << MB); j += 1u << mylen) s.h.clut[j] = e;
+    }
+    WSYNC();
+    return true;
+}
+
+// The run-length coded code lengths (InflatorBuffers.Stream.swift:191-263).  64 bit positions at a time: every
+// lane decodes the symbol that WOULD start at its position, the true chain through the 64 answers is walked
+// on the scalar unit (v_readlane), a prefix sum over the symbols on it gives the write positions, and "the
+// previous length" of a repeat is the nearest lower lane that defines one.  On success lens[0 .. want) are
+// the code lengths and `rel` is the first bit behind them.  false: a sequence the reference rejects (repeat
+// without a previous length, a run past the declared count), or one that does not end inside the input.
+__device__ __attribute__((always_inline)) bool decode_lengths2(DLds &s, uint32_t &rel, uint32_t rel_end, uint32_t want, int lane)
+{
+    for (int i = lane; i < 128; i += 64) ((uint32_t *)s.h.lens)[i] = 0;
+    WSYNC();
+    uint32_t have = 0, p = rel;
+    uint32_t prev = 0; bool prev_ok = false;
+    for (int window = 0; window < 80; ++window) {           // (a sequence is at most 318 symbols of >= 1 bit)
+        if (p >= rel_end || p + 64 + 16 > 256u * 32) return false;     // (a header parse stages 1 KiB)
+        const uint32_t q = p + (uint32_t)lane;
+        const uint32_t w = q >> 5;
+        const uint32_t bits = __builtin_amdgcn_alignbit(s.stage[w + 1], s.stage[w], q);
+        const uint32_t e = s.h.clut[bits & ((1u << MB) - 1)];
+        const uint32_t len = e & 15, sym = e >> 16;
+        const uint32_t extra = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+        const uint32_t rep = sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + ((bits >> len) & ((1u << extra) - 1));
+        const uint32_t nb = len + extra;                      // 1 .. 14
+        // the chain through this window
+        unsigned long long mask = 0;
+        uint32_t pp = 0;
+        while (pp < 64) {
+            mask |= 1ull << pp;
+            pp += (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)pp);
+        }
+        const bool is = (mask >> lane) & 1;
+        const uint32_t r = is ? rep : 0u;
+        uint32_t tot;
+        const uint32_t idx = have + wave_excl_scan(r, tot, lane);
+        // the previous length as seen by a repeat (symbol 16): the nearest lower symbol that is not one
+        const uint32_t val = sym < 16 ? sym : 0u;
+        const unsigned long long defm = __ballot(is && sym != 16);
+        const unsigned long long below = defm & ((1ull << lane) - 1);
+        const int pl = below ? 63 - __clzll((long long)below) : 0;
+        const uint32_t pv = (uint32_t)__shfl((int)val, pl, 64);
+        const uint32_t lastcur = below ? pv : prev;
+        const bool ok = below ? true : prev_ok;
+        const bool active = is && idx < want;
+        const bool bad = active && (idx + r > want || (sym == 16 && !ok));
+        if (active && !bad) {
+            if (sym < 16) s.h.lens[idx] = (uint8_t)sym;
+            else if (sym == 16) for (uint32_t k = 0; k < r; ++k) s.h.lens[idx + k] = (uint8_t)lastcur;
+        }
+        const unsigned long long endm = __ballot(active && idx + r == want);
+        if (__ballot(bad)) return false;
+        if (endm) {
+            const int el = __ffsll((long long)endm) - 1;
+            rel = p + (uint32_t)el + (uint32_t)__builtin_amdgcn_readlane((int)nb, el);
+            WSYNC();
+            return rel <= rel_end;
+        }
+        have += tot;
+        if (defm) { prev = (uint32_t)__shfl((int)val, 63 - __clzll((long long)defm), 64); prev_ok = true; }
+        p += pp;
+    }
+    return false;
+}
+
+// Both decode tables of a Huffman block from lens[0 .. literals + distances), in three LDS phases: per-batch
+// histograms of the code lengths; completeness, canonical first codes and offsets (lit/len in lanes 0-15, distances
+// in lanes 16-31); then every lane ranks its own symbols and scatters their LUT copies.  Restates
+// HuffmanTree.swift:80-174 (validate / size) and the decade tables of LZ77.Composites.swift.  false: a code
+// the reference rejects.  minlen = the shortest lit/len code.
+__device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t literals, uint32_t distances, uint32_t &minlen, int lane)
+{
+    uint32_t ll[5], dl;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const uint32_t sym = (uint32_t)lane + 64u * k; ll[k] = sym < literals ? s.h.lens[sym] : 0u; }
+    dl = (uint32_t)lane < distances ? s.h.lens[literals + lane] : 0u;
+    for (int i = lane; i < 96; i += 64) (&s.h.hb[0][0])[i] = 0;
+    WSYNC();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) __hip_atomic_fetch_add(&s.h.hb[k][ll[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&s.h.hb[5][dl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t dused = (uint32_t)__popcll(__ballot(dl != 0));
+    const unsigned long long d1m = __ballot(dl == 1);
+    WSYNC();
+    // lanes 0-15: lit/len lengths, lanes 16-31: distance lengths
+    const uint32_t L = (uint32_t)lane & 15;
+    const bool isd = lane >= 16 && lane < 32;
+    uint32_t c = 0;
+    if (lane < 16) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const uint32_t v = s.h.hb[k][L]; s.h.hb[k][L] = run; run += v; }   // -> symbols of this length in earlier batches
+        c = L ? run : 0u;
+    } else if (isd) {
+        c = L ? s.h.hb[5][L] : 0u;
+    }
+    const uint32_t scaled = c << (15 - L);                  // (c is 0 in lanes >= 32)
+    const uint32_t kraft = row_scan(scaled);                 // inclusive, per row of 16 lanes
+    const uint32_t klit = (uint32_t)__builtin_amdgcn_readlane((int)kraft, 15);
+    const uint32_t kdist = (uint32_t)__builtin_amdgcn_readlane((int)kraft, 31);
+    if (klit != 32768u) return false;
+    // distances: 0 or 1 used symbol of length 1 gives a stub whose unused half the reference leaves uninitialised
+    // (HuffmanTree.swift:52-65, validate(symbols:normalizing:) :112-135)
+    const bool stub = dused == 0 || (dused == 1 && d1m != 0);
+    if (!stub && kdist != 32768u) return false;
+    const uint32_t first = (kraft - scaled) >> (15 - L);
+    const uint32_t off = row_scan(c) - c;
+    if (lane < 32 && L) {
+        Tree &t = isd ? s.tdist : s.tlit;
+        t.first[L] = (uint16_t)first; t.count[L] = (uint16_t)c; t.offset[L] = (uint16_t)off;
+    }
+    {
+        const unsigned long long nz = __ballot(lane < 16 && c != 0);
+        minlen = (uint32_t)__ffsll((long long)nz) - 1;
+    }
+#pragma unroll
+    for (int j = 0; j < (1 << LB) / 64; ++j) s.lit[j * 64 + lane] = 0;      // 0 = "longer than the LUT index"
+#pragma unroll
+    for (int j = 0; j < (1 << DB) / 64; ++j)
+        s.dist[j * 64 + lane] = !stub ? 0u : (dused && !((j * 64 + lane) & 1)) ? dist_entry((uint32_t)(__ffsll((long long)d1m) - 1), 1)
+                                                                               : entry(1, 0, K_UNDEF, 0);
+    WSYNC();
+    // ---- every lane: its five lit/len symbols and its distance symbol
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t my = ll[k], sym = (uint32_t)lane + 64u * k;
+        unsigned long long same = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned long long bk = __ballot((my >> b) & 1);
+            same &= (my >> b) & 1 ? bk : ~bk;
+        }
+        if (my) {
+            const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1));
+            const uint32_t rank = s.h.hb[k][my] + before;
+            const uint32_t f = s.tlit.first[my], o = s.tlit.offset[my];
+            const uint32_t e = litlen_entry(sym, my);
+            s.ext_lit[o + rank] = e;
+            if (my <= (uint32_t)LB) {
+                const uint32_t rev = __brev(f + rank) >> (32 - my);
+                for (uint32_t j = rev; j < (1u << LB); j += 1u << my) s.lit[j] = e;
+            }
+        }
+    }
+    if (!stub) {
+        const uint32_t my = dl;
+        unsigned long long same = ~0ull;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned long long bk = __ballot((my >> b) & 1);
+            same &= (my >> b) & 1 ? bk : ~bk;
+        }
+        if (my) {
+            const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
+            const uint32_t f = s.tdist.first[my], o = s.tdist.offset[my];
+            const uint32_t e = dist_entry((uint32_t)lane, my);
+            s.ext_dist[o + rank] = e;
+            if (my <= (uint32_t)DB) {
+                const uint32_t rev = __brev(f + rank) >> (32 - my);
+                for (uint32_t j = rev; j < (1u << DB); j += 1u << my) s.dist[j] = e;
+            }
+        }
+    } else if (lane >= 1 && lane < 16) {
+        // (a stub has no long codes: every length's limit must read "none")
+        s.tdist.first[lane] = 0; s.tdist.count[lane] = 0; s.tdist.offset[lane] = 0;
+    }
+    WSYNC();
+    return true;
+}
+
+// Parses the block header at absolute bit `pos` with the reference's rules (readBlockMetadata /
+// readBlockTables, InflatorBuffers.Stream.swift:59-263) and, for Huffman blocks, builds the decode
+// tables.  false = anything the reference would not accept as is (errors, truncation): the caller
+// gives the block up.  Wave-uniform.
+__device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *src, uint64_t n, uint64_t pos, Hdr2 &h, int lane)
+{
+    const uint64_t total = n * 8;
+    if (pos + 3 > total) return false;
+    const uint64_t wbyte = (pos >> 5) << 2;
+    stage_bytes2(s.stage, src, n, wbyte, 256, lane);
+    uint32_t rel = (uint32_t)(pos - wbyte * 8);
+    const uint32_t first = upeek32_2(s.stage, rel);
+    h.bfinal = first & 1; h.type = (first >> 1) & 3;
+    h.stored = 0; h.minlen = 7; h.payload = 0;
+    if (h.type == 0) {
+        const uint64_t boundary = (pos + 3 + 7) & ~(uint64_t)7;
+        if (boundary + 32 > total) return false;
+        const uint32_t v = upeek32_2(s.stage, (uint32_t)(boundary - wbyte * 8));
+        const uint32_t l = v & 0xffff, m = v >> 16;
+        if (l != (~m & 0xffffu)) return false;
+        const uint64_t from = boundary / 8 + 4;
+        if (from + l > n) return false;
+        h.stored = l; h.payload = from * 8;
+        return true;
+    }
+    if (h.type == 3) return false;
+    uint32_t literals, distances;
+    if (h.type == 1) {
+        for (int i = lane; i < 320; i += 64) s.h.lens[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : i < 288 ? 8 : 5;
+        WSYNC();
+        literals = 288; distances = 32;
+        h.payload = pos + 3;
+    } else {
+        if (pos + 17 > total) return false;
+        literals = 257 + ((first >> 3) & 31);
+        distances = 1 + ((first >> 8) & 31);
+        const uint32_t codelengths = 4 + ((first >> 13) & 15);
+        rel += 17;
+        if (pos + 17 + 3 * (uint64_t)codelengths > total) return false;
+        if (literals > 286) return false;
+        const uint64_t packed = upeek64_2(s.stage, rel) & ((1ull << (3 * codelengths)) - 1);
+        rel += 3 * codelengths;
+        // lane i <- the length of code-length symbol i (transmitted in the order 16, 17, 18, 0, 8, 7, ...)
+        // (position of symbol i in that order, in closed form: 16-18 first, 0, then 8 7 9 6 10 5 ... alternating)
+        const uint32_t sym = (uint32_t)lane;
+        const uint32_t at = sym >= 16 ? sym - 16 : sym == 0 ? 3u : sym <= 7 ? 19 - 2 * sym : 2 * sym - 12;
+        const uint32_t mylen = (lane < 19 && at < codelengths) ? (uint32_t)((packed >> (3 * (at < 19 ? at : 0))) & 7) : 0u;
+        if (!UB(build_clut(s, mylen, lane))) return false;
+        const uint32_t rel_end = (uint32_t)((total - wbyte * 8) > 0xffffffffull ? 0xffffffffu : (total - wbyte * 8));
+        if (!UB(decode_lengths2(s, rel, rel_end, literals + distances, lane))) return false;
+        h.payload = wbyte * 8 + rel;
+    }
+    uint32_t minlen = 7;
+    if (!UB(build_tables2(s, literals, distances, minlen, lane))) return false;
+    h.minlen = UNI(minlen);
+    return true;
+}
+
+__device__ __forceinline__ void load_limits2(const DLds &s, Lim2 &lc)
+{
+    // lengths no symbol has: limit = that of the next shorter length (count 0), so the compare chain skips them
+#pragma unroll
+    for (int k = 0; k < 15 - LB; ++k) { const int l = LB + 1 + k; lc.lit[k] = UNI((uint32_t)(s.tlit.first[l] + s.tlit.count[l]) << (15 - l)); }
+#pragma unroll
+    for (int k = 0; k < 15 - DB; ++k) { const int l = DB + 1 + k; lc.dist[k] = UNI((uint32_t)(s.tdist.first[l] + s.tdist.count[l]) << (15 - l)); }
+}
+
+// ---- per-lane token decoding ----------------------------------------------------------------------------
+// A code longer than the LUT index.  The canonical codes of one length are consecutive and lengths ascend with
+// the code value, so the length of the code in front of us is the number of (left-aligned) per-length upper
+// limits it reaches: a handful of compares against scalar registers; its entry then sits at a computed index
+// of the canonical-order table.
+template <int KIND>
+__device__ __forceinline__ uint32_t long_code2(uint32_t bits, const Lim2 &lim, const Tree &t, const uint32_t *ext)
+{
+    const uint32_t v = __brev(bits) >> 17;                     // next 15 bits, MSB first
+    uint32_t l;
+    if (KIND == 0) {
+        l = LB + 1;
+#pragma unroll
+        for (int k = 0; k < 14 - LB; ++k) l += v >= lim.lit[k];
+        if (v >= lim.lit[14 - LB]) return entry(15, 0, K_UNDEF, 0);
+    } else {
+        l = DB + 1;
+#pragma unroll
+        for (int k = 0; k < 14 - DB; ++k) l += v >= lim.dist[k];
+        if (v >= lim.dist[14 - DB]) return entry(15, 0, K_UNDEF, 0);
+    }
+    const uint32_t idx = t.offset[l] + (v >> (15 - l)) - t.first[l];
+    return ext[idx < (KIND == 0 ? 288u : 32u) ? idx : 0];
+}
+
+// decodes the token that starts at staged bit q.  -> bits | kind << 8 with kind 0 literal, 4 back-reference, 1 end
+// of block, 3 not a token the fast path takes (undefined code, zero run or distance, past the end of the input
+// `lim`).  FULL also produces the token's halfwords (h0, and h1 for a reference).
+static constexpr uint32_t D2_LIT = 0, D2_EOB = 1, D2_BAD = 3, D2_REF = 4;
+template <bool FULL>
+__device__ __forceinline__ uint32_t decode_at2(const DLds &s, const Lim2 &lc, uint32_t q, uint32_t lim, uint32_t &h0, uint32_t &h1)
+{
+    uint32_t lo, hi;
+    fetch2(s.stage, q, lo, hi);
+    uint32_t e = s.lit[lo & ((1 << LB) - 1)];
+    if ((e & 15) == 0) e = long_code2<0>(lo, lc, s.tlit, s.ext_lit);
+    const uint32_t len1 = e & 15, kind = (e >> 8) & 3;
+    uint32_t nbits = len1, k = kind == K_LIT ? D2_LIT : kind == K_EOB ? D2_EOB : kind == K_MATCH ? D2_REF : D2_BAD;
+    if (kind == K_MATCH) {
+        const uint32_t cx = (e >> 4) & 15, p2 = len1 + cx;
+        const uint32_t b2 = (uint32_t)(((uint64_t)hi << 32 | lo) >> p2);
+        uint32_t d = s.dist[b2 & ((1 << DB) - 1)];
+        if ((d & 15) == 0) d = long_code2<1>(b2, lc, s.tdist, s.ext_dist);
+        const uint32_t dl = d & 15, ox = (d >> 4) & 15;
+        nbits = p2 + dl + ox;
+        if (((d >> 8) & 3) == K_UNDEF || (d >> 16) == 0 || (e >> 16) == 0) k = D2_BAD;
+        if (FULL) {
+            const uint32_t run = (e >> 16) + ((lo >> len1) & ((1u << cx) - 1));
+            const uint32_t dd = (d >> 16) + ((b2 >> dl) & ((1u << ox) - 1));
+            h0 = tk_m0(run, dd); h1 = tk_m1(dd);
+        }
+    } else if (FULL) {
+        h0 = e >> 16;
+    }
+    if (q + nbits > lim) k = D2_BAD;
+    return nbits | k << 8;
+}
+
+// ---- segment search ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs)
+{
+    __shared__ __attribute__((aligned(16))) DLds s;
+    __shared__ __attribute__((aligned(16))) uint32_t win[512 + 16];
+    const int lane = threadIdx.x;
+    PSeg &sg = segs[blockIdx.x];
+    const PStream &st = streams[UNI(sg.stream)];
+    const g8 *src = (const g8 *)uni64((uint64_t)st.src);
+    const uint64_t n = uni64(st.src_len), total = n * 8;
+    const uint32_t j = UNI(sg.index);
+    uint64_t found = NONE2;
+    const uint64_t resume_bit = uni64(st.start_bit);       // resumable streams: nothing in front of it is looked at again
+    if (j == 0) {
+        // .initial (InflatorBuffers.swift:92-104, StreamHeader.swift:16-54)
+        if (resume_bit) found = resume_bit;
+        else if (UNI(st.format) == SPNG_FORMAT_IOS) found = 0;
+        else if (n >= 2) {
+            const uint32_t cmf = src[0], flg = src[1];
+            if ((cmf & 15) == 8 && (cmf >> 4) < 8 && ((cmf << 8) + flg) % 31 == 0 && !(flg & 0x20)) found = 16;
+        }
+    } else {
+        const uint64_t sb = uni64(st.seg_bytes) * 8;
+        const uint64_t lo_nom = (uint64_t)j * sb;
+        const uint64_t lo_bit = lo_nom > resume_bit ? lo_nom : ((resume_bit + 1 + 63) & ~(uint64_t)63);   // (window loads want whole bytes)
+        const uint64_t hi_bit = lo_nom + sb < total ? lo_nom + sb : total;
+        for (uint64_t wb = lo_bit; wb < hi_bit && found == NONE2; wb += 16384) {
+            stage_bytes2(win, src, n, wb >> 3, 512, lane);
+            {   // the 64 bytes behind the window (a header straddling its end)
+                const uint64_t off = (wb >> 3) + 2048 + (uint64_t)lane * 4;
+                uint32_t v = 0;
+                if (lane < 16) { for (int b = 0; b < 4; ++b) if (off + b < n) v |= (uint32_t)src[off + b] << (8 * b); win[512 + lane] = v; }
+                WSYNC();
+            }
+            for (uint32_t p = 0; p < 16384 && wb + p < hi_bit && found == NONE2; p += 64) {
+                const uint32_t q = p + (uint32_t)lane;
+                const uint32_t w = q >> 5;
+                const uint32_t d0 = win[w], d1 = win[w + 1], d2 = win[w + 2], d3 = win[w + 3];
+                const uint32_t v0 = __builtin_amdgcn_alignbit(d1, d0, q);
+                const uint32_t v1 = __builtin_amdgcn_alignbit(d2, d1, q);
+                const uint32_t v2 = __builtin_amdgcn_alignbit(d3, d2, q);
+                const uint32_t ncl = ((v0 >> 13) & 15) + 4;
+                bool cand = ((v0 >> 1) & 3) == 2 && ((v0 >> 3) & 31) <= 29 && ((v0 >> 8) & 31) <= 29 &&
+                            wb + q + 17 + 3 * ncl <= total && wb + q < hi_bit;
+                if (__ballot(cand)) {
+                    // the code-length code must be complete: sum of 2^(7-len) over the used lengths == 128
+                    const uint64_t W = ((uint64_t)v2 << 47) | ((uint64_t)v1 << 15) | (v0 >> 17);
+                    uint32_t kraft = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < 19; ++k) {
+                        const uint32_t l = (uint32_t)(W >> (3 * k)) & 7;
+                        kraft += (k < ncl && l) ? 128u >> l : 0u;
+                    }
+                    cand = cand && kraft == 128;
+                }
+                unsigned long long m = __ballot(cand);
+                while (m && found == NONE2) {
+                    const int l = __ffsll((long long)m) - 1;
+                    const uint64_t at = wb + p + (uint32_t)l;
+                    Hdr2 h;
+                    if (UB(parse_header2(s, src, n, at, h, lane))) found = at;
+                    m &= m - 1;
+                }
+            }
+        }
+    }
+    if (lane == 0) { sg.start_bit = found; sg.end_bit = 0; sg.ntok = 0; sg.tok_base = 0; sg.status = PSEG_FAIL; sg.used = 0; sg.next = 0; }
+}
+
+// ---- decode: tokens of a segment ----------------------------------------------------------------------------
+// Where a segment's tokens go: whole 16-byte units (8 halfwords) in pages of the pool, the page numbers in the
+// segment's page table; the halfwords of the last, incomplete unit wait in `carry`.
+struct Cursor {
+    uint64_t units;                    // units stored
+    uint32_t npages;                   // pages taken
+    uint32_t carry_n;                  // halfwords in carry (0 .. 7)
+    v4u      carry;
+    g8      *ptr;                      // page of unit `units` (when npages > units >> 12)
+};
+
+// takes a page.  null: the pool or the segment's page table is exhausted
+__device__ __forceinline__ g8 *take_page(const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &c, int lane)
+{
+    if (c.npages >= pt_cap) return nullptr;
+    uint32_t id = 0;
+    if (lane == 0) id = atomicAdd(pool.next, 1u);
+    id = UNI(id);
+    if (id >= pool.pages) return nullptr;
+    if (lane == 0) pt[c.npages] = id;
+    c.npages += 1;
+    return (g8 *)(pool.base + ((uint64_t)id << PAGE_SHIFT));
+}
+
+// s.hw[0 .. carry_n + filled) = the carry and `filled` new halfwords: stores the whole units, keeps the rest.
+__device__ __forceinline__ bool flush_tokens(DLds &s, const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &c, uint32_t filled, int lane)
+{
+    const uint32_t total = c.carry_n + filled;
+    const uint32_t nu = total >> 3;
+    if (nu) {
+        const uint64_t first_pg = c.units >> (PAGE_SHIFT - 4), last_pg = (c.units + nu - 1) >> (PAGE_SHIFT - 4);
+        if (first_pg == c.npages) { c.ptr = take_page(pool, pt, pt_cap, c, lane); if (!c.ptr) return false; }
+        g8 *pa = c.ptr, *pb = c.ptr;
+        if (last_pg != first_pg) { pb = take_page(pool, pt, pt_cap, c, lane); if (!pb) return false; }
+        for (uint32_t k = 0; k * 64 < nu; ++k) {
+            const uint32_t i = k * 64 + (uint32_t)lane;
+            if (i < nu) {
+                const uint64_t abs = c.units + i;
+                g8 *p = (abs >> (PAGE_SHIFT - 4)) == first_pg ? pa : pb;
+                ((gPV4 *)(p + ((abs & (PAGE_UNITS - 1)) << 4)))->v = *(const v4u *)(s.hw + i * 8);
+            }
+        }
+        c.units += nu;
+        c.ptr = pb;
+    }
+    WSYNC();
+    {
+        const v4u v = *(const v4u *)(s.hw + nu * 8);          // (uniform address)
+        c.carry[0] = UNI(v[0]); c.carry[1] = UNI(v[1]); c.carry[2] = UNI(v[2]); c.carry[3] = UNI(v[3]);
+    }
+    c.carry_n = total & 7;
+    WSYNC();
+    return true;
+}
+__device__ __forceinline__ void put_carry(DLds &s, const Cursor &c, int lane)
+{
+    if (lane == 0) *(v4u *)s.hw = c.carry;
+}
+
+// One chunk (64 subsequences of sdw dwords) of a Huffman block.  `cb` = absolute first bit of the chunk, `entry`
+// = absolute bit at which the first token of the chunk starts (>= cb).  Appends the chunk's tokens and returns:
+// state 0 = the block goes on (next = entry of the next chunk), 1 = end of block (next = bit after the
+// end-of-block code), 2 = give up.
+//
+//   round 0   every lane decodes its own subsequence from a guessed start (lane 0: the true start), marks the
+//             token starts it visits in its bitmap and notes which of its tokens are back-references (two
+//             halfwords); its chain leaves the subsequence at q.
+//   round 1   every lane follows its chain on through the subsequences behind it until it lands on a bit that
+//             the owner of that subsequence has marked (from there on the two chains are one), or leaves the
+//             chunk, or stops (end of block / not a token): a link (lane it merged into, position).  At every
+//             subsequence it enters it notes position and halfwords so far (tokens are shorter than a
+//             subsequence, so none is skipped).
+//   path      lane 0 starts on a true token boundary, so the true chain is lane 0's chain up to its link, then
+//             that lane's chain up to its link, ...: the lanes reachable from lane 0 (pointer doubling).
+//   replay    per subsequence the true chain enters it at `e` and `mine` halfwords of tokens start in it: the
+//             crossing chain's, then the owner's marks behind the merge point.  Every lane decodes exactly
+//             those, into the LDS token buffer at its prefix-sum offset; the buffer leaves in 16-byte units.
+__device__ __forceinline__ uint32_t decode_chunk(DLds &s, const Lim2 &lim_codes, SR2 &sr, const g8 *src, uint64_t n, uint64_t cb,
+                                                 uint64_t entry, uint32_t sdw, const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &cur,
+                                                 uint64_t &next, int lane)
+{
+    const uint32_t sb = sdw * 32, chb = sb * 64;
+    const uint32_t inv = (65536u + sdw - 1) / sdw;            // x / sdw == x * inv >> 16 for x < 640
+    const uint64_t sbyte = (cb >> 5) << 2;
+    stage_put2(s.stage, sr, lane);                              // (fetched while the chunk before was decoded)
+    stage_fetch2(sr, src, n, ((cb + chb) >> 5) << 2, lane);
+    const uint64_t sbit = sbyte * 8;
+    const uint64_t left = n * 8 - sbit;
+    const uint32_t lim = left > 0xffffffffull ? 0xffffffffu : (uint32_t)left;
+    const uint32_t off0 = (uint32_t)(cb - sbit), cend = off0 + chb;
+    const uint32_t sub0 = off0 + (uint32_t)lane * sb, sub1 = sub0 + sb;
+#pragma unroll
+    for (int w = 0; w < SDW_MAX; ++w) s.c.vmap[w * 64 + lane] = 0;
+    s.c.flag[lane] = 0;
+    s.c.ent[lane] = 0;
+    WSYNC();
+    uint32_t d0, d1;
+    const uint32_t q0 = lane == 0 ? (uint32_t)(entry - sbit) : sub0;
+    uint32_t q = q0, st = 0;                                    // st: 0 running, 1 end of block, 2 not a token
+    uint64_t mb0 = 0, mb1 = 0;                                  // which of my tokens (by ordinal) are back-references
+    uint32_t ntk = 0;
+    while (q < sub1) {
+        const uint32_t t = decode_at2<false>(s, lim_codes, q, lim, d0, d1);
+        const uint32_t k = t >> 8;
+        if (k & 3) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
+        const uint32_t b = q - sub0;
+        atomicOr(&s.c.vmap[(b >> 5) * 64 + lane], 1u << (b & 31));
+        if (k == D2_REF) { if (ntk < 64) mb0 |= 1ull << ntk; else mb1 |= 1ull << (ntk - 64); }
+        ntk += 1;
+        q += t & 255;
+    }
+    WSYNC();
+    uint32_t link = 64, cnt2 = 0, nh = 0, lastj = (uint32_t)lane;
+    uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;                    // crossings: position | halfwords before it << 16
+    if (st == 0) {
+        while (q < cend) {
+            const uint32_t j = (((q - off0) >> 5) * inv) >> 16, b = q - off0 - j * sb;
+            if (j != lastj) {
+                const uint32_t v = q | cnt2 << 16;
+                x0 = nh == 0 ? v : x0; x1 = nh == 1 ? v : x1; x2 = nh == 2 ? v : x2; x3 = nh == 3 ? v : x3;
+                nh += 1; lastj = j;
+            }
+            if ((s.c.vmap[(b >> 5) * 64 + j] >> (b & 31)) & 1) { link = j; break; }
+            const uint32_t t = decode_at2<false>(s, lim_codes, q, lim, d0, d1);
+            const uint32_t k = t >> 8;
+            if (k & 3) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
+            cnt2 += k == D2_REF ? 2u : 1u;
+            q += t & 255;
+        }
+    }
+    // q: where my chain merged / left the chunk / stopped
+    bool onpath = lane == 0;
+    uint32_t jump = link;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (onpath && jump < 64) s.c.flag[jump] = 1;
+        WSYNC();
+        onpath = onpath || s.c.flag[lane] != 0;
+        const uint32_t jj = (uint32_t)__shfl((int)jump, (int)(jump & 63), 64);
+        jump = jump < 64 ? jj : 64;
+    }
+    if (onpath) {
+        // the subsequences my chain crossed (beyond the fourth crossing they all count for the fourth: rare)
+        const uint32_t nrec = nh < 4 ? nh : 4;
+        const uint32_t xs[5] = {x0, x1, x2, x3, 0};
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            if ((uint32_t)h < nrec) {
+                const uint32_t upto = (uint32_t)h + 1 < nrec ? xs[h + 1] >> 16 : cnt2;
+                s.c.ent[lane + 1 + h] = (xs[h] & 0xffff) | (upto - (xs[h] >> 16)) << 16;
+            }
+        if (link < 64) {
+            s.c.mpos[link] = (uint16_t)q;
+            if (link != (uint32_t)lane + nrec) s.c.ent[link] = q;  // (merged behind the recorded crossings: no prefix)
+        }
+    }
+    WSYNC();
+    const uint32_t e = lane == 0 ? q0 : s.c.ent[lane];
+    const uint32_t m = lane == 0 ? q0 : s.c.mpos[lane];         // where the true chain merges into mine
+    uint32_t mine = e >> 16;                                    // halfwords
+    if (onpath) {
+        const uint32_t mb = m - sub0;                            // 0 .. sb - 1
+        uint32_t k0 = 0;                                         // my tokens in front of the merge point
+#pragma unroll
+        for (int w = 0; w < SDW_MAX; ++w) {
+            const uint32_t word = s.c.vmap[w * 64 + lane];
+            const uint32_t lo = w * 32;
+            const uint32_t below = mb >= lo + 32 ? ~0u : mb > lo ? ~(~0u << (mb - lo)) : 0u;
+            k0 += (uint32_t)__popc(word & below);
+        }
+        uint64_t r0m = mb0, r1m = mb1;                          // back-references among my tokens k0 ...
+        if (k0 >= 64) { r0m = k0 >= 128 ? 0 : r1m >> (k0 - 64); r1m = 0; }
+        else if (k0) { r0m = r0m >> k0 | r1m << (64 - k0); r1m >>= k0; }
+        mine += (ntk - k0) + (uint32_t)__popcll(r0m) + (uint32_t)__popcll(r1m);
+    }   // (a lane off the path whose subsequence the true chain crossed without merging replays the crossing: ent)
+    uint32_t tot;
+    const uint32_t off = wave_excl_scan(mine, tot, lane);
+#ifdef SPNG_EMU_TRACE
+    if (getenv("EMU_TRACE")) fprintf(stderr, "chunk cb %llu lane %2d: q0 %5u ntk %3u st %u link %2u q %5u nh %u cnt2 %u onpath %d e %5u|%u m %5u mine %3u off %4u\n",
+                                     (unsigned long long)cb, lane, q0, ntk, st, link, q, nh, cnt2, (int)onpath, e & 0xffff, e >> 16, m, mine, off);
+#endif
+    // the lane on the path whose chain left the chunk or stopped
+    const unsigned long long endm = __ballot(onpath && link == 64);
+    const int el = endm ? __ffsll((long long)endm) - 1 : 0;
+    const uint32_t qe = (uint32_t)__shfl((int)q, el, 64), ste = endm ? (uint32_t)__shfl((int)st, el, 64) : 2u;
+    next = sbit + qe;
+    if (ste == 2) return 2;
+    if (__ballot(mine > HWCAP - 8)) return 2;                  // (a chain that never merged: not this path's case)
+    // ---- replay: the tokens, window after window of the LDS buffer
+    uint32_t base = 0;
+    while (base < tot) {
+        const bool in = mine != 0 && off >= base && off + mine <= base + (HWCAP - 8);
+        WSYNC();                                                // (everybody is done with what the buffer overlays)
+        put_carry(s, cur, lane);
+        WSYNC();
+        if (in) {
+            uint32_t qq = e & 0xffff, o = cur.carry_n + off - base, done = 0;
+            while (done < mine) {
+                uint32_t h0 = 0, h1 = 0;
+                const uint32_t t = decode_at2<true>(s, lim_codes, qq, 0xffffffffu, h0, h1);
+                s.hw[o + done] = (uint16_t)h0;
+                if ((t >> 8) == D2_REF) { s.hw[o + done + 1] = (uint16_t)h1; done += 2; } else done += 1;
+                qq += t & 255;
+            }
+        }
+        WSYNC();
+        const unsigned long long inm = __ballot(in);
+        if (!inm) return 2;
+        const int hi = 63 - __clzll((long long)inm);
+        const uint32_t endv = (uint32_t)__shfl((int)(off + mine), hi, 64);
+        if (!UB(flush_tokens(s, pool, pt, pt_cap, cur, endv - base, lane))) return 2;
+        base = endv;
+    }
+    return ste;
+}
+
+__global__ __launch_bounds__(64, 4) void pinf2_decode_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs,
+                                                          uint32_t *__restrict__ pt_slab, DPool pool)
+{
+    __shared__ __attribute__((aligned(16))) DLds s;
+    const int lane = threadIdx.x;
+    PSeg &sg = segs[blockIdx.x];
+    const PStream &st = streams[UNI(sg.stream)];
+    const uint64_t start = uni64(sg.start_bit);
+    if (start == NONE2) return;
+    const g8 *src = (const g8 *)uni64((uint64_t)st.src);
+    const uint64_t n = uni64(st.src_len);
+    // this segment ends where a later one begins: at the first found start it stops ON.  One it runs past
+    // was no block start (a look-alike inside stored data or inside a block); whatever its wave decodes
+    // from there stays off the chain (scan).
+    uint64_t limit = NONE2;
+    uint32_t nk = UNI(sg.index) + 1;
+    const uint32_t seg_first = UNI(st.seg_first), seg_count = UNI(st.seg_count);
+    auto advance = [&](uint64_t from) {
+        limit = NONE2;
+        for (; nk < seg_count; ++nk) {
+            const uint64_t v = uni64(segs[seg_first + nk].start_bit);
+            if (v != NONE2 && v >= from) { limit = v; break; }
+        }
+    };
+    advance(start + 1);
+    g32 *pt = (g32 *)(pt_slab + uni64(sg.log_off));
+    const uint32_t pt_cap = (uint32_t)uni64(sg.log_cap);
+    Cursor cur;
+    cur.units = 0; cur.npages = 0; cur.carry_n = 0; cur.ptr = nullptr;
+    cur.carry[0] = cur.carry[1] = cur.carry[2] = cur.carry[3] = 0;
+    uint64_t pos = start;
+    int32_t status = PSEG_FAIL;
+    // A resumable stream stops in front of the first block that cannot be taken as it stands -- cut off by the end
+    // of the input so far, or not acceptable: the serial kernel, started there, tells which -- and keeps the
+    // blocks before it.
+    const bool resumable = uni64((uint64_t)st.state) != 0;
+    uint64_t hw_block = 0;
+    for (;;) {
+        if (pos >= limit) {
+            if (pos == limit) { status = PSEG_CONT; break; }
+            nk += 1; advance(pos);
+            continue;
+        }
+        Hdr2 h;
+        hw_block = cur.units * 8 + cur.carry_n;
+        if (!UB(parse_header2(s, src, n, pos, h, lane))) break;
+        if (h.type == 0) {
+            // stored bytes are literal tokens
+            const uint64_t from = h.payload / 8;
+            bool ok = true;
+            for (uint32_t k = 0; k < h.stored && ok; k += HWCAP - 8) {
+                const uint32_t m = h.stored - k < HWCAP - 8 ? h.stored - k : HWCAP - 8;
+                WSYNC();
+                put_carry(s, cur, lane);
+                WSYNC();
+                for (uint32_t i = (uint32_t)lane; i < m; i += 64) s.hw[cur.carry_n + i] = src[from + k + i];
+                WSYNC();
+                ok = UB(flush_tokens(s, pool, pt, pt_cap, cur, m, lane));
+            }
+            if (!ok) break;
+            pos = h.payload + (uint64_t)h.stored * 8;
+        } else {
+            // subsequence length: at most 128 tokens may start in one (their kinds are kept in two 64-bit masks), and
+            // no token may jump a whole subsequence (it is at most 48 bits long)
+            const uint32_t sdw = h.minlen >= 3 ? 9u : h.minlen == 2 ? 7u : 3u;
+            uint64_t entry = h.payload, cb = h.payload;
+            uint32_t state = 0;
+            Lim2 lc;
+            load_limits2(s, lc);
+            SR2 sr;
+            stage_fetch2(sr, src, n, (cb >> 5) << 2, lane);
+            for (;;) {
+                uint64_t next;
+                state = UNI(decode_chunk(s, lc, sr, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane));
+                entry = uni64(next);
+                if (state) break;
+                cb += (uint64_t)sdw * 32 * 64;
+            }
+            if (state != 1) break;
+            pos = entry;
+        }
+        if (h.bfinal) { status = PSEG_FINAL; break; }
+    }
+    uint64_t nhw = cur.units * 8 + cur.carry_n;
+    if (status == PSEG_FAIL && resumable) { status = PSEG_PARTIAL; nhw = hw_block; }   // (pos is still the block's first bit)
+    // the last unit, padded
+    if (cur.carry_n) {
+        WSYNC();
+        put_carry(s, cur, lane);
+        WSYNC();
+        if ((uint32_t)lane >= cur.carry_n && lane < 8) s.hw[lane] = (uint16_t)TK_NULL;
+        WSYNC();
+        const uint32_t pad = 8 - cur.carry_n;
+        if (!UB(flush_tokens(s, pool, pt, pt_cap, cur, pad, lane))) status = PSEG_FAIL;
+    }
+    if (lane == 0) { sg.end_bit = pos; sg.ntok = nhw; sg.status = status; sg.next = nk; }
+}
+
+// ---- scan: the segment chain of every stream -----------------------------------------------------------------
+// One wave per stream walks the chain: segment 0, then the segment decode says it stopped at, ... up to the
+// first one that saw the final block.  A found start that no chain member stops at (a bit pattern inside
+// stored data or in the middle of a block that happens to parse as a header) is simply not on the chain.
+__global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ streams, PSeg *__restrict__ segs)
+{
+    const int lane = threadIdx.x;
+    PStream &st = streams[blockIdx.x];
+    const uint32_t first = UNI(st.seg_first), count = UNI(st.seg_count);
+    bool ok = false, partial = false;
+    uint64_t tok = 0, end_bit = 0;
+    uint32_t k = 0;
+    for (uint32_t hops = 0; hops < count; ++hops) {
+        PSeg *sg = segs + first + k;
+        const uint64_t start = uni64(sg->start_bit), end = uni64(sg->end_bit);
+        const int32_t status = (int32_t)UNI(sg->status);
+        if (start == NONE2 || status == PSEG_FAIL) break;
+        if (lane == 0) { sg->tok_base = tok; sg->used = 1; }
+        tok += uni64(sg->ntok);
+        if (status == PSEG_FINAL) { ok = true; end_bit = end; break; }
+        if (status == PSEG_PARTIAL) { ok = true; partial = true; end_bit = end; break; }
+        const uint32_t nx = UNI(sg->next);
+        if (nx <= k || nx >= count) break;
+        if (uni64(segs[first + nx].start_bit) != end) break;
+        k = nx;
+    }
+    if (lane == 0) { st.ok = ok ? (partial ? 2 : 1) : 0; st.ntok = tok; st.end_bit = end_bit; st.pass = 0; st.tok_base = 0; }
+}
+
+// ---- resolve: tokens -> bytes -------------------------------------------------------------------------------
+static constexpr uint32_t RT2 = 512;                 // threads per stream
+static constexpr uint32_t TILE2 = 8192;              // output bytes resolved per step (16 per thread)
+static constexpr uint32_t MAXM2 = 1024;              // back-references per tile
+static constexpr uint32_t WINDOW2 = 32768;           // the DEFLATE window
+static constexpr uint32_t R2_DONE = 0x8000;          // state: R2_DONE | byte, or the tile index of an earlier byte
+static constexpr uint32_t PTC = 256;                 // page-table entries cached in LDS
+
+struct RLds2 {
+    uint8_t  ring[WINDOW2];            // the last 32 KiB of output, at position mod 32 KiB
+    uint16_t state[TILE2];
+    uint32_t rec[MAXM2][2];            // back-references of the tile: first byte | run << 16; distance
+    uint32_t bitmap[TILE2 / 32];       // their first bytes
+    uint16_t h0[RT2 + 8];              // every thread's first halfword (the second half of its neighbour's last reference)
+    uint32_t pt[PTC];
+    uint32_t part[40];
+    uint32_t again[3];                 // pointer jumping: somebody still has an unknown byte (flag of round r: r mod 3)
+};
+
+// exclusive prefix sum over the workgroup (8 waves); every thread gets the grand total too
+__device__ __forceinline__ uint32_t block_excl_scan2(RLds2 &s, uint32_t v, uint32_t &total, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t wt;
+    const uint32_t off = wave_excl_scan(v, wt, lane);
+    __syncthreads();
+    if (lane == 0) s.part[wave] = wt;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < (int)(RT2 / 64); ++w) { const uint32_t p = s.part[w]; before += w < wave ? p : 0u; all += p; }
+    total = all;
+    return off + before;
+}
+
+__global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__restrict__ streams, const PSeg *__restrict__ segs,
+                                                               const uint32_t *__restrict__ pt_slab, DPool pool,
+                                                               spng_result *__restrict__ results, int32_t *__restrict__ done)
+{
+    __shared__ __attribute__((aligned(16))) RLds2 s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (int)UNI((uint32_t)tid >> 6);
+    const PStream &st = streams[blockIdx.x];
+    if (!UNI(st.ok)) return;
+    g8 *dst = (g8 *)uni64((uint64_t)st.dst);
+    const uint64_t cap = uni64(st.dst_cap);
+    const g8 *src = (const g8 *)uni64((uint64_t)st.src);
+    const uint64_t n = uni64(st.src_len);
+    uint64_t pos = uni64(st.out_pos);                  // (resumable streams: the bytes earlier calls produced are in dst)
+    uint32_t accS = 0, accI = 0;                     // Adler-32 partial sums (inflate.hip: struct Out)
+    bool bad = false, over = false;
+    uint64_t *state = (uint64_t *)uni64((uint64_t)st.state);
+    if (pos) {
+        // the window so far
+        for (uint64_t p = (pos > WINDOW2 ? pos - WINDOW2 : 0) + (uint32_t)tid; p < pos; p += RT2) s.ring[p & (WINDOW2 - 1)] = dst[p];
+    }
+    if (tid < (int)(TILE2 / 32)) s.bitmap[tid] = 0;
+    if (tid < 3) s.again[tid] = 0;
+    __syncthreads();
+    const uint32_t seg_first = UNI(st.seg_first), seg_count = UNI(st.seg_count);
+    uint32_t sk = 0;
+    for (uint32_t hops = 0; hops < seg_count && !over; ++hops) {
+        const PSeg &sg = segs[seg_first + sk];
+        const uint64_t nhw = uni64(sg.ntok);
+        const g32 *ptg = (const g32 *)(pt_slab + uni64(sg.log_off));
+        const int32_t sstatus = (int32_t)UNI(sg.status);
+        uint64_t cursor = 0;                           // halfwords of this segment consumed
+        uint64_t pt_lo = 0;                            // first page in s.pt
+        __syncthreads();
+        for (uint32_t i = (uint32_t)tid; i < PTC; i += RT2) s.pt[i] = (pt_lo + i) * PAGE_UNITS * 8 < nhw + 8 ? ptg[pt_lo + i] : 0u;
+        __syncthreads();
+        // a thread's unit of the token window that starts at halfword `from`
+        auto load_unit = [&](uint64_t from) -> v4u {
+            const uint64_t u = (from >> 3) + (uint32_t)tid;
+            v4u v = {TK_NULL | TK_NULL << 16, TK_NULL | TK_NULL << 16, TK_NULL | TK_NULL << 16, TK_NULL | TK_NULL << 16};
+            if (u * 8 < nhw) {
+                const uint32_t pid = s.pt[(u >> (PAGE_SHIFT - 4)) - pt_lo];
+                v = ((const gPV4 *)((const g8 *)pool.base + ((uint64_t)pid << PAGE_SHIFT) + ((u & (PAGE_UNITS - 1)) << 4)))->v;
+            }
+            return v;
+        };
+        v4u tv = load_unit(0);
+        while (cursor < nhw) {
+            // ---- the window: eight halfwords per thread
+            const uint64_t ub = cursor >> 3;
+            const uint32_t hskip = (uint32_t)(cursor & 7);
+            uint32_t hh[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t idx = (uint32_t)tid * 8 + j;
+                const uint32_t v = (tv[j >> 1] >> (16 * (j & 1))) & 0xffff;
+                hh[j] = (idx >= hskip && ub * 8 + idx < nhw) ? v : TK_NULL;
+            }
+            s.h0[tid] = (uint16_t)hh[0];
+            uint32_t bytes = 0, refs = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t v = hh[j];
+                const bool lit = !(v & 0x8000), m0 = (v & 0xC000) == 0x8000;
+                bytes += lit ? 1u : m0 ? (v & 0xff) + 3 : 0u;
+                refs += m0 ? 1u : 0u;
+            }
+            uint32_t total;
+            const uint32_t offp = block_excl_scan2(s, refs << 20 | bytes, total, tid);      // (barriers inside: h0 is visible)
+            uint32_t curb = offp & 0xfffff, curm = offp >> 20;
+            const uint32_t hnext = tid + 1 < (int)RT2 ? s.h0[tid + 1] : TK_NULL;
+            // take tokens while the tile has room
+            uint32_t taken = 0, stop = 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t v = hh[j];
+                const bool lit = !(v & 0x8000), m0 = (v & 0xC000) == 0x8000;
+                if (lit || m0) {
+                    const uint32_t len = lit ? 1u : (v & 0xff) + 3;
+                    const bool fits = curb + len <= TILE2 && curm + (m0 ? 1u : 0u) <= MAXM2 && !(m0 && j == 7 && tid == (int)RT2 - 1);
+                    if (fits) {
+                        if (lit) s.state[curb] = (uint16_t)(R2_DONE | v);
+                        else {
+                            const uint32_t h1 = j < 7 ? hh[j < 7 ? j + 1 : 7] : hnext;
+                            const uint32_t dd = (((v >> 8) & 63) | (h1 & 0x1ff) << 6) + 1;
+                            atomicOr(&s.bitmap[curb >> 5], 1u << (curb & 31));
+                            s.rec[curm][0] = curb | len << 16;
+                            s.rec[curm][1] = dd;
+                        }
+                        taken += len;
+                    } else if (stop == 0xffffffffu) stop = (uint32_t)tid * 8 + j;
+                    curb += len; curm += m0 ? 1u : 0u;
+                }
+            }
+            // bytes taken, first halfword left
+            {
+                const uint32_t wt = wave_sum(taken);
+                uint32_t ws = stop;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)ws, m, 64); ws = o < ws ? o : ws; }
+                if (lane == 0) { s.part[16 + wave] = wt; s.part[24 + wave] = ws; }
+            }
+            __syncthreads();
+            uint32_t tlen = 0, stopall = 0xffffffffu;
+#pragma unroll
+            for (int w = 0; w < (int)(RT2 / 64); ++w) { tlen += s.part[16 + w]; const uint32_t o = s.part[24 + w]; stopall = o < stopall ? o : stopall; }
+            const uint64_t wend = nhw - ub * 8 < (uint64_t)RT2 * 8 ? nhw - ub * 8 : (uint64_t)RT2 * 8;      // window end (halfwords from ub * 8)
+            const uint32_t wlast = stopall != 0xffffffffu ? stopall : (uint32_t)wend;
+            if (pos + tlen > cap) { over = true; break; }
+            // the next window travels while this tile is resolved
+            const uint64_t cursor_next = ub * 8 + wlast;
+            if ((((cursor_next >> 3) + 2 * RT2) >> (PAGE_SHIFT - 4)) >= pt_lo + PTC) {
+                __syncthreads();
+                pt_lo = (cursor_next >> 3) >> (PAGE_SHIFT - 4);     // page of the next window's first unit
+                for (uint32_t i = (uint32_t)tid; i < PTC; i += RT2) s.pt[i] = (pt_lo + i) * PAGE_UNITS * 8 < nhw + 8 ? ptg[pt_lo + i] : 0u;
+                __syncthreads();
+            }
+            tv = load_unit(cursor_next);
+            // ---- expand: the reference (if any) that covers each of my bytes
+            const uint32_t rbase = (uint32_t)pos & (WINDOW2 - 1);
+            uint32_t sv[16];
+            {
+                // back-references that start in front of each row: prefix sum over the bitmap (lane l: rows 2l, 2l + 1)
+                const v4u bw = *(const v4u *)(s.bitmap + 4 * lane);
+                const uint32_t ca = (uint32_t)__popc(bw[0]) + (uint32_t)__popc(bw[1]), cbb = (uint32_t)__popc(bw[2]) + (uint32_t)__popc(bw[3]);
+                uint32_t tt;
+                const uint32_t rb = wave_excl_scan(ca + cbb, tt, lane);
+                // (row = wave + 8 k: its parity is the wave's)
+                const bool odd = wave & 1;
+                const uint32_t srclo = odd ? bw[2] : bw[0], srchi = odd ? bw[3] : bw[1], srcbase = odd ? rb + ca : rb;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t row = (uint32_t)wave + 8u * k;
+                    const uint32_t j = row * 64 + (uint32_t)lane;
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)srclo, (int)(row >> 1));
+                    const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)srchi, (int)(row >> 1));
+                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)srcbase, (int)(row >> 1));
+                    sv[k] = R2_DONE;
+                    if (row * 64 >= tlen) continue;
+                    const unsigned long long mw = (unsigned long long)mhi << 32 | mlo;
+                    const uint32_t id = base + (uint32_t)__popcll(mw & ((2ull << lane) - 1));
+                    const uint32_t r0 = s.rec[id ? id - 1 : 0][0], r1 = s.rec[id ? id - 1 : 0][1];
+                    const uint32_t startb = r0 & 0xffff, len = r0 >> 16, d = r1;
+                    uint32_t kk = j - startb;
+                    const bool inside = id != 0 && kk < len && j < tlen;
+                    // A run longer than its distance repeats its first `distance` bytes: a byte beyond the first
+                    // period copies the period in front of the run (same value, chain one level deep instead of
+                    // run / distance levels).
+                    if (inside && kk >= d) kk -= d * (uint32_t)__fdividef((float)kk + 0.5f, (float)d);          // kk mod d, kk < 258
+                    const uint32_t si = startb - d + kk;          // >= 0x80000000: before the tile
+                    const uint32_t far = s.ring[(rbase + si) & (WINDOW2 - 1)];
+                    if (inside && (int32_t)si < 0 && pos < (uint64_t)(0u - si)) bad = true;
+                    if (inside) {
+                        const uint32_t v = (int32_t)si < 0 ? R2_DONE | far : si;
+                        sv[k] = v;
+                        s.state[j] = (uint16_t)v;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < (int)(TILE2 / 32)) s.bitmap[tid] = 0;          // (read above; next written after the next scan's barriers)
+            // ---- pointer jumping
+            for (uint32_t round = 0;; ++round) {
+                bool more = false;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const bool unk = !(sv[k] & R2_DONE);
+                    if (__ballot(unk)) {
+                        const uint32_t j = ((uint32_t)wave + 8u * k) * 64 + (uint32_t)lane;
+                        const uint32_t g = s.state[unk ? sv[k] : j];
+                        if (unk) { sv[k] = g; s.state[j] = (uint16_t)g; more = more || !(g & R2_DONE); }
+                    }
+                }
+                // one barrier per round.  Three flags in rotation: the one cleared here was last read before
+                // this round's barrier and is next set after the next round's.
+                const uint32_t fr = round % 3;
+                if (more) s.again[fr] = 1;
+                __syncthreads();
+                const bool go = s.again[fr] != 0;
+                if (tid == 0) s.again[fr == 0 ? 2 : fr - 1] = 0;
+                if (!go) break;
+            }
+            // ---- the bytes: into the ring, then to the output in whole 16-byte units of the position
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t j = ((uint32_t)wave + 8u * k) * 64 + (uint32_t)lane;
+                if (j < tlen) s.ring[(rbase + j) & (WINDOW2 - 1)] = (uint8_t)s.state[j];
+            }
+            __syncthreads();
+            {
+                const uint64_t u0 = pos >> 4, u1 = (pos + tlen) >> 4;
+                for (uint64_t u = u0 + (uint32_t)tid; u < u1; u += RT2) {
+                    const v4u v = *(const v4u *)(s.ring + ((u << 4) & (WINDOW2 - 1)));
+                    ((gPV4 *)(dst + (u << 4)))->v = v;
+                    uint32_t A = 0, J = 0;
+                    A = __builtin_amdgcn_sad_u8(v[0], 0, A); A = __builtin_amdgcn_sad_u8(v[1], 0, A);
+                    A = __builtin_amdgcn_sad_u8(v[2], 0, A); A = __builtin_amdgcn_sad_u8(v[3], 0, A);
+                    J = __builtin_amdgcn_udot4(v[0], 0x03020100u, J, false);
+                    J = __builtin_amdgcn_udot4(v[1], 0x07060504u, J, false);
+                    J = __builtin_amdgcn_udot4(v[2], 0x0b0a0908u, J, false);
+                    J = __builtin_amdgcn_udot4(v[3], 0x0f0e0d0cu, J, false);
+                    const uint32_t g = (uint32_t)((u << 4) % 65521);
+                    accS = (accS + A) % 65521;
+                    accI = (uint32_t)((accI + (uint64_t)g * A + J) % 65521);
+                }
+            }
+            pos += tlen;
+            cursor = cursor_next;
+        }
+        if (sstatus == PSEG_FINAL || sstatus == PSEG_PARTIAL) break;
+        sk = UNI(sg.next);
+    }
+    // the bytes behind the last whole unit
+    __syncthreads();
+    {
+        const uint64_t u1 = pos >> 4 << 4;
+        if (!over && u1 + (uint32_t)tid < pos) {
+            const uint32_t b = s.ring[(u1 + (uint32_t)tid) & (WINDOW2 - 1)];
+            dst[u1 + (uint32_t)tid] = (uint8_t)b;
+            const uint32_t g = (uint32_t)((u1 + (uint32_t)tid) % 65521);
+            accS = (accS + b) % 65521;
+            accI = (uint32_t)((accI + (uint64_t)g * b) % 65521);
+        }
+    }
+    // ---- verdict
+    if (__syncthreads_or(bad || over)) return;                  // leave it to the serial kernel
+    {
+        // S = sum b_i, I = sum i * b_i (mod 65521) over the workgroup
+        const uint32_t S1 = wave_sum(accS) % 65521, I1 = wave_sum(accI % 65521) % 65521;
+        __syncthreads();
+        if (lane == 0) { s.part[wave] = S1; s.part[8 + wave] = I1; }
+        __syncthreads();
+        uint32_t S = 0, I = 0;
+        for (int w = 0; w < (int)(RT2 / 64); ++w) { S += s.part[w]; I += s.part[8 + w]; }
+        S %= 65521; I %= 65521;
+        if (tid == 0 && st.ok == 2) {
+            // resumable, and the chain stopped in front of a block the input does not hold (or that is not
+            // acceptable): the serial kernel goes on from there
+            state[0] = st.end_bit; state[1] = pos;
+        } else if (tid == 0 && state) {
+            // resumable and complete: the trailer must be there; the sum over ALL bytes is compared afterwards (gzip.hip)
+            const uint64_t endb = (st.end_bit + 7) / 8, consumed = endb + (st.format == SPNG_FORMAT_ZLIB ? 4 : 0);
+            spng_result &res = results[st.image];
+            if (consumed <= n) {
+                res.status = SPNG_DONE; res.reserved = 1;
+                res.written = pos; res.consumed = consumed;
+                res.aux[0] = res.aux[1] = 0;
+                done[blockIdx.x] = 1;
+            }   // (else: the serial kernel, from where this call started, reports "need more input")
+        } else if (tid == 0) {
+            const uint64_t endb = (st.end_bit + 7) / 8;
+            bool good = true;
+            uint64_t consumed = endb;
+            if (st.format != SPNG_FORMAT_IOS) {
+                // .checksum (InflatorBuffers.swift:112-130; Stream.swift:402-429)
+                if (endb + 4 > n) good = false;
+                else {
+                    const uint32_t declared = (uint32_t)src[endb] << 24 | (uint32_t)src[endb + 1] << 16 |
+                                              (uint32_t)src[endb + 2] << 8 | (uint32_t)src[endb + 3];
+                    // Adler-32 from S and I: a = 1 + S, b = N + N * S - I  (i counted from 0)
+                    const uint32_t N = (uint32_t)(pos % 65521);
+                    const uint32_t computed = (uint32_t)((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
+                    good = declared == computed;
+                    consumed = endb + 4;
+                }
+            }
+            if (good) {
+                spng_result &res = results[st.image];
+                res.status = SPNG_DONE; res.reserved = 1;
+                res.written = pos; res.consumed = consumed;
+                res.aux[0] = res.aux[1] = 0;
+                done[blockIdx.x] = 1;
+            }
+        }
+    }
+}
+
+// pages a group took: ctr = {page counter, total over the groups of the batch, some group ran dry}
+__global__ void pinf2_account_kernel(uint32_t *ctr, uint32_t pages)
+{
+    const uint32_t used = ctr[0];
+    ctr[1] += used < pages ? used : pages;
+    if (used >= pages) ctr[2] = 1;
+}
+
+// ---- host ------------------------------------------------------------------------------------------------
+#ifndef SPNG_EMU
+hipError_t launch_pinf2_find(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, hipStream_t stream)
+{
+    pinf2_find_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs);
+    return hipGetLastError();
+}
+hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint32_t *d_pt, uint8_t *d_pool, uint32_t *d_next,
+                               uint32_t pages, hipStream_t stream)
+{
+    DPool pool{d_pool, d_next, pages, 0};
+    pinf2_decode_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_pt, pool);
+    return hipGetLastError();
+}
+hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, hipStream_t stream)
+{
+    pinf2_scan_kernel<<<nstreams, 64, 0, stream>>>(d_streams, d_segs);
+    return hipGetLastError();
+}
+hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
+                                spng_result *d_results, int32_t *d_done, hipStream_t stream)
+{
+    DPool pool{d_pool, nullptr, pages, 0};
+    pinf2_resolve_kernel<<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done);
+    return hipGetLastError();
+}
+hipError_t launch_pinf2_account(uint32_t *d_ctr, uint32_t pages, hipStream_t stream)
+{
+    pinf2_account_kernel<<<1, 1, 0, stream>>>(d_ctr, pages);
+    return hipGetLastError();
+}
+#endif
+
+}  // namespace spng
