@@ -487,12 +487,20 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
     for (auto &j : p.jobs) total += j.src_len;
     uint64_t seg_bytes = (uint64_t)c->cfg[SPNG_CFG_SEGMENT_BYTES];
     if (!seg_bytes) {
-        seg_bytes = total / 8192;
+        // (pinflate2: ~9 rounds of resident waves, so that the last, partly filled one costs little; the search costs 7 ms per 10^4 segments)
+        seg_bytes = total / (p.legacy ? 8192 : 32768);
         if (seg_bytes < (256u << 10)) seg_bytes = 256u << 10;
     }
     seg_bytes = (seg_bytes + 255) & ~(uint64_t)255;
     p.streams.resize(p.jobs.size());
-    // what the last batch taught about token volume
+    // what the last batch taught about token volume (its page count comes back behind its kernels: when the planning
+    // figure would cut THIS batch into groups, waiting for that number is cheaper than not knowing it)
+    if (!p.legacy && c->pool_pending && c->pool_ratio == 0 && hipEventQuery(c->pool_ev) != hipSuccess) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        uint64_t room = c->cfg[SPNG_CFG_TOKEN_BYTES] ? (uint64_t)c->cfg[SPNG_CFG_TOKEN_BYTES] : (uint64_t)(free_b + c->tok_cap) / 2;
+        if ((double)total * 3.2 > (double)room) HIP_TRY(hipEventSynchronize(c->pool_ev));
+    }
     if (!p.legacy && c->pool_pending && hipEventQuery(c->pool_ev) == hipSuccess) {
         c->pool_pending = false;
         const uint64_t used = c->h_pool_used[1];
@@ -656,13 +664,16 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
         PSeg *dg = a.dev<PSeg>(p.segs_at);
         int32_t *dd = a.dev<int32_t>(p.done_at);
         uint32_t *dnext = a.dev<uint32_t>(p.next_at);
-        for (size_t gi = 0; gi < p.groups.size(); ++gi) {
-            const InflatePlan::Group &g = p.groups[gi];
+        // every group of streams in turn, then once more those whose segments found the pool empty (a batch unlike the
+        // one the pool was sized by): they get a second pass instead of the serial kernel
+        for (size_t gi = 0; gi <= p.groups.size(); ++gi) {
+            const bool retry = gi == p.groups.size();
+            const InflatePlan::Group g = retry ? InflatePlan::Group{0, n, 0, (uint32_t)p.segs.size()} : p.groups[gi];
             if (gi) HIP_TRY(hipMemsetAsync(dnext, 0, 4, c->stream));
-            { Timed t(c, SPNG_K_PINF_FIND); HIP_TRY(launch_pinf2_find(ds, dg + g.g0, g.g1 - g.g0, c->stream)); }
-            { Timed t(c, SPNG_K_PINF_DECODE); HIP_TRY(launch_pinf2_decode(ds, dg + g.g0, g.g1 - g.g0, (uint32_t *)c->d_log, (uint8_t *)c->d_tok, dnext, p.pool_pages, c->stream)); }
-            HIP_TRY(launch_pinf2_scan(ds + g.s0, g.s1 - g.s0, dg, c->stream));
-            { Timed t(c, SPNG_K_PINF_RESOLVE); HIP_TRY(launch_pinf2_resolve(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, (uint8_t *)c->d_tok, p.pool_pages, dr, dd + g.s0, c->stream)); }
+            { Timed t(c, SPNG_K_PINF_FIND); HIP_TRY(launch_pinf2_find(ds, dg, g.g0, g.g1 - g.g0, retry, c->stream)); }
+            { Timed t(c, SPNG_K_PINF_DECODE); HIP_TRY(launch_pinf2_decode(ds, dg, g.g0, g.g1 - g.g0, (uint32_t *)c->d_log, (uint8_t *)c->d_tok, dnext, p.pool_pages, retry, c->stream)); }
+            HIP_TRY(launch_pinf2_scan(ds + g.s0, g.s1 - g.s0, dg, retry, c->stream));
+            { Timed t(c, SPNG_K_PINF_RESOLVE); HIP_TRY(launch_pinf2_resolve(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, (uint8_t *)c->d_tok, p.pool_pages, dr, dd + g.s0, retry, c->stream)); }
             HIP_TRY(launch_pinf2_account(dnext, p.pool_pages, c->stream));
         }
         if (!c->pool_pending) {
@@ -693,6 +704,25 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipMemcpy(hs.data(), a.dev<PStream>(p.streams_at), n * sizeof(PStream), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(hg.data(), a.dev<PSeg>(p.segs_at), hg.size() * sizeof(PSeg), hipMemcpyDeviceToHost));
+        {
+            // anomalies over the whole batch: segments without a start, segments that did not end on the next one
+            uint64_t nostart = 0, fail = 0, skipped = 0; uint32_t shown = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                const PStream &st = hs[i];
+                for (uint32_t k = 0; k < st.seg_count; ++k) {
+                    const PSeg &sg = hg[st.seg_first + k];
+                    const bool a = sg.start_bit == ~0ull, b = !a && sg.status != PSEG_CONT && sg.status != PSEG_FINAL, cskip = !a && !b && sg.status == PSEG_CONT && sg.next != k + 1;
+                    nostart += a; fail += b; skipped += cskip;
+                    if ((a || b || cskip) && shown < 12) {
+                        ++shown;
+                        fprintf(stderr, "[pinflate] anomaly: stream %u seg %u/%u start %lld end %lld status %d next %u ntok %llu\n", i, k, st.seg_count,
+                                (long long)sg.start_bit, (long long)sg.end_bit, sg.status, sg.next, (unsigned long long)sg.ntok);
+                    }
+                }
+            }
+            fprintf(stderr, "[pinflate] %u streams, %zu segments in %zu groups, pool %u pages: %llu without a start, %llu failed, %llu ran past the next start\n", n,
+                    hg.size(), p.groups.size(), p.pool_pages, (unsigned long long)nostart, (unsigned long long)fail, (unsigned long long)skipped);
+        }
         for (uint32_t i = 0; i < n && i < 4; ++i) {
             const PStream &st = hs[i];
             fprintf(stderr, "[pinflate] stream %u: len %llu segs %u seg_bytes %llu ok %d pass %u ntok %llu end_bit %llu\n", i,

@@ -95,7 +95,7 @@ struct PStream {
     uint64_t       start_bit, out_pos;
     uint64_t      *state;
 };
-enum { PSEG_FAIL = 0, PSEG_CONT = 1, PSEG_FINAL = 2, PSEG_PARTIAL = 3 };
+enum { PSEG_FAIL = 0, PSEG_CONT = 1, PSEG_FINAL = 2, PSEG_PARTIAL = 3, PSEG_NOPAGE = 4 };
 // One segment: the blocks that start in [index * seg_bytes, (index + 1) * seg_bytes).
 struct PSeg {
     uint32_t stream, index;
@@ -142,12 +142,12 @@ hipError_t launch_pinf_emit(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, ui
 hipError_t launch_pinf_resolve(PStream *d_streams, uint32_t nstreams, uint32_t *d_tokens, spng_result *d_results, int32_t *d_done,
                                uint32_t pass, hipStream_t stream);
 // pinflate2.hip
-hipError_t launch_pinf2_find(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, hipStream_t stream);
-hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint32_t *d_pt, uint8_t *d_pool, uint32_t *d_next,
-                               uint32_t pages, hipStream_t stream);
-hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, hipStream_t stream);
+hipError_t launch_pinf2_find(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t retry, hipStream_t stream);
+hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t *d_pt, uint8_t *d_pool, uint32_t *d_next,
+                               uint32_t pages, uint32_t retry, hipStream_t stream);
+hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t retry, hipStream_t stream);
 hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
-                                spng_result *d_results, int32_t *d_done, hipStream_t stream);
+                                spng_result *d_results, int32_t *d_done, uint32_t retry, hipStream_t stream);
 hipError_t launch_pinf2_account(uint32_t *d_ctr, uint32_t pages, hipStream_t stream);
 hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 // gzip.hip

@@ -61,7 +61,10 @@ typedef PV4 AS_GLOBAL gPV4;
 static constexpr int LB = 9, DB = 8, MB = 7;         // LUT index bits: lit/len, distance, code-length code
 static constexpr int SDW_MAX = 9;                      // dwords per lane subsequence (odd: conflict-free LDS stride)
 static constexpr int STAGE2_DW = 592;                  // staged compressed data: a chunk (2304 B) + alignment + a token's reach
-static constexpr uint32_t HWCAP = 2048;                // halfwords the LDS token buffer holds
+#ifndef SPNG_HWCAP
+#define SPNG_HWCAP 1920
+#endif
+static constexpr uint32_t HWCAP = SPNG_HWCAP;          // halfwords the LDS token buffer holds
 static constexpr uint32_t PAGE_SHIFT = 16;             // token pages: 64 KiB
 static constexpr uint32_t PAGE_UNITS = 1u << (PAGE_SHIFT - 4);
 static constexpr uint64_t NONE2 = ~0ull;
@@ -74,13 +77,58 @@ __device__ __forceinline__ uint32_t tk_m1(uint32_t dist) { return 0xC000u | (dis
 
 struct DPool { uint8_t *base; uint32_t *next; uint32_t pages, pad; };
 
+// phase cycle counters of a tuning build (-DSPNG_D_PROF; SPNG_LIB=... tools/probe_v2.py): one wave / workgroup prints
+#ifdef SPNG_D_PROF
+#define DP_ARG , uint64_t *dp
+#define DP_PASS , dp
+#define DP(k) do { const uint64_t now_ = __builtin_readcyclecounter(); dp[k] += now_ - dp[31]; dp[31] = now_; } while (0)
+#define DPN(k, v) (dp[k] += (v))
+#else
+#define DP_ARG
+#define DP_PASS
+#define DP(k)
+#define DPN(k, v)
+#endif
+
 // ---- per-wave LDS of find / decode ----------------------------------------------------------------------
+static constexpr uint32_t EXT = 480;                   // second-level table space, both codes together (zlib's bound for 286 symbols
+                                                       // behind a 2^9 root is 340; distances behind a 2^8 root rarely need more than 130)
+
+// Decode-table entries.  The loops that only need token LENGTHS (rounds 0 and 1) read two fields and add:
+//   lit/len   [4:0] bits of the code and its extra bits together, [7:5] class, [11:8] code length, [15:12] extra-bit
+//             count, [31:16] literal / base run
+//   distance  [4:0] bits of the code and its extra bits together, [5] not a usable distance (undefined half of a stub
+//             tree, symbols 30 / 31), [11:8] code length, [15:12] extra-bit count, [31:16] base distance
+//   link      class C_LINK / bit 7: the code is longer than the root index: [11:8] further index bits, [31:16] where its
+//             second-level table starts in ext
+enum { C_LIT = 0, C_EOB = 1, C_REF = 2, C_BAD = 3, C_LINK = 7 };      // (odd: the chain stops here)
+__device__ __forceinline__ uint32_t lit_entry2(uint32_t sym, uint32_t len)
+{
+    if (sym < 256) return len | C_LIT << 5 | len << 8 | sym << 16;
+    if (sym == 256) return len | C_EOB << 5 | len << 8;
+    // LZ77.Composites.swift:25-66 (run decades; symbols 286 / 287 are zero padding rows: (extra 0, base 0))
+    uint32_t base, cx;
+    if (sym < 265) { base = sym - 254; cx = 0; }
+    else if (sym < 285) { cx = (sym - 261) >> 2; base = ((4 + ((sym - 265) & 3)) << cx) + 3; }
+    else if (sym == 285) { base = 258; cx = 0; }
+    else { base = 0; cx = 0; }
+    return (len + cx) | (base ? C_REF : C_BAD) << 5 | len << 8 | cx << 12 | base << 16;
+}
+__device__ __forceinline__ uint32_t dist_entry2(uint32_t sym, uint32_t len)
+{
+    // LZ77.Composites.swift:68-110 (distance decades; 30 / 31 are zero padding rows)
+    uint32_t base, ox;
+    if (sym < 4) { base = sym + 1; ox = 0; }
+    else if (sym < 30) { ox = (sym >> 1) - 1; base = ((2 + (sym & 1)) << ox) + 1; }
+    else { base = 0; ox = 0; }
+    return (len + ox) | (base ? 0u : 32u) | len << 8 | ox << 12 | base << 16;
+}
+static constexpr uint32_t DIST_UNDEF = 1 | 32;             // the unused half of a stub tree: one bit, not usable
+
 struct DLds {
     uint32_t lit[1 << LB];
     uint32_t dist[1 << DB];
-    uint32_t ext_lit[288];             // LUT entries in canonical code order, for codes longer than the LUT index
-    uint32_t ext_dist[32];
-    Tree     tlit, tdist;
+    uint32_t ext[EXT];                 // second-level tables of the codes longer than the root index
     uint32_t stage[STAGE2_DW];
     union {
         struct {                       // while a header is parsed
@@ -88,17 +136,16 @@ struct DLds {
             uint32_t clut[1 << MB];    //   LUT of the code-length code
             uint32_t hb[6][16];        //   per batch of 64 symbols: how many of each length (5 lit/len batches, distances)
             uint32_t cl[32];
+            uint16_t first[2][16];     //   canonical first code of each length (lit/len, distance)
         } h;
         struct {                       // rounds 0 and 1 of a chunk
             uint32_t vmap[SDW_MAX * 64];   // visited-token-start bitmaps, word w of lane l at [w * 64 + l]
             uint16_t flag[64], mpos[64];   // lanes on the true chain; where it merges into their chains
             uint32_t ent[64];              // where it enters each subsequence | halfwords it decodes there before merging << 16
         } c;
-        uint16_t hw[HWCAP];            // the chunk's tokens on their way to HBM (find: the search window)
+        uint16_t hw[HWCAP];            // the chunk's tokens on their way to HBM
     };
 };
-
-struct Lim2 { uint32_t lit[15 - LB], dist[15 - DB]; };
 
 // ---- staging ------------------------------------------------------------------------------------------
 __device__ __forceinline__ v4u ld16(const g8 *src, uint64_t n, uint64_t off)
@@ -251,11 +298,64 @@ __device__ __attribute__((always_inline)) bool decode_lengths2(DLds &s, uint32_t
     return false;
 }
 
-// Both decode tables of a Huffman block from lens[0 .. literals + distances), in three LDS phases: per-batch
-// histograms of the code lengths; completeness, canonical first codes and offsets (lit/len in lanes 0-15, distances
-// in lanes 16-31); then every lane ranks its own symbols and scatters their LUT copies.  Restates
-// HuffmanTree.swift:80-174 (validate / size) and the decade tables of LZ77.Composites.swift.  false: a code
-// the reference rejects.  minlen = the shortest lit/len code.
+// Both decode tables of a Huffman block from lens[0 .. literals + distances), in LDS phases: per-batch histograms of
+// the code lengths; completeness and canonical first codes (lit/len in lanes 0-15, distances in lanes 16-31); every lane
+// ranks its own symbols, scatters the root-table copies of the short codes and notes, per root index, the longest code
+// behind it; the second-level tables are laid out by a prefix sum over the root table; the long codes fill them.
+// Restates HuffmanTree.swift:80-174 (validate / size) and the decade tables of LZ77.Composites.swift.  false: a code
+// the reference rejects (or second-level tables that outgrow their space: not this path's case).  minlen = the
+// shortest lit/len code.
+template <int ROOT, int KIND>
+__device__ __forceinline__ void place_symbol(uint32_t *lut, uint32_t sym, uint32_t my, uint32_t code)
+{
+    // short code: every root index that ends in it; long code: its root index learns how long codes behind it get
+    const uint32_t rev = __brev(code) >> (32 - my);
+    if (my <= (uint32_t)ROOT) {
+        const uint32_t e = KIND == 0 ? lit_entry2(sym, my) : dist_entry2(sym, my);
+        for (uint32_t j = rev; j < (1u << ROOT); j += 1u << my) lut[j] = e;
+    } else {
+        atomicMax(&lut[rev & ((1u << ROOT) - 1)], my);
+    }
+}
+template <int ROOT, int KIND>
+__device__ __forceinline__ void place_long(const uint32_t *lut, uint32_t *ext, uint32_t sym, uint32_t my, uint32_t code)
+{
+    if (my > (uint32_t)ROOT) {
+        const uint32_t rev = __brev(code) >> (32 - my);
+        const uint32_t link = lut[rev & ((1u << ROOT) - 1)];
+        const uint32_t sub = (link >> 8) & 15, at = link >> 16;
+        const uint32_t e = KIND == 0 ? lit_entry2(sym, my) : dist_entry2(sym, my);
+        for (uint32_t j = rev >> ROOT; j < (1u << sub); j += 1u << (my - ROOT)) ext[at + j] = e;
+    }
+}
+// root entries that hold a length (ROOT < v <= 15) become links; -> false when the second-level tables do not fit
+template <int ROOT>
+__device__ __forceinline__ bool layout_links(uint32_t *lut, uint32_t &used, uint32_t cap, int lane)
+{
+    constexpr int PER = (1 << ROOT) / 64;
+    uint32_t v[PER], need = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        v[k] = lut[lane * PER + k];
+        const bool link = v[k] > (uint32_t)ROOT && v[k] <= 15;
+        need += link ? 1u << (v[k] - ROOT) : 0u;
+    }
+    uint32_t tot;
+    uint32_t at = used + wave_excl_scan(need, tot, lane);
+    tot += used;
+#ifdef SPNG_EMU_TRACE
+    if (tot > cap && lane == 0) fprintf(stderr, "layout_links<%d>: need %u > cap %u\n", ROOT, tot, cap);
+#endif
+    if (tot > cap) return false;
+    used = tot;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const bool link = v[k] > (uint32_t)ROOT && v[k] <= 15;
+        if (link) { lut[lane * PER + k] = C_LINK << 5 | (v[k] - ROOT) << 8 | at << 16; at += 1u << (v[k] - ROOT); }
+    }
+    return true;
+}
+
 __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t literals, uint32_t distances, uint32_t &minlen, int lane)
 {
     uint32_t ll[5], dl;
@@ -291,43 +391,32 @@ __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t l
     // (HuffmanTree.swift:52-65, validate(symbols:normalizing:) :112-135)
     const bool stub = dused == 0 || (dused == 1 && d1m != 0);
     if (!stub && kdist != 32768u) return false;
-    const uint32_t first = (kraft - scaled) >> (15 - L);
-    const uint32_t off = row_scan(c) - c;
-    if (lane < 32 && L) {
-        Tree &t = isd ? s.tdist : s.tlit;
-        t.first[L] = (uint16_t)first; t.count[L] = (uint16_t)c; t.offset[L] = (uint16_t)off;
-    }
+    if (lane < 32) s.h.first[isd ? 1 : 0][L] = (uint16_t)((kraft - scaled) >> (15 - L));
     {
         const unsigned long long nz = __ballot(lane < 16 && c != 0);
         minlen = (uint32_t)__ffsll((long long)nz) - 1;
     }
 #pragma unroll
-    for (int j = 0; j < (1 << LB) / 64; ++j) s.lit[j * 64 + lane] = 0;      // 0 = "longer than the LUT index"
+    for (int j = 0; j < (1 << LB) / 64; ++j) s.lit[j * 64 + lane] = 0;
 #pragma unroll
     for (int j = 0; j < (1 << DB) / 64; ++j)
-        s.dist[j * 64 + lane] = !stub ? 0u : (dused && !((j * 64 + lane) & 1)) ? dist_entry((uint32_t)(__ffsll((long long)d1m) - 1), 1)
-                                                                               : entry(1, 0, K_UNDEF, 0);
+        s.dist[j * 64 + lane] = !stub ? 0u : (dused && !((j * 64 + lane) & 1)) ? dist_entry2((uint32_t)(__ffsll((long long)d1m) - 1), 1) : DIST_UNDEF;
     WSYNC();
-    // ---- every lane: its five lit/len symbols and its distance symbol
+    // ---- every lane: its five lit/len symbols and its distance symbol: canonical code = first code of the length + rank
+    uint32_t lcode[5], dcode = 0;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const uint32_t my = ll[k], sym = (uint32_t)lane + 64u * k;
+        const uint32_t my = ll[k];
         unsigned long long same = ~0ull;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const unsigned long long bk = __ballot((my >> b) & 1);
             same &= (my >> b) & 1 ? bk : ~bk;
         }
+        lcode[k] = 0;
         if (my) {
-            const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1));
-            const uint32_t rank = s.h.hb[k][my] + before;
-            const uint32_t f = s.tlit.first[my], o = s.tlit.offset[my];
-            const uint32_t e = litlen_entry(sym, my);
-            s.ext_lit[o + rank] = e;
-            if (my <= (uint32_t)LB) {
-                const uint32_t rev = __brev(f + rank) >> (32 - my);
-                for (uint32_t j = rev; j < (1u << LB); j += 1u << my) s.lit[j] = e;
-            }
+            lcode[k] = s.h.first[0][my] + s.h.hb[k][my] + (uint32_t)__popcll(same & ((1ull << lane) - 1));
+            place_symbol<LB, 0>(s.lit, (uint32_t)lane + 64u * k, my, lcode[k]);
         }
     }
     if (!stub) {
@@ -339,20 +428,24 @@ __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t l
             same &= (my >> b) & 1 ? bk : ~bk;
         }
         if (my) {
-            const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
-            const uint32_t f = s.tdist.first[my], o = s.tdist.offset[my];
-            const uint32_t e = dist_entry((uint32_t)lane, my);
-            s.ext_dist[o + rank] = e;
-            if (my <= (uint32_t)DB) {
-                const uint32_t rev = __brev(f + rank) >> (32 - my);
-                for (uint32_t j = rev; j < (1u << DB); j += 1u << my) s.dist[j] = e;
-            }
+            dcode = s.h.first[1][my] + (uint32_t)__popcll(same & ((1ull << lane) - 1));
+            place_symbol<DB, 1>(s.dist, (uint32_t)lane, my, dcode);
         }
-    } else if (lane >= 1 && lane < 16) {
-        // (a stub has no long codes: every length's limit must read "none")
-        s.tdist.first[lane] = 0; s.tdist.count[lane] = 0; s.tdist.offset[lane] = 0;
     }
     WSYNC();
+    // ---- second-level tables (only when some code is longer than its root index)
+    const bool longl = __ballot(ll[0] > (uint32_t)LB || ll[1] > (uint32_t)LB || ll[2] > (uint32_t)LB || ll[3] > (uint32_t)LB || ll[4] > (uint32_t)LB) != 0;
+    const bool longd = !stub && __ballot(dl > (uint32_t)DB) != 0;
+    uint32_t used = 0;
+    if (longl) { if (!UB(layout_links<LB>(s.lit, used, EXT, lane))) return false; }
+    if (longd) { if (!UB(layout_links<DB>(s.dist, used, EXT, lane))) return false; }
+    if (longl || longd) {
+        WSYNC();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (ll[k]) place_long<LB, 0>(s.lit, s.ext, (uint32_t)lane + 64u * k, ll[k], lcode[k]);
+        if (!stub && dl) place_long<DB, 1>(s.dist, s.ext, (uint32_t)lane, dl, dcode);
+        WSYNC();
+    }
     return true;
 }
 
@@ -414,62 +507,28 @@ __device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *
     return true;
 }
 
-__device__ __forceinline__ void load_limits2(const DLds &s, Lim2 &lc)
-{
-    // lengths no symbol has: limit = that of the next shorter length (count 0), so the compare chain skips them
-#pragma unroll
-    for (int k = 0; k < 15 - LB; ++k) { const int l = LB + 1 + k; lc.lit[k] = UNI((uint32_t)(s.tlit.first[l] + s.tlit.count[l]) << (15 - l)); }
-#pragma unroll
-    for (int k = 0; k < 15 - DB; ++k) { const int l = DB + 1 + k; lc.dist[k] = UNI((uint32_t)(s.tdist.first[l] + s.tdist.count[l]) << (15 - l)); }
-}
-
 // ---- per-lane token decoding ----------------------------------------------------------------------------
-// A code longer than the LUT index.  The canonical codes of one length are consecutive and lengths ascend with
-// the code value, so the length of the code in front of us is the number of (left-aligned) per-length upper
-// limits it reaches: a handful of compares against scalar registers; its entry then sits at a computed index
-// of the canonical-order table.
-template <int KIND>
-__device__ __forceinline__ uint32_t long_code2(uint32_t bits, const Lim2 &lim, const Tree &t, const uint32_t *ext)
-{
-    const uint32_t v = __brev(bits) >> 17;                     // next 15 bits, MSB first
-    uint32_t l;
-    if (KIND == 0) {
-        l = LB + 1;
-#pragma unroll
-        for (int k = 0; k < 14 - LB; ++k) l += v >= lim.lit[k];
-        if (v >= lim.lit[14 - LB]) return entry(15, 0, K_UNDEF, 0);
-    } else {
-        l = DB + 1;
-#pragma unroll
-        for (int k = 0; k < 14 - DB; ++k) l += v >= lim.dist[k];
-        if (v >= lim.dist[14 - DB]) return entry(15, 0, K_UNDEF, 0);
-    }
-    const uint32_t idx = t.offset[l] + (v >> (15 - l)) - t.first[l];
-    return ext[idx < (KIND == 0 ? 288u : 32u) ? idx : 0];
-}
-
-// decodes the token that starts at staged bit q.  -> bits | kind << 8 with kind 0 literal, 4 back-reference, 1 end
+// decodes the token that starts at staged bit q.  -> bits | kind << 8 with kind 0 literal, 2 back-reference, 1 end
 // of block, 3 not a token the fast path takes (undefined code, zero run or distance, past the end of the input
 // `lim`).  FULL also produces the token's halfwords (h0, and h1 for a reference).
-static constexpr uint32_t D2_LIT = 0, D2_EOB = 1, D2_BAD = 3, D2_REF = 4;
+static constexpr uint32_t D2_LIT = C_LIT, D2_EOB = C_EOB, D2_REF = C_REF, D2_BAD = C_BAD;   // (the entry's class as it is)
 template <bool FULL>
-__device__ __forceinline__ uint32_t decode_at2(const DLds &s, const Lim2 &lc, uint32_t q, uint32_t lim, uint32_t &h0, uint32_t &h1)
+__device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32_t lim, uint32_t &h0, uint32_t &h1)
 {
     uint32_t lo, hi;
     fetch2(s.stage, q, lo, hi);
     uint32_t e = s.lit[lo & ((1 << LB) - 1)];
-    if ((e & 15) == 0) e = long_code2<0>(lo, lc, s.tlit, s.ext_lit);
-    const uint32_t len1 = e & 15, kind = (e >> 8) & 3;
-    uint32_t nbits = len1, k = kind == K_LIT ? D2_LIT : kind == K_EOB ? D2_EOB : kind == K_MATCH ? D2_REF : D2_BAD;
-    if (kind == K_MATCH) {
-        const uint32_t cx = (e >> 4) & 15, p2 = len1 + cx;
+    if (e & 0x80) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index
+    const uint32_t p2 = e & 31, cls = (e >> 5) & 3;
+    uint32_t nbits = p2, k = cls;
+    if (cls == C_REF) {
         const uint32_t b2 = (uint32_t)(((uint64_t)hi << 32 | lo) >> p2);
         uint32_t d = s.dist[b2 & ((1 << DB) - 1)];
-        if ((d & 15) == 0) d = long_code2<1>(b2, lc, s.tdist, s.ext_dist);
-        const uint32_t dl = d & 15, ox = (d >> 4) & 15;
-        nbits = p2 + dl + ox;
-        if (((d >> 8) & 3) == K_UNDEF || (d >> 16) == 0 || (e >> 16) == 0) k = D2_BAD;
+        if (d & 0x80) d = s.ext[(d >> 16) + ((b2 >> DB) & ((1u << ((d >> 8) & 15)) - 1))];
+        nbits = p2 + (d & 31);
+        k |= (d >> 5) & 1;                                       // (not a usable distance: C_BAD)
         if (FULL) {
+            const uint32_t len1 = (e >> 8) & 15, cx = (e >> 12) & 15, dl = (d >> 8) & 15, ox = (d >> 12) & 15;
             const uint32_t run = (e >> 16) + ((lo >> len1) & ((1u << cx) - 1));
             const uint32_t dd = (d >> 16) + ((b2 >> dl) & ((1u << ox) - 1));
             h0 = tk_m0(run, dd); h1 = tk_m1(dd);
@@ -477,18 +536,20 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, const Lim2 &lc, ui
     } else if (FULL) {
         h0 = e >> 16;
     }
-    if (q + nbits > lim) k = D2_BAD;
+    k = q + nbits > lim ? D2_BAD : k;
     return nbits | k << 8;
 }
 
 // ---- segment search ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs)
+// (retry: only the streams whose first pass ran out of token pages -- PStream.pass == 1 -- are looked at again)
+__global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs, uint32_t seg0, uint32_t retry)
 {
     __shared__ __attribute__((aligned(16))) DLds s;
     __shared__ __attribute__((aligned(16))) uint32_t win[512 + 16];
     const int lane = threadIdx.x;
-    PSeg &sg = segs[blockIdx.x];
+    PSeg &sg = segs[seg0 + blockIdx.x];
     const PStream &st = streams[UNI(sg.stream)];
+    if (retry && UNI(st.pass) != 1) return;
     const g8 *src = (const g8 *)uni64((uint64_t)st.src);
     const uint64_t n = uni64(st.src_len), total = n * 8;
     const uint32_t j = UNI(sg.index);
@@ -559,16 +620,17 @@ struct Cursor {
     uint32_t carry_n;                  // halfwords in carry (0 .. 7)
     v4u      carry;
     g8      *ptr;                      // page of unit `units` (when npages > units >> 12)
+    bool     dry;                      // a page was wanted and none was left
 };
 
 // takes a page.  null: the pool or the segment's page table is exhausted
 __device__ __forceinline__ g8 *take_page(const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &c, int lane)
 {
-    if (c.npages >= pt_cap) return nullptr;
+    if (c.npages >= pt_cap) { c.dry = true; return nullptr; }
     uint32_t id = 0;
     if (lane == 0) id = atomicAdd(pool.next, 1u);
     id = UNI(id);
-    if (id >= pool.pages) return nullptr;
+    if (id >= pool.pages) { c.dry = true; return nullptr; }
     if (lane == 0) pt[c.npages] = id;
     c.npages += 1;
     return (g8 *)(pool.base + ((uint64_t)id << PAGE_SHIFT));
@@ -627,12 +689,12 @@ __device__ __forceinline__ void put_carry(DLds &s, const Cursor &c, int lane)
 //   replay    per subsequence the true chain enters it at `e` and `mine` halfwords of tokens start in it: the
 //             crossing chain's, then the owner's marks behind the merge point.  Every lane decodes exactly
 //             those, into the LDS token buffer at its prefix-sum offset; the buffer leaves in 16-byte units.
-__device__ __forceinline__ uint32_t decode_chunk(DLds &s, const Lim2 &lim_codes, SR2 &sr, const g8 *src, uint64_t n, uint64_t cb,
+__device__ __forceinline__ uint32_t decode_chunk(DLds &s, SR2 &sr, const g8 *src, uint64_t n, uint64_t cb,
                                                  uint64_t entry, uint32_t sdw, const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &cur,
-                                                 uint64_t &next, int lane)
+                                                 uint64_t &next, int lane DP_ARG)
 {
+    DP(0);
     const uint32_t sb = sdw * 32, chb = sb * 64;
-    const uint32_t inv = (65536u + sdw - 1) / sdw;            // x / sdw == x * inv >> 16 for x < 640
     const uint64_t sbyte = (cb >> 5) << 2;
     stage_put2(s.stage, sr, lane);                              // (fetched while the chunk before was decoded)
     stage_fetch2(sr, src, n, ((cb + chb) >> 5) << 2, lane);
@@ -647,40 +709,51 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const Lim2 &lim_codes,
     s.c.ent[lane] = 0;
     WSYNC();
     uint32_t d0, d1;
+    DP(1);
     const uint32_t q0 = lane == 0 ? (uint32_t)(entry - sbit) : sub0;
     uint32_t q = q0, st = 0;                                    // st: 0 running, 1 end of block, 2 not a token
     uint64_t mb0 = 0, mb1 = 0;                                  // which of my tokens (by ordinal) are back-references
     uint32_t ntk = 0;
     while (q < sub1) {
-        const uint32_t t = decode_at2<false>(s, lim_codes, q, lim, d0, d1);
+        DPN(16, 1);
+        const uint32_t t = decode_at2<false>(s, q, lim, d0, d1);
         const uint32_t k = t >> 8;
-        if (k & 3) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
+        if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
         const uint32_t b = q - sub0;
         atomicOr(&s.c.vmap[(b >> 5) * 64 + lane], 1u << (b & 31));
-        if (k == D2_REF) { if (ntk < 64) mb0 |= 1ull << ntk; else mb1 |= 1ull << (ntk - 64); }
+        {
+            const uint64_t bit = (uint64_t)(k >> 1) << (ntk & 63);
+            mb0 |= ntk < 64 ? bit : 0ull; mb1 |= ntk < 64 ? 0ull : bit;
+        }
         ntk += 1;
         q += t & 255;
     }
     WSYNC();
-    uint32_t link = 64, cnt2 = 0, nh = 0, lastj = (uint32_t)lane;
+    DP(2);
+    uint32_t link = 64, cnt2 = 0, nh = 0;
     uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;                    // crossings: position | halfwords before it << 16
     if (st == 0) {
+        uint32_t j = (uint32_t)lane, jb = sub1;                 // the subsequence q is in, and where it ends
         while (q < cend) {
-            const uint32_t j = (((q - off0) >> 5) * inv) >> 16, b = q - off0 - j * sb;
-            if (j != lastj) {
+            DPN(17, 1);
+            if (q >= jb) {                                      // (a token is shorter than a subsequence: one step at most)
                 const uint32_t v = q | cnt2 << 16;
                 x0 = nh == 0 ? v : x0; x1 = nh == 1 ? v : x1; x2 = nh == 2 ? v : x2; x3 = nh == 3 ? v : x3;
-                nh += 1; lastj = j;
+                nh += 1; j += 1; jb += sb;
             }
-            if ((s.c.vmap[(b >> 5) * 64 + j] >> (b & 31)) & 1) { link = j; break; }
-            const uint32_t t = decode_at2<false>(s, lim_codes, q, lim, d0, d1);
+            // (the mark's word travels with the token's bits: its test comes behind the decode it may make useless)
+            const uint32_t b = q + sb - jb;
+            const uint32_t mword = s.c.vmap[(b >> 5) * 64 + j];
+            const uint32_t t = decode_at2<false>(s, q, lim, d0, d1);
+            if ((mword >> (b & 31)) & 1) { link = j; break; }
             const uint32_t k = t >> 8;
-            if (k & 3) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
-            cnt2 += k == D2_REF ? 2u : 1u;
+            if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
+            cnt2 += 1 + (k >> 1);
             q += t & 255;
-        }
+            }
     }
     // q: where my chain merged / left the chunk / stopped
+    DP(3);
     bool onpath = lane == 0;
     uint32_t jump = link;
 #pragma unroll
@@ -736,43 +809,64 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const Lim2 &lim_codes,
     const int el = endm ? __ffsll((long long)endm) - 1 : 0;
     const uint32_t qe = (uint32_t)__shfl((int)q, el, 64), ste = endm ? (uint32_t)__shfl((int)st, el, 64) : 2u;
     next = sbit + qe;
+#ifdef SPNG_EMU_TRACE
+    if (ste == 2 && lane == 0) fprintf(stderr, "chunk cb %llu: path ends in a bad token (end lane %d, q %u)\n", (unsigned long long)cb, el, qe);
+#endif
     if (ste == 2) return 2;
-    if (__ballot(mine > HWCAP - 8)) return 2;                  // (a chain that never merged: not this path's case)
-    // ---- replay: the tokens, window after window of the LDS buffer
-    uint32_t base = 0;
+    DP(4);
+    DPN(20, 1); DPN(21, tot);
+    // ---- replay: the tokens, window after window of the LDS buffer.  A lane takes part in the window its next
+    // halfword falls in and stops where a token would cross the window's end (a lane that stands for a long unmerged
+    // stretch of the chain may need several windows).
+    uint32_t base = 0, done = 0, qq = e & 0xffff;
     while (base < tot) {
-        const bool in = mine != 0 && off >= base && off + mine <= base + (HWCAP - 8);
+        const uint32_t wend = base + (HWCAP - 8);
+        const bool in = done < mine && off + done >= base && off + done < wend;
         WSYNC();                                                // (everybody is done with what the buffer overlays)
         put_carry(s, cur, lane);
         WSYNC();
         if (in) {
-            uint32_t qq = e & 0xffff, o = cur.carry_n + off - base, done = 0;
+            const uint32_t o = cur.carry_n + off - base;
             while (done < mine) {
+                DPN(18, 1);
                 uint32_t h0 = 0, h1 = 0;
-                const uint32_t t = decode_at2<true>(s, lim_codes, qq, 0xffffffffu, h0, h1);
+                const uint32_t t = decode_at2<true>(s, qq, 0xffffffffu, h0, h1);
+                const uint32_t two = (t >> 8) == D2_REF ? 1u : 0u;
+                if (off + done + 1 + two > wend) break;
                 s.hw[o + done] = (uint16_t)h0;
-                if ((t >> 8) == D2_REF) { s.hw[o + done + 1] = (uint16_t)h1; done += 2; } else done += 1;
+                if (two) s.hw[o + done + 1] = (uint16_t)h1;
+                done += 1 + two;
                 qq += t & 255;
             }
         }
         WSYNC();
-        const unsigned long long inm = __ballot(in);
+        DP(5);
+        DPN(22, 1);
+        // the window ends where its first unfinished lane stopped, else behind its last lane
+        const unsigned long long inm = __ballot(in), cutm = __ballot(in && done < mine);
         if (!inm) return 2;
-        const int hi = 63 - __clzll((long long)inm);
-        const uint32_t endv = (uint32_t)__shfl((int)(off + mine), hi, 64);
+        const int pick = cutm ? __ffsll((long long)cutm) - 1 : 63 - __clzll((long long)inm);
+        const uint32_t endv = (uint32_t)__shfl((int)(off + done), pick, 64);
+        if (endv <= base) return 2;
         if (!UB(flush_tokens(s, pool, pt, pt_cap, cur, endv - base, lane))) return 2;
+        DP(6);
         base = endv;
     }
     return ste;
 }
 
-__global__ __launch_bounds__(64, 4) void pinf2_decode_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs,
-                                                          uint32_t *__restrict__ pt_slab, DPool pool)
+#ifndef SPNG_D_WAVES
+#define SPNG_D_WAVES 4
+#endif
+__global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs,
+                                                          uint32_t *__restrict__ pt_slab, DPool pool, uint32_t seg0, uint32_t retry)
 {
+    // (segs = the whole table -- a stream's seg_first counts from its beginning; this launch's segments start at seg0)
     __shared__ __attribute__((aligned(16))) DLds s;
     const int lane = threadIdx.x;
-    PSeg &sg = segs[blockIdx.x];
+    PSeg &sg = segs[seg0 + blockIdx.x];
     const PStream &st = streams[UNI(sg.stream)];
+    if (retry && UNI(st.pass) != 1) return;
     const uint64_t start = uni64(sg.start_bit);
     if (start == NONE2) return;
     const g8 *src = (const g8 *)uni64((uint64_t)st.src);
@@ -791,10 +885,18 @@ __global__ __launch_bounds__(64, 4) void pinf2_decode_kernel(const PStream *__re
         }
     };
     advance(start + 1);
+    // the page table: my own entries and those of the segments behind me in which no start was found (nobody else
+    // writes there; a stream whose stored or fixed blocks hide every later start needs them)
     g32 *pt = (g32 *)(pt_slab + uni64(sg.log_off));
-    const uint32_t pt_cap = (uint32_t)uni64(sg.log_cap);
+    uint32_t pt_cap;
+    {
+        const PSeg &upto = segs[seg_first + (nk < seg_count ? nk : seg_count - 1)];
+        const uint64_t end = uni64(upto.log_off) + (nk < seg_count ? 0 : uni64(upto.log_cap));
+        const uint64_t room = end - uni64(sg.log_off);
+        pt_cap = room > 0xffffff00ull ? 0xffffff00u : (uint32_t)room;
+    }
     Cursor cur;
-    cur.units = 0; cur.npages = 0; cur.carry_n = 0; cur.ptr = nullptr;
+    cur.units = 0; cur.npages = 0; cur.carry_n = 0; cur.ptr = nullptr; cur.dry = false;
     cur.carry[0] = cur.carry[1] = cur.carry[2] = cur.carry[3] = 0;
     uint64_t pos = start;
     int32_t status = PSEG_FAIL;
@@ -803,6 +905,12 @@ __global__ __launch_bounds__(64, 4) void pinf2_decode_kernel(const PStream *__re
     // blocks before it.
     const bool resumable = uni64((uint64_t)st.state) != 0;
     uint64_t hw_block = 0;
+#ifdef SPNG_D_PROF
+    uint64_t dp[32];
+    for (int i = 0; i < 32; ++i) dp[i] = 0;
+    dp[31] = __builtin_readcyclecounter();
+    const uint64_t dp_t0 = dp[31];
+#endif
     for (;;) {
         if (pos >= limit) {
             if (pos == limit) { status = PSEG_CONT; break; }
@@ -811,7 +919,14 @@ __global__ __launch_bounds__(64, 4) void pinf2_decode_kernel(const PStream *__re
         }
         Hdr2 h;
         hw_block = cur.units * 8 + cur.carry_n;
-        if (!UB(parse_header2(s, src, n, pos, h, lane))) break;
+        DP(7);
+        const bool hok_ = UB(parse_header2(s, src, n, pos, h, lane));
+        DP(8);
+        DPN(23, 1);
+#ifdef SPNG_EMU_TRACE
+        if (!hok_ && lane == 0) fprintf(stderr, "header at bit %llu rejected\n", (unsigned long long)pos);
+#endif
+        if (!hok_) break;
         if (h.type == 0) {
             // stored bytes are literal tokens
             const uint64_t from = h.payload / 8;
@@ -833,13 +948,11 @@ __global__ __launch_bounds__(64, 4) void pinf2_decode_kernel(const PStream *__re
             const uint32_t sdw = h.minlen >= 3 ? 9u : h.minlen == 2 ? 7u : 3u;
             uint64_t entry = h.payload, cb = h.payload;
             uint32_t state = 0;
-            Lim2 lc;
-            load_limits2(s, lc);
             SR2 sr;
             stage_fetch2(sr, src, n, (cb >> 5) << 2, lane);
             for (;;) {
                 uint64_t next;
-                state = UNI(decode_chunk(s, lc, sr, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane));
+                state = UNI(decode_chunk(s, sr, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS));
                 entry = uni64(next);
                 if (state) break;
                 cb += (uint64_t)sdw * 32 * 64;
@@ -861,26 +974,35 @@ __global__ __launch_bounds__(64, 4) void pinf2_decode_kernel(const PStream *__re
         const uint32_t pad = 8 - cur.carry_n;
         if (!UB(flush_tokens(s, pool, pt, pt_cap, cur, pad, lane))) status = PSEG_FAIL;
     }
+    if (status == PSEG_FAIL && cur.dry) status = PSEG_NOPAGE;
     if (lane == 0) { sg.end_bit = pos; sg.ntok = nhw; sg.status = status; sg.next = nk; }
+#ifdef SPNG_D_PROF
+    if (blockIdx.x == 1 && lane == 0)
+        printf("decode: %lu blocks %lu chunks %lu halfwords %lu windows; lane-0 steps r0 %lu r1 %lu replay %lu; cycles: total %lu stage %lu setup %lu round0 %lu "
+               "round1 %lu path %lu replay %lu flush %lu header %lu other %lu\n",
+               dp[23], dp[20], dp[21], dp[22], dp[16], dp[17], dp[18], __builtin_readcyclecounter() - dp_t0, dp[0], dp[1], dp[2], dp[3], dp[4], dp[5], dp[6], dp[8], dp[7]);
+#endif
 }
 
 // ---- scan: the segment chain of every stream -----------------------------------------------------------------
 // One wave per stream walks the chain: segment 0, then the segment decode says it stopped at, ... up to the
 // first one that saw the final block.  A found start that no chain member stops at (a bit pattern inside
 // stored data or in the middle of a block that happens to parse as a header) is simply not on the chain.
-__global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ streams, PSeg *__restrict__ segs)
+__global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ streams, PSeg *__restrict__ segs, uint32_t retry)
 {
     const int lane = threadIdx.x;
     PStream &st = streams[blockIdx.x];
+    if (retry && UNI(st.pass) != 1) return;
     const uint32_t first = UNI(st.seg_first), count = UNI(st.seg_count);
-    bool ok = false, partial = false;
+    bool ok = false, partial = false, dry = false;
     uint64_t tok = 0, end_bit = 0;
     uint32_t k = 0;
     for (uint32_t hops = 0; hops < count; ++hops) {
         PSeg *sg = segs + first + k;
         const uint64_t start = uni64(sg->start_bit), end = uni64(sg->end_bit);
         const int32_t status = (int32_t)UNI(sg->status);
-        if (start == NONE2 || status == PSEG_FAIL) break;
+        if (status == PSEG_NOPAGE && start != NONE2) dry = true;
+        if (start == NONE2 || status == PSEG_FAIL || status == PSEG_NOPAGE) break;
         if (lane == 0) { sg->tok_base = tok; sg->used = 1; }
         tok += uni64(sg->ntok);
         if (status == PSEG_FINAL) { ok = true; end_bit = end; break; }
@@ -890,7 +1012,8 @@ __global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ st
         if (uni64(segs[first + nx].start_bit) != end) break;
         k = nx;
     }
-    if (lane == 0) { st.ok = ok ? (partial ? 2 : 1) : 0; st.ntok = tok; st.end_bit = end_bit; st.pass = 0; st.tok_base = 0; }
+    // pass: 1 = the chain broke where the token pool was empty: once more, with the pool to itself and its like (retry)
+    if (lane == 0) { st.ok = ok ? (partial ? 2 : 1) : 0; st.ntok = tok; st.end_bit = end_bit; st.pass = (!retry && dry) ? 1 : 0; st.tok_base = 0; }
 }
 
 // ---- resolve: tokens -> bytes -------------------------------------------------------------------------------
@@ -930,12 +1053,12 @@ __device__ __forceinline__ uint32_t block_excl_scan2(RLds2 &s, uint32_t v, uint3
 
 __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__restrict__ streams, const PSeg *__restrict__ segs,
                                                                const uint32_t *__restrict__ pt_slab, DPool pool,
-                                                               spng_result *__restrict__ results, int32_t *__restrict__ done)
+                                                               spng_result *__restrict__ results, int32_t *__restrict__ done, uint32_t retry)
 {
     __shared__ __attribute__((aligned(16))) RLds2 s;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)UNI((uint32_t)tid >> 6);
     const PStream &st = streams[blockIdx.x];
-    if (!UNI(st.ok)) return;
+    if (!UNI(st.ok) || (retry && done[blockIdx.x])) return;
     g8 *dst = (g8 *)uni64((uint64_t)st.dst);
     const uint64_t cap = uni64(st.dst_cap);
     const g8 *src = (const g8 *)uni64((uint64_t)st.src);
@@ -953,6 +1076,14 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
     __syncthreads();
     const uint32_t seg_first = UNI(st.seg_first), seg_count = UNI(st.seg_count);
     uint32_t sk = 0;
+#ifdef SPNG_D_PROF
+    uint64_t rp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, rp_t = __builtin_readcyclecounter();
+#define RP2(k) do { const uint64_t now_ = __builtin_readcyclecounter(); rp[k] += now_ - rp_t; rp_t = now_; } while (0)
+#define RPN2(k, v) (rp[k] += (v))
+#else
+#define RP2(k)
+#define RPN2(k, v)
+#endif
     for (uint32_t hops = 0; hops < seg_count && !over; ++hops) {
         const PSeg &sg = segs[seg_first + sk];
         const uint64_t nhw = uni64(sg.ntok);
@@ -975,6 +1106,7 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
         };
         v4u tv = load_unit(0);
         while (cursor < nhw) {
+            RP2(0);
             // ---- the window: eight halfwords per thread
             const uint64_t ub = cursor >> 3;
             const uint32_t hskip = (uint32_t)(cursor & 7);
@@ -996,6 +1128,7 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
             }
             uint32_t total;
             const uint32_t offp = block_excl_scan2(s, refs << 20 | bytes, total, tid);      // (barriers inside: h0 is visible)
+            RP2(1);
             uint32_t curb = offp & 0xfffff, curm = offp >> 20;
             const uint32_t hnext = tid + 1 < (int)RT2 ? s.h0[tid + 1] : TK_NULL;
             // take tokens while the tile has room
@@ -1045,6 +1178,7 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
                 __syncthreads();
             }
             tv = load_unit(cursor_next);
+            RP2(2);
             // ---- expand: the reference (if any) that covers each of my bytes
             const uint32_t rbase = (uint32_t)pos & (WINDOW2 - 1);
             uint32_t sv[16];
@@ -1057,47 +1191,64 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
                 // (row = wave + 8 k: its parity is the wave's)
                 const bool odd = wave & 1;
                 const uint32_t srclo = odd ? bw[2] : bw[0], srchi = odd ? bw[3] : bw[1], srcbase = odd ? rb + ca : rb;
+                // eight rows at a time, so that the record reads and then the ring reads of a batch travel together
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t row = (uint32_t)wave + 8u * k;
-                    const uint32_t j = row * 64 + (uint32_t)lane;
-                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)srclo, (int)(row >> 1));
-                    const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)srchi, (int)(row >> 1));
-                    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)srcbase, (int)(row >> 1));
-                    sv[k] = R2_DONE;
-                    if (row * 64 >= tlen) continue;
-                    const unsigned long long mw = (unsigned long long)mhi << 32 | mlo;
-                    const uint32_t id = base + (uint32_t)__popcll(mw & ((2ull << lane) - 1));
-                    const uint32_t r0 = s.rec[id ? id - 1 : 0][0], r1 = s.rec[id ? id - 1 : 0][1];
-                    const uint32_t startb = r0 & 0xffff, len = r0 >> 16, d = r1;
-                    uint32_t kk = j - startb;
-                    const bool inside = id != 0 && kk < len && j < tlen;
-                    // A run longer than its distance repeats its first `distance` bytes: a byte beyond the first
-                    // period copies the period in front of the run (same value, chain one level deep instead of
-                    // run / distance levels).
-                    if (inside && kk >= d) kk -= d * (uint32_t)__fdividef((float)kk + 0.5f, (float)d);          // kk mod d, kk < 258
-                    const uint32_t si = startb - d + kk;          // >= 0x80000000: before the tile
-                    const uint32_t far = s.ring[(rbase + si) & (WINDOW2 - 1)];
-                    if (inside && (int32_t)si < 0 && pos < (uint64_t)(0u - si)) bad = true;
-                    if (inside) {
-                        const uint32_t v = (int32_t)si < 0 ? R2_DONE | far : si;
-                        sv[k] = v;
-                        s.state[j] = (uint16_t)v;
+                for (int half = 0; half < 2; ++half) {
+                    uint32_t r0v[8], r1v[8];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int k = half * 8 + kk;
+                        const uint32_t row = (uint32_t)wave + 8u * k;
+                        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)srclo, (int)(row >> 1));
+                        const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)srchi, (int)(row >> 1));
+                        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)srcbase, (int)(row >> 1));
+                        const unsigned long long mw = (unsigned long long)mhi << 32 | mlo;
+                        const uint32_t id = base + (uint32_t)__popcll(mw & ((2ull << lane) - 1));
+                        r0v[kk] = id ? s.rec[id - 1][0] : 0u;          // (no reference in front of this byte: run 0)
+                        r1v[kk] = id ? s.rec[id - 1][1] : 1u;
+                    }
+                    uint32_t siv[8], farv[8];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int k = half * 8 + kk;
+                        const uint32_t j = ((uint32_t)wave + 8u * k) * 64 + (uint32_t)lane;
+                        const uint32_t startb = r0v[kk] & 0xffff, len = r0v[kk] >> 16, d = r1v[kk];
+                        uint32_t kk2 = j - startb;
+                        const bool inside = kk2 < len && j < tlen;
+                        // A run longer than its distance repeats its first `distance` bytes: a byte beyond the first
+                        // period copies the period in front of the run (same value, chain one level deep instead of
+                        // run / distance levels).
+                        if (inside && kk2 >= d) kk2 -= d * (uint32_t)__fdividef((float)kk2 + 0.5f, (float)d);     // kk2 mod d, kk2 < 258
+                        siv[kk] = inside ? startb - d + kk2 : 0x7fffffffu;                     // >= 0x80000000: before the tile
+                        farv[kk] = s.ring[(rbase + siv[kk]) & (WINDOW2 - 1)];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int k = half * 8 + kk;
+                        const uint32_t j = ((uint32_t)wave + 8u * k) * 64 + (uint32_t)lane;
+                        const uint32_t si = siv[kk];
+                        sv[k] = R2_DONE;
+                        if (si != 0x7fffffffu) {
+                            if ((int32_t)si < 0 && pos < (uint64_t)(0u - si)) bad = true;
+                            const uint32_t v = (int32_t)si < 0 ? R2_DONE | farv[kk] : si;
+                            sv[k] = v;
+                            s.state[j] = (uint16_t)v;
+                        }
                     }
                 }
             }
             __syncthreads();
+            RP2(3);
             if (tid < (int)(TILE2 / 32)) s.bitmap[tid] = 0;          // (read above; next written after the next scan's barriers)
             // ---- pointer jumping
             for (uint32_t round = 0;; ++round) {
                 bool more = false;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const bool unk = !(sv[k] & R2_DONE);
-                    if (__ballot(unk)) {
+                    if (!(sv[k] & R2_DONE)) {
                         const uint32_t j = ((uint32_t)wave + 8u * k) * 64 + (uint32_t)lane;
-                        const uint32_t g = s.state[unk ? sv[k] : j];
-                        if (unk) { sv[k] = g; s.state[j] = (uint16_t)g; more = more || !(g & R2_DONE); }
+                        const uint32_t g = s.state[sv[k]];
+                        sv[k] = g; s.state[j] = (uint16_t)g; more = more || !(g & R2_DONE);
                     }
                 }
                 // one barrier per round.  Three flags in rotation: the one cleared here was last read before
@@ -1107,8 +1258,10 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
                 __syncthreads();
                 const bool go = s.again[fr] != 0;
                 if (tid == 0) s.again[fr == 0 ? 2 : fr - 1] = 0;
+                RPN2(9, 1);
                 if (!go) break;
             }
+            RP2(4);
             // ---- the bytes: into the ring, then to the output in whole 16-byte units of the position
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -1135,10 +1288,17 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
             }
             pos += tlen;
             cursor = cursor_next;
+            RP2(5);
+            RPN2(8, 1); RPN2(10, tlen);
         }
         if (sstatus == PSEG_FINAL || sstatus == PSEG_PARTIAL) break;
         sk = UNI(sg.next);
     }
+#ifdef SPNG_D_PROF
+    if (blockIdx.x == 0 && (tid == 0 || tid == 300))
+        printf("resolve[t%d]: %lu tiles (%lu bytes), %lu rounds; cycles: loop %lu window+scan %lu take+prefetch %lu expand %lu jump %lu store %lu\n",
+               tid, rp[8], rp[10], rp[9], rp[0], rp[1], rp[2], rp[3], rp[4], rp[5]);
+#endif
     // the bytes behind the last whole unit
     __syncthreads();
     {
@@ -1214,28 +1374,28 @@ __global__ void pinf2_account_kernel(uint32_t *ctr, uint32_t pages)
 
 // ---- host ------------------------------------------------------------------------------------------------
 #ifndef SPNG_EMU
-hipError_t launch_pinf2_find(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, hipStream_t stream)
+hipError_t launch_pinf2_find(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t retry, hipStream_t stream)
 {
-    pinf2_find_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs);
+    pinf2_find_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs, seg0, retry);
     return hipGetLastError();
 }
-hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint32_t *d_pt, uint8_t *d_pool, uint32_t *d_next,
-                               uint32_t pages, hipStream_t stream)
+hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t *d_pt, uint8_t *d_pool, uint32_t *d_next,
+                               uint32_t pages, uint32_t retry, hipStream_t stream)
 {
     DPool pool{d_pool, d_next, pages, 0};
-    pinf2_decode_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_pt, pool);
+    pinf2_decode_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_pt, pool, seg0, retry);
     return hipGetLastError();
 }
-hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, hipStream_t stream)
+hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t retry, hipStream_t stream)
 {
-    pinf2_scan_kernel<<<nstreams, 64, 0, stream>>>(d_streams, d_segs);
+    pinf2_scan_kernel<<<nstreams, 64, 0, stream>>>(d_streams, d_segs, retry);
     return hipGetLastError();
 }
 hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
-                                spng_result *d_results, int32_t *d_done, hipStream_t stream)
+                                spng_result *d_results, int32_t *d_done, uint32_t retry, hipStream_t stream)
 {
     DPool pool{d_pool, nullptr, pages, 0};
-    pinf2_resolve_kernel<<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done);
+    pinf2_resolve_kernel<<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, retry);
     return hipGetLastError();
 }
 hipError_t launch_pinf2_account(uint32_t *d_ctr, uint32_t pages, hipStream_t stream)

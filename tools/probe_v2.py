@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--kinds", default="zlib,swiftpng")
     ap.add_argument("--modes", default="auto,legacy")
+    ap.add_argument("--segments", default="0", help="comma list of SPNG_CFG_SEGMENT_BYTES values to try (auto mode)")
     args = ap.parse_args()
     import torch
     import swift_png_amd as spng
@@ -32,8 +33,9 @@ def main():
         d_streams = [s.to_device(z) for z in streams]
         print(f"[{kind}] inputs in {time.time() - t0:.1f} s, ratio {sum(len(r) for r in rows) / sum(len(z) for z in streams):.3f}", flush=True)
         ref = [s.to_device(img.reshape(-1)) for img in images]
-        for mode in args.modes.split(","):
+        for mode, segb in [(m, int(sb)) for m in args.modes.split(",") for sb in (args.segments.split(",") if m == "auto" else ["0"])]:
             s.configure(spng.CFG_INFLATE_MODE, {"auto": spng.INFLATE_AUTO, "legacy": spng.INFLATE_LEGACY}[mode])
+            s.configure(spng.CFG_SEGMENT_BYTES, segb)
             job = bench.DecodeJob(spng, s, torch, d_streams, args.images, 0, args.unique, 1)
             for _ in range(2):
                 job.decode_group(0)
@@ -51,8 +53,8 @@ def main():
             bad = [r.status for r in res if r.status or r.written != job.U][:4]
             okay = all(torch.equal(job.d_out[j * job.S:(j + 1) * job.S], ref[job.src[j]]) for j in range(0, args.images, max(1, args.images // 64)))
             line = {"ms_per_step": round(dt * 1e3, 2), "stages": prof, "pipeline_streams": fast, "bad": bad, "bit_exact": okay}
-            out[f"{kind}/{mode}"] = line
-            print(kind, mode, json.dumps(line), flush=True)
+            out[f"{kind}/{mode}/{segb}"] = line
+            print(kind, mode, segb, json.dumps(line), flush=True)
             del job
             torch.cuda.empty_cache()
         s.configure(spng.CFG_INFLATE_MODE, spng.INFLATE_AUTO)
