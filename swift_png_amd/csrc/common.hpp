@@ -6,6 +6,20 @@
 
 namespace spng {
 
+// ---- device-side vocabulary shared by every kernel file --------------------------------------------------------
+// Wave-uniform values loaded through the vector path are pinned to scalar registers (the bit readers and
+// symbol-boundary chains then run on the scalar unit).
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)UNI(v >> 32) << 32 | UNI((uint32_t)v); }
+// A wave-uniform condition, said so to the compiler: its divergence analysis is conservative at control-flow joins,
+// and one branch it takes for lane-dependent turns every loop around it into exec-mask bookkeeping.
+#define UB(c) (UNI((c) ? 1u : 0u) != 0u)
+#ifndef SPNG_EMU
+typedef uint8_t __attribute__((address_space(1))) gbyte;      // a byte in global memory (global_load, not flat_load)
+#else
+typedef uint8_t gbyte;
+#endif
+
 // One unfilter job = one dependency chain of scanlines: a whole non-interlaced image or one
 // Adam7 sub-image (PNG.Decoder.swift:59-140).  Rows are `in_stride` apart starting at `in`
 // (which points at the first row's filter byte); defiltered bytes of row y go to

@@ -6,9 +6,6 @@
 
 namespace spng {
 
-typedef uint8_t __attribute__((address_space(1))) gbyte;
-#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)UNI(v >> 32) << 32 | UNI((uint32_t)v); }
 #define LSYNC() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
 
 static constexpr uint32_t POLY = 0xedb88320u;
@@ -17,8 +14,8 @@ static constexpr uint32_t POLY = 0xedb88320u;
 __host__ __device__ inline uint32_t multmodp(uint32_t a, uint32_t b)
 {
     uint32_t m = 1u << 31, p = 0;
-    for (;;) {
-        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+    while (a) {                                               // (a == 0: the product is 0)
+        if (a & m) { p ^= b; a &= ~m; }
         m >>= 1;
         b = b & 1 ? (b >> 1) ^ POLY : b >> 1;
     }

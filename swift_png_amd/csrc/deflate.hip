@@ -42,7 +42,6 @@ struct __attribute__((packed)) U32u { uint32_t v; };
 struct __attribute__((packed)) U128u { u32x4 v; };
 // Input, output and the link ring are global memory, and say so in their types (a generic pointer
 // costs flat instructions, which also tie up the LDS counter).
-typedef uint8_t __attribute__((address_space(1))) gbyte;
 typedef uint32_t __attribute__((address_space(1))) gword;
 typedef U32u __attribute__((address_space(1))) gU32u;
 

@@ -10,15 +10,6 @@
 
 namespace spng {
 
-// Wave-uniform values loaded through the vector path (LDS) are pinned to scalar registers so that
-// the whole bit reader and the symbol-boundary chain run on the scalar unit.
-#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)UNI(v >> 32) << 32 | UNI((uint32_t)v); }
-// A wave-uniform condition, said so to the compiler: its divergence analysis is conservative at
-// control-flow joins, and one branch it takes for lane-dependent turns every loop around it into
-// exec-mask bookkeeping.
-#define UB(c) (UNI((c) ? 1u : 0u) != 0u)
-
 // LUT entry: [3:0] code length (0 = longer than the LUT index), [7:4] extra bits,
 // [9:8] kind, [10] literal / [11] back-reference half that the speculative decoder may take without
 // any further check (a real code with a non-zero base), [31:16] literal / base run / base distance.

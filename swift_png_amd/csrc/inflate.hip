@@ -60,7 +60,6 @@ struct __attribute__((packed)) U128u { u32x4 v; };
 // The stream and output pointers are rebuilt from scalar registers; typed as global memory they
 // compile to global_load/global_store (a generic pointer would cost flat instructions, which also
 // tie up the LDS counter).
-typedef uint8_t __attribute__((address_space(1))) gbyte;
 typedef U128u __attribute__((address_space(1))) gU128u;
 
 static constexpr int RING = 32768;           // output window in LDS (power of two)

@@ -60,7 +60,6 @@ namespace spng {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed)) PU128 { u32x4 v; };
-typedef uint8_t __attribute__((address_space(1))) gbyte;
 typedef PU128 __attribute__((address_space(1))) gPU128;
 
 #ifndef SPNG_LBITS

@@ -137,6 +137,7 @@ struct DLds {
             uint32_t hb[6][16];        //   per batch of 64 symbols: how many of each length (5 lit/len batches, distances)
             uint32_t cl[32];
             uint16_t first[2][16];     //   canonical first code of each length (lit/len, distance)
+            uint16_t codes[6][64];     //   every lane's canonical codes (five lit/len symbols, one distance symbol)
         } h;
         struct {                       // rounds 0 and 1 of a chunk
             uint32_t vmap[SDW_MAX * 64];   // visited-token-start bitmaps, word w of lane l at [w * 64 + l]
@@ -358,15 +359,19 @@ __device__ __forceinline__ bool layout_links(uint32_t *lut, uint32_t &used, uint
 
 __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t literals, uint32_t distances, uint32_t &minlen, int lane)
 {
-    uint32_t ll[5], dl;
+    // (the six code lengths of a lane -- five lit/len symbols, one distance symbol -- travel in one register)
+    uint32_t packed = 0;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { const uint32_t sym = (uint32_t)lane + 64u * k; ll[k] = sym < literals ? s.h.lens[sym] : 0u; }
-    dl = (uint32_t)lane < distances ? s.h.lens[literals + lane] : 0u;
+    for (int k = 0; k < 5; ++k) { const uint32_t sym = (uint32_t)lane + 64u * k; packed |= (sym < literals ? (uint32_t)s.h.lens[sym] : 0u) << (4 * k); }
+    packed |= ((uint32_t)lane < distances ? (uint32_t)s.h.lens[literals + lane] : 0u) << 20;
+#define LL(k) ((packed >> (4 * (k))) & 15)
+#define DL ((packed >> 20) & 15)
     for (int i = lane; i < 96; i += 64) (&s.h.hb[0][0])[i] = 0;
     WSYNC();
 #pragma unroll
-    for (int k = 0; k < 5; ++k) __hip_atomic_fetch_add(&s.h.hb[k][ll[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(&s.h.hb[5][dl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int k = 0; k < 5; ++k) __hip_atomic_fetch_add(&s.h.hb[k][LL(k)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&s.h.hb[5][DL], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t dl = DL;
     const uint32_t dused = (uint32_t)__popcll(__ballot(dl != 0));
     const unsigned long long d1m = __ballot(dl == 1);
     WSYNC();
@@ -403,20 +408,20 @@ __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t l
         s.dist[j * 64 + lane] = !stub ? 0u : (dused && !((j * 64 + lane) & 1)) ? dist_entry2((uint32_t)(__ffsll((long long)d1m) - 1), 1) : DIST_UNDEF;
     WSYNC();
     // ---- every lane: its five lit/len symbols and its distance symbol: canonical code = first code of the length + rank
-    uint32_t lcode[5], dcode = 0;
+    // (the codes wait in LDS for the second-level pass)
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const uint32_t my = ll[k];
+        const uint32_t my = LL(k);
         unsigned long long same = ~0ull;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const unsigned long long bk = __ballot((my >> b) & 1);
             same &= (my >> b) & 1 ? bk : ~bk;
         }
-        lcode[k] = 0;
         if (my) {
-            lcode[k] = s.h.first[0][my] + s.h.hb[k][my] + (uint32_t)__popcll(same & ((1ull << lane) - 1));
-            place_symbol<LB, 0>(s.lit, (uint32_t)lane + 64u * k, my, lcode[k]);
+            const uint32_t code = s.h.first[0][my] + s.h.hb[k][my] + (uint32_t)__popcll(same & ((1ull << lane) - 1));
+            s.h.codes[k][lane] = (uint16_t)code;
+            place_symbol<LB, 0>(s.lit, (uint32_t)lane + 64u * k, my, code);
         }
     }
     if (!stub) {
@@ -428,13 +433,14 @@ __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t l
             same &= (my >> b) & 1 ? bk : ~bk;
         }
         if (my) {
-            dcode = s.h.first[1][my] + (uint32_t)__popcll(same & ((1ull << lane) - 1));
-            place_symbol<DB, 1>(s.dist, (uint32_t)lane, my, dcode);
+            const uint32_t code = s.h.first[1][my] + (uint32_t)__popcll(same & ((1ull << lane) - 1));
+            s.h.codes[5][lane] = (uint16_t)code;
+            place_symbol<DB, 1>(s.dist, (uint32_t)lane, my, code);
         }
     }
     WSYNC();
     // ---- second-level tables (only when some code is longer than its root index)
-    const bool longl = __ballot(ll[0] > (uint32_t)LB || ll[1] > (uint32_t)LB || ll[2] > (uint32_t)LB || ll[3] > (uint32_t)LB || ll[4] > (uint32_t)LB) != 0;
+    const bool longl = __ballot(LL(0) > (uint32_t)LB || LL(1) > (uint32_t)LB || LL(2) > (uint32_t)LB || LL(3) > (uint32_t)LB || LL(4) > (uint32_t)LB) != 0;
     const bool longd = !stub && __ballot(dl > (uint32_t)DB) != 0;
     uint32_t used = 0;
     if (longl) { if (!UB(layout_links<LB>(s.lit, used, EXT, lane))) return false; }
@@ -442,10 +448,12 @@ __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t l
     if (longl || longd) {
         WSYNC();
 #pragma unroll
-        for (int k = 0; k < 5; ++k) if (ll[k]) place_long<LB, 0>(s.lit, s.ext, (uint32_t)lane + 64u * k, ll[k], lcode[k]);
-        if (!stub && dl) place_long<DB, 1>(s.dist, s.ext, (uint32_t)lane, dl, dcode);
+        for (int k = 0; k < 5; ++k) if (LL(k) > (uint32_t)LB) place_long<LB, 0>(s.lit, s.ext, (uint32_t)lane + 64u * k, LL(k), s.h.codes[k][lane]);
+        if (!stub && dl > (uint32_t)DB) place_long<DB, 1>(s.dist, s.ext, (uint32_t)lane, dl, s.h.codes[5][lane]);
         WSYNC();
     }
+#undef LL
+#undef DL
     return true;
 }
 

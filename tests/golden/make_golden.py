@@ -54,8 +54,9 @@ def main():
 
     # encoder goldens: swift-png's own committed level-9 outputs (Tests/Outputs, written by
     # PNGCompressionTests/Compression.swift:56) next to the inputs they were made from
-    # (Tests/Baselines).  All 28 pairs are digested; five small pairs are copied so that the GPU
-    # box can run the same check without the reference checkout.
+    # (Tests/Baselines).  All 28 inputs are copied (5 MB) and all 28 outputs digested, so that the GPU box --
+    # which has no reference checkout -- runs the device's graph search on every one of them, the 16-bit
+    # photographic ones included; five small outputs are copied too, for a byte-wise diff when a digest fails.
     enc = HERE / "encode"
     enc.mkdir(exist_ok=True)
     keep = {"indexed8-color-nonphotographic", "v8-monochrome-nonphotographic", "va8-monochrome-nonphotographic",
@@ -64,8 +65,8 @@ def main():
     for f in sorted((REFERENCE / "Tests" / "Baselines").glob("*.png")):
         gold = parse_png((REFERENCE / "Tests" / "Outputs" / f.name).read_bytes())
         digests[f.stem] = {"idat_sha256": hashlib.sha256(gold.idat).hexdigest(), "idat_len": len(gold.idat)}
+        shutil.copyfile(f, enc / (f.stem + ".baseline.png"))
         if f.stem in keep:
-            shutil.copyfile(f, enc / (f.stem + ".baseline.png"))
             shutil.copyfile(REFERENCE / "Tests" / "Outputs" / f.name, enc / (f.stem + ".swiftpng9.png"))
     (HERE / "encode.json").write_text(json.dumps(digests, indent=1, sort_keys=True) + "\n")
     print(len(digests), "encoder goldens digested,", len(keep), "copied")

@@ -1,4 +1,4 @@
-"""Code-generation guards for the inflate kernel (no GPU needed: hipcc cross-compiles gfx950).
+"""Code-generation guards for the hot kernels (no GPU needed: hipcc cross-compiles gfx950).
 
 The kernel's speed depends on properties the source cannot express and a refactor can silently
 lose (profiles/r01_unfilter_tuning.md): four workgroups of 256 threads per CU (LDS <= 40 KiB), no
@@ -52,3 +52,62 @@ def test_inflate_walk_is_straight_line(inflate_asm):
     # the chain walk: eight v_readlane hops and the mask updates in one block, no SALU between hops
     m = re.search(r"(v_readlane_b32 s\d+, v\d+, s\d+\n\s+v_readlane_b32 s\d+, v\d+, s\d+\n\s+s_nop 2\n\s+){3}", inflate_asm)
     assert m, "the double-hop walk was reordered or split"
+
+
+# ---- the kernels the decode step spends its time in: occupancy is set by LDS and registers ------
+def _kernels(name):
+    if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
+        pytest.skip("hipcc not available")
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(ROOT, "swift_png_amd", "csrc", name + ".hip")
+        out = os.path.join(tmp, name + ".s")
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out, src],
+                       check=True, capture_output=True, timeout=900)
+        asm = open(out).read()
+    table = {}
+    for blk in re.split(r"\n  - ", asm[asm.index("amdhsa.kernels:"):])[1:]:
+        def get(key, blk=blk):
+            m = re.search(r"\." + key + r":\s+(\S+)", blk)
+            return m.group(1) if m else "0"
+        table[get("name")] = {k: int(get(k)) for k in ("group_segment_fixed_size", "private_segment_fixed_size", "vgpr_count",
+                                                       "vgpr_spill_count", "max_flat_workgroup_size")}
+    return asm, table
+
+
+def _one(table, fragment):
+    hits = [v for k, v in table.items() if fragment in k]
+    assert len(hits) == 1, (fragment, list(table))
+    return hits[0]
+
+
+def test_pipeline_kernel_resources():
+    asm, table = _kernels("pinflate2")
+    dec = _one(table, "pinf2_decode_kernel")
+    assert dec["group_segment_fixed_size"] <= 11264          # 14 one-wave workgroups per CU (22 x 512-byte LDS granules)
+    assert dec["vgpr_count"] <= 128                          # >= 4 waves per SIMD
+    assert dec["private_segment_fixed_size"] <= 32 and dec["vgpr_spill_count"] <= 6     # (kernel-lifetime values only)
+    res = _one(table, "pinf2_resolve_kernel")
+    assert res["group_segment_fixed_size"] <= 65536          # (static LDS) and two 512-thread workgroups per CU
+    assert res["vgpr_count"] <= 128 and res["private_segment_fixed_size"] == 0 and res["max_flat_workgroup_size"] == 512
+    find = _one(table, "pinf2_find_kernel")
+    assert find["private_segment_fixed_size"] == 0 and find["group_segment_fixed_size"] <= 16384
+    # LDS and global memory are reached with their own instructions
+    assert len(re.findall(r"^\s+flat_(load|store)", asm, re.M)) <= 8
+
+
+def test_unfilter_kernel_resources():
+    _, table = _kernels("unfilter")
+    k4 = [v for k, v in table.items() if "unfilter_kernel" in k]
+    assert k4
+    for v in k4:
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0
+        assert v["group_segment_fixed_size"] <= 81920        # >= 2 workgroups per CU (LDS tiles set the occupancy)
+
+
+def test_deflate_kernel_resources():
+    _, table = _kernels("deflate")
+    full = [v for k, v in table.items() if "deflate_full_kernel" in k]
+    assert full
+    for v in full:
+        assert v["private_segment_fixed_size"] <= 64 and v["vgpr_spill_count"] <= 10     # (40 bytes today, outside the passes' inner loops)
+        assert v["group_segment_fixed_size"] <= 65536

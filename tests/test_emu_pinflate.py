@@ -1,0 +1,112 @@
+"""The kernels of csrc/pinflate2.hip (find -> decode -> scan -> resolve), run on the CPU by the wave emulator of tools/emu
+(one fiber per GPU thread; wave builtins are rendezvous points) and compared with zlib's output.  The build container has
+no GPU: this is how the pipeline's LOGIC -- token chains, merges, page bookkeeping, replay windows, pointer jumping -- is
+checked before a GPU minute is spent, and kept checked.  Timing, bank conflicts and memory ordering are not modelled; the
+`-m gpu` tests remain the parity tests proper."""
+import os
+import shutil
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    out = tmp_path_factory.mktemp("emu") / "emu_pinflate2"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DSPNG_EMU", "-I" + os.path.join(ROOT, "tools", "emu"), "-x", "c++", "-fpermissive",
+                    "-Wno-attributes", "-w", "-o", str(out), os.path.join(ROOT, "tools", "emu", "emu_pinflate2.cpp")],
+                   check=True, capture_output=True, timeout=600)
+    return out
+
+
+def scanlines(seed, n):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(-3, 4, n).astype(np.int16)
+    a[rng.random(n) < 0.6] = 0
+    rows = a.astype(np.uint8).reshape(-1, 512)
+    rows[::13] = rng.integers(0, 256, (len(rows[::13]), 512), dtype=np.uint8)
+    rows[::4, 0] = 1
+    return rows.tobytes()
+
+
+def deflate(data, level=6, wbits=15, strategy=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, wbits, 9, strategy)
+    return c.compress(data) + c.flush()
+
+
+def cases():
+    rng = np.random.default_rng(3)
+    rows = scanlines(1, 96 * 512)
+    yield "zlib6", deflate(rows, 6), rows, 0
+    yield "zlib1", deflate(rows, 1), rows, 0                        # (long unmerged chains: a lane replays over several windows)
+    yield "raw9", deflate(rows, 9, -15), rows, 1
+    yield "fixed", deflate(rows[:20000], 6, 15, zlib.Z_FIXED), rows[:20000], 0
+    noise = rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
+    yield "stored", deflate(noise, 0), noise, 0
+    yield "huffonly", deflate(noise, 6, 15, zlib.Z_HUFFMAN_ONLY), noise, 0
+    yield "zeros", deflate(bytes(200000), 6), bytes(200000), 0     # one-bit codes: short subsequences
+    yield "period4", deflate(bytes([1, 2, 3, 255]) * 20000, 9), bytes([1, 2, 3, 255]) * 20000, 0
+    co = zlib.compressobj(6)
+    parts = []
+    for i in range(0, len(rows), 9000):
+        parts.append(co.compress(rows[i:i + 9000]))
+        parts.append(co.flush(zlib.Z_FULL_FLUSH if (i // 9000) % 2 else zlib.Z_SYNC_FLUSH))
+    yield "flushes", b"".join(parts) + co.flush(), rows, 0
+
+
+CASES = list(cases())
+
+
+@pytest.mark.parametrize("segment", [1 << 20, 4096])
+@pytest.mark.parametrize("name", [c[0] for c in CASES])
+def test_emulated_pipeline_matches_zlib(emu, tmp_path, name, segment):
+    _, z, raw, fmt = next(c for c in CASES if c[0] == name)
+    assert zlib.decompress(z, -15 if fmt else 15) == raw
+    (tmp_path / "z").write_bytes(z)
+    (tmp_path / "raw").write_bytes(raw)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), str(fmt), str(segment)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (name, r.stdout[-300:], r.stderr[-300:])
+    assert r.stdout.startswith("ok:")
+
+
+def test_emulated_pipeline_swiftpng_shaped_stream(emu, tmp_path):
+    """the oracle's own level-6 deflate: a dynamic block every <= 2047 tokens, as PNG.Image.compress makes them"""
+    import pnghelp as ph
+    rows = scanlines(2, 64 * 512)
+    z = ph.orc_deflate(rows, 6)
+    assert zlib.decompress(z) == rows
+    (tmp_path / "z").write_bytes(z)
+    (tmp_path / "raw").write_bytes(rows)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", "8192"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-300:])
+
+
+def test_emulated_pipeline_with_a_small_page_table(emu, tmp_path):
+    """stored data hides every later segment start: the first segment decodes the whole stream and borrows the page-table
+    entries of the start-less segments behind it"""
+    rng = np.random.default_rng(9)
+    noise = rng.integers(0, 256, 150000, dtype=np.uint8).tobytes()
+    z = deflate(noise, 0)
+    (tmp_path / "z").write_bytes(z)
+    (tmp_path / "raw").write_bytes(noise)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", "8192"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, EMU_PTCAP="2"))
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-300:])
+
+
+def test_emulated_pipeline_declines_a_corrupt_stream(emu, tmp_path):
+    """a flipped bit in the middle: the pipeline must not report success (exit 3 = left to the serial kernel)"""
+    rows = scanlines(5, 32 * 512)
+    z = bytearray(deflate(rows, 6))
+    z[len(z) // 2] ^= 0x10
+    (tmp_path / "z").write_bytes(bytes(z))
+    (tmp_path / "raw").write_bytes(rows)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", "1048576"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stdout[-300:])

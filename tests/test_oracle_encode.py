@@ -31,15 +31,47 @@ def _encode9(png, storage):
 
 @pytest.mark.parametrize("name", LOCAL)
 def test_level9_stream_is_bit_exact_local(name):
+    """All 28 inputs of Tests/Baselines travel with the repo; the stream the oracle makes of each must have the digest of
+    the IDAT data swift-png committed under Tests/Outputs (and equal it byte for byte where that file was copied too)."""
     src = ph.parse_png((ph.GOLDEN / "encode" / (name + ".baseline.png")).read_bytes())
-    gold = ph.parse_png((ph.GOLDEN / "encode" / (name + ".swiftpng9.png")).read_bytes())
     st, storage, _ = ph.orc_decode(src)
     assert st == 0
     mine = _encode9(src, storage)
-    assert mine == gold.idat
-    assert hashlib.sha256(mine).hexdigest() == ENC[name]["idat_sha256"]
-    # and swift-png's output decodes back to the same raster (Compression.swift:56-84)
-    assert (ph.orc_decode(gold)[1] == storage).all()
+    assert len(mine) == ENC[name]["idat_len"] and hashlib.sha256(mine).hexdigest() == ENC[name]["idat_sha256"]
+    out = ph.GOLDEN / "encode" / (name + ".swiftpng9.png")
+    if out.exists():
+        gold = ph.parse_png(out.read_bytes())
+        assert mine == gold.idat
+        # and swift-png's output decodes back to the same raster (Compression.swift:56-84)
+        assert (ph.orc_decode(gold)[1] == storage).all()
+
+
+def test_all_reference_level9_goldens_travel():
+    assert len(LOCAL) == 28 == len(ENC)
+
+
+def test_stored_tail_departure_of_the_row_pushed_reference():
+    """DESIGN section 1 (iii).  PNG.Encoder pushes one scanline at a time and finishes with push([], last: true);
+    when the last non-final compress() leaves one or two bytes queued, compressBlocks(final:) takes the stored-tail
+    path and drops the pending terms (LZ77.DeflatorBuffers.Stream.swift:45-60): the reference's own stream is corrupt.
+    A flat 1033 x 4 RGBA8 raster at level 6 is such an input (rows of 4133 bytes: every push compresses).  The
+    row-pushed restatement reproduces the bug; the one-shot stream -- what the device emits (test_gpu_decode.py::
+    test_encode_departs_from_the_stored_tail_bug) -- is the correct one."""
+    w, h = 1033, 4
+    storage = np.tile(np.array([9, 200, 31, 255], np.uint8), w * h)
+    rows = ph.orc_filter(storage, w, h, 8, 4, False)
+    lib = ph.oracle()
+    cap = len(storage) * 2 + 4096
+    dst = np.empty(cap, np.uint8)
+    wr = ctypes.c_size_t(0)
+    assert lib.orc_encode(ph._ptr(storage), w, h, 8, 4, 0, 0, 6, ph._ptr(dst), cap, ctypes.byref(wr)) == 0
+    pushed = dst[:wr.value].tobytes()
+    oneshot = ph.orc_deflate(bytes(rows), 6)
+    assert pushed != oneshot and len(pushed) < len(oneshot)
+    assert zlib.decompress(oneshot) == bytes(rows)
+    with pytest.raises(zlib.error):
+        zlib.decompress(pushed)
+    assert ph.orc_inflate(pushed, 0, cap=len(rows) + 16)[0] != 0          # (the pinned inflate oracle rejects it as well)
 
 
 @pytest.mark.skipif(not ph.have_reference(), reason="reference checkout not mounted")
