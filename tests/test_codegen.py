@@ -110,4 +110,4 @@ def test_deflate_kernel_resources():
     assert full
     for v in full:
         assert v["private_segment_fixed_size"] <= 64 and v["vgpr_spill_count"] <= 10     # (40 bytes today, outside the passes' inner loops)
-        assert v["group_segment_fixed_size"] <= 65536
+        assert v["group_segment_fixed_size"] <= 81920           # (the helper-wave form: 76 KiB, one workgroup of four waves per stream)
