@@ -41,7 +41,8 @@ W = H = 4096
 DEPTH, CHANNELS = 8, 4
 MPIX = W * H / 1e6
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-STAGES = ("pinf_find", "pinf_count", "pinf_emit", "pinf_resolve", "inflate", "unfilter")
+STAGES = ("pinf_find", "pinf_decode", "pinf_resolve", "inflate", "unfilter")
+PMC_FILE = "r03_pmc_traffic.json"      # rocprofv3 --pmc passes of this very workload (tools/final_run.sh), committed
 
 
 def build_inputs(session, unique: int, threads: int, encoder: str):
@@ -64,42 +65,42 @@ def build_inputs(session, unique: int, threads: int, encoder: str):
 
 
 def cpu_baseline(streams, images, rows, cores: int):
-    """The CPU oracle (restatement of swift-png's CPU path: inflate + defilter + assign) on a bounded
-    sample of the same streams: all host cores (one image per thread), one core, and -- as a sanity anchor
-    -- zlib's inflate followed by the oracle's defilter on one core (the reference publishes
-    swift-png = 1.35 x libpng decode time).  Test infrastructure used as a reported baseline only."""
+    """The CPU oracle (restatement of swift-png's CPU path: inflate + defilter + assign) on a bounded sample of the
+    same streams: all host cores -- one worker PROCESS per core, library loaded and buffers touched before the clock
+    starts (bench_cpu.py, a fresh interpreter without torch) --, one core, and -- as a sanity anchor -- zlib's inflate
+    followed by the oracle's defilter on one core (the reference publishes swift-png = 1.35 x libpng decode time).
+    Test infrastructure used as a reported baseline only."""
+    import shutil
+    import tempfile
     sys.path.insert(0, str(ROOT / "tests"))
-    import numpy as np
     import pnghelp as ph
-    lib = ph.oracle()
-
-    def one(k):
-        z = streams[k % len(streams)]
-        src = np.frombuffer(z, dtype=np.uint8)
-        storage = np.empty(W * H * 4, dtype=np.uint8)
-        aux = (ctypes.c_uint64 * 2)()
-        st = lib.orc_decode(ph._ptr(src), len(z), 0, W, H, DEPTH, CHANNELS, 0, ph._ptr(storage), aux)
-        return st == 0 and bytes(storage[:4096]) == images[k % len(streams)].reshape(-1)[:4096].tobytes()
-
-    sample = max(16, cores)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as pool:
-        ok = list(pool.map(one, range(sample)))
-    dt = time.perf_counter() - t0
-    assert all(ok)
-    t0 = time.perf_counter()
-    assert one(0)
-    dt1 = time.perf_counter() - t0
+    tmp = tempfile.mkdtemp(prefix="spng_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        for k, z in enumerate(streams[:8]):
+            (Path(tmp) / f"z{k}").write_bytes(z)
+        tasks = max(64, 4 * cores)
+        out = subprocess.run([sys.executable, str(ROOT / "bench_cpu.py"), "decode", tmp, str(cores), str(tasks), str(W), str(H)],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-400:]
+        allc = json.loads(out.stdout.strip().splitlines()[-1])
+        out = subprocess.run([sys.executable, str(ROOT / "bench_cpu.py"), "decode", tmp, "1", "2", str(W), str(H)],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-400:]
+        one = json.loads(out.stdout.strip().splitlines()[-1])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     t0 = time.perf_counter()
     raw = zlib.decompress(streams[0])
     st, storage = ph.orc_unfilter(raw, W, H, DEPTH, CHANNELS, False)
     dtz = time.perf_counter() - t0
-    assert st == 0 and raw == rows[0]
-    return {"value": round(sample * MPIX / dt, 1), "unit": "MPixels/s", "cores": cores, "kind": "port",
-            "sample": f"{sample} of the same 4096x4096 RGBA8 level-6 streams, one image per thread, oracle "
-                      f"inflate+defilter+assign, {dt:.1f} s wall",
-            "one_core": {"value": round(MPIX / dt1, 2), "unit": "MPixels/s", "cores": 1,
-                         "sample": f"1 image, {dt1:.1f} s"},
+    assert st == 0 and raw == rows[0] and bytes(storage[:4096]) == images[0].reshape(-1)[:4096].tobytes()
+    v_all, v_one = tasks * MPIX / allc["wall_s"], 2 * MPIX / one["wall_s"]
+    return {"value": round(v_all, 1), "unit": "MPixels/s", "cores": cores, "kind": "port",
+            "sample": f"{tasks} decodes of the same 4096x4096 RGBA8 level-6 streams on {cores} worker processes (one per core, "
+                      f"buffers touched before the clock), oracle inflate+defilter+assign, {allc['wall_s']:.1f} s wall, "
+                      f"{allc['task_s']:.2f} s per image inside a worker",
+            "scaling_vs_one_core": round(v_all / v_one / cores, 3),
+            "one_core": {"value": round(v_one, 2), "unit": "MPixels/s", "cores": 1, "sample": f"2 images, {one['wall_s']:.1f} s"},
             "zlib_anchor": {"value": round(MPIX / dtz, 2), "unit": "MPixels/s", "cores": 1,
                             "sample": f"zlib 1.2.11 inflate + oracle defilter of 1 image, {dtz:.1f} s"}}
 
@@ -109,7 +110,7 @@ def pmc_traffic(kind: str, images: int, unique: int):
     (profiles/r02_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
     MI355X_MICROARCH.md prescribes); None when the file does not describe this configuration."""
     try:
-        pmc = json.loads((ROOT / "profiles" / "r02_pmc_traffic.json").read_text())
+        pmc = json.loads((ROOT / "profiles" / PMC_FILE).read_text())
         cfg = pmc["configs"][kind]
         if cfg["images"] != images or cfg["unique"] != unique:
             return {}
@@ -253,7 +254,7 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
     job.d_rows = job.d_out = job.dres = None                  # (the slabs go back to the allocator before the next workload)
     torch.cuda.empty_cache()
     per_step = {k: prof[k][0] / args.steps for k in STAGES}
-    alg = {"pinf_find": 0, "pinf_count": total_c, "pinf_emit": total_c, "pinf_resolve": n * U,
+    alg = {"pinf_find": 0, "pinf_decode": total_c, "pinf_resolve": n * U,
            "inflate": 0 if fast == n else total_c + n * U, "unfilter": n * (U + S)}
     return {"dt": dt, "n": n, "weak": weak, "per_step_ms": per_step, "alg": alg, "total_c": total_c, "U": U, "S": S,
             "fast": fast, "gather": bool(do_gather), "gather_error": gather_error, "hi_lo": hi - lo,
@@ -276,6 +277,149 @@ def kernel_report(m, traffic):
     return rep
 
 
+# ---- the other BASELINE configs and the neighbours of the path, reported in the same line --------------------------
+def copy_ceiling(torch, s):
+    """Measured device copy next to the 8 TB/s spec peak: read + write bytes per second of a
+    plain 16-bytes-per-lane HBM-to-HBM copy of 8 GiB."""
+    n = 8 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=s.tdev)
+    b = torch.empty(n, dtype=torch.uint8, device=s.tdev)
+    a.zero_(); b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    del a, b
+    torch.cuda.empty_cache()
+    return {"gbps": round(2 * n / (ms * 1e-3) / 1e9, 1), "ms": round(ms, 3), "bytes": 2 * n,
+            "how": "torch uint8 tensor copy of 8 GiB, read + write counted, HIP events, 5 repeats"}
+
+
+def parallel_zlib(rows: bytes, level: int, threads: int) -> bytes:
+    """A zlib stream of `rows` made of independently compressed slices (raw DEFLATE, each but the last ended with a sync
+    flush), so that half a gigabyte of scanlines is compressed on all host cores in a few seconds."""
+    n = len(rows)
+    k = max(1, min(threads, n >> 22))
+    cuts = [n * i // k for i in range(k + 1)]
+
+    def one(i):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        return co.compress(rows[cuts[i]:cuts[i + 1]]) + co.flush(zlib.Z_FINISH if i == k - 1 else zlib.Z_SYNC_FLUSH)
+
+    with ThreadPoolExecutor(threads) as pool:
+        parts = list(pool.map(one, range(k)))
+    return b"\x78\x9c" + b"".join(parts) + zlib.adler32(rows).to_bytes(4, "big")
+
+
+def run_config5(torch, spng, s, steps):
+    """BASELINE configs[4]: one 8192 x 8192 RGBA16 Adam7 image (536,886,272 inflated bytes, seven sub-images, one
+    stream), level 6, decoded on one GPU: inflate pipeline + per-pass unfilter + scatter."""
+    import numpy as np
+    from swift_png_amd import synth
+    w = h = 8192
+    tile = synth.image(11, 2048, 2048, 4, 16)                       # (rows of 2048 * 8 bytes)
+    img = np.tile(tile, (4, 4))
+    raw = img.tobytes()
+    rows = s.filter(raw, w, h, 16, 4, True)
+    z = parallel_zlib(rows, 6, min(os.cpu_count() or 1, 64))
+    d_idat, d_rows, d_out = s.to_device(z), s.empty(len(rows) + 4096), s.empty(len(raw))
+    desc = s.image_desc(d_idat, d_rows, d_out, w, h, 16, 4, True, 0, rows_cap=len(rows) + 4096)
+    s.decode_batch([desc])
+    torch.cuda.synchronize()
+    names = ("pinf_find", "pinf_decode", "pinf_resolve", "inflate", "unfilter", "scatter")
+    s.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = s.decode_batch([desc])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    prof = {k: round(s.profile_get(getattr(spng, "K_" + k.upper()))[0] / steps, 3) for k in names}
+    s.profile(False)
+    assert res[0].status == 0 and res[0].written == len(rows)
+    want = s.to_device(raw)
+    assert torch.equal(d_out, want), "config 5: raster differs"
+    alg = len(z) + 2 * len(rows) + len(raw)                           # inflate: C + U; unfilter (+ scatter): U + S
+    return {"workload": "1 x 8192x8192 RGBA16 Adam7 PNG decode, level 6 (host zlib, 64 slices), one stream; BASELINE configs[4]",
+            "ms": round(dt * 1e3, 2), "mpixels_per_s": round(w * h / 1e6 / dt, 1), "compressed_bytes": len(z),
+            "inflated_bytes": len(rows), "algorithmic_bytes": alg, "gbps": round(alg / dt / 1e9, 2),
+            "frac_of_hbm_peak": round(alg / dt / 1e9 / HBM_PEAK_GBPS, 5), "pipeline": res[0].reserved == 1,
+            "kernels_ms": prof, "bit_exact": True}
+
+
+def run_file_to_pixels(torch, spng, s, streams, images, n, steps):
+    """File -> pixels, as the reference times it (Benchmarks/Decompression/Swift/Main.swift:103-109: decompress +
+    unpack(as: RGBA<UInt8>)): spng_lex_batch (chunk walk, CRC-32 of every chunk, IDAT assembly) -> spng_decode_batch ->
+    spng_unpack_batch over n PNG files resident in HBM (the level-6 streams of the headline, cut into 64 KiB IDATs)."""
+    import struct
+    U = spng.inflated_size(W, H, DEPTH, CHANNELS, False)
+    S = spng.storage_size(W, H, DEPTH, CHANNELS)
+
+    def png_file(z):
+        def chunk(t, body):
+            return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+        out = [bytes([137, 80, 78, 71, 13, 10, 26, 10]), chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 6, 0, 0, 0))]
+        out += [chunk(b"IDAT", z[i:i + 65536]) for i in range(0, len(z), 65536)]
+        out.append(chunk(b"IEND", b""))
+        return b"".join(out)
+
+    files = [png_file(z) for z in streams]
+    d_files = [s.to_device(f) for f in files]
+    unique = len(files)
+    cap = max(len(f) for f in files)
+    d_idat = torch.empty(n * cap, dtype=torch.uint8, device=s.tdev)
+    d_rows = torch.empty(n * (U + 4096), dtype=torch.uint8, device=s.tdev)
+    d_sto = torch.empty(n * S, dtype=torch.uint8, device=s.tdev)
+    d_rgba = torch.empty(n * S, dtype=torch.uint8, device=s.tdev)
+    fdescs = (spng.FileDesc * n)()
+    for j in range(n):
+        f = d_files[j % unique]
+        fdescs[j] = spng.FileDesc(f.data_ptr(), f.numel(), d_idat.data_ptr() + j * cap, cap)
+    infos = (spng.Lexed * n)()
+    idescs = (spng.ImageDesc * n)()
+    udescs = (spng.UnpackDesc * n)()
+    dres = s.empty(n * ctypes.sizeof(spng.Result))
+
+    def step(first):
+        assert s.lib.spng_lex_batch(s.ctx, fdescs, n, None, infos) == 0       # (the IHDR fields come back to the host)
+        if first:
+            for j in range(n):
+                r = infos[j]
+                assert r.status == 0 and (r.width, r.height, r.depth, r.color, r.interlace) == (W, H, 8, 6, 0)
+                idescs[j] = spng.ImageDesc(d_idat.data_ptr() + j * cap, r.idat_len, d_rows.data_ptr() + j * (U + 4096), U + 4096,
+                                           d_sto.data_ptr() + j * S, W, H, 8, 4, 0, 0, 0)
+                udescs[j] = spng.UnpackDesc(d_sto.data_ptr() + j * S, d_rgba.data_ptr() + j * S, None, W, H, 0, (ctypes.c_uint16 * 3)(),
+                                            8, 4, 0, 0, 0, 8)
+        assert s.lib.spng_decode_batch(s.ctx, idescs, n, ctypes.c_void_p(dres.data_ptr()), None) == 0
+        assert s.lib.spng_unpack_batch(s.ctx, udescs, n) == 0
+
+    step(True)
+    torch.cuda.synchronize()
+    s.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    lex_ms, unp_ms = s.profile_get(spng.K_LEX)[0] / steps, s.profile_get(spng.K_UNPACK)[0] / steps
+    s.profile(False)
+    ref = [s.to_device(img.reshape(-1)) for img in images]
+    for j in range(0, n, max(1, n // 16)):
+        assert torch.equal(d_rgba[j * S:(j + 1) * S], ref[j % unique]), f"file {j}: RGBA8 differs from its source raster"
+    total_f = sum(len(files[j % unique]) for j in range(n))
+    return {"workload": f"{n} PNG files (4096x4096 RGBA8, level 6, 64 KiB IDATs) in HBM -> lex + CRC-32 -> inflate -> unfilter -> "
+                        f"RGBA<UInt8>", "ms_per_step": round(dt * 1e3, 2), "mpixels_per_s": round(n * MPIX / dt, 1),
+            "kernels": {"lex": {"ms_per_step": round(lex_ms, 3), "algorithmic_bytes": total_f,
+                                "gbps": round(total_f / (lex_ms * 1e-3) / 1e9, 2) if lex_ms else None},
+                        "unpack": {"ms_per_step": round(unp_ms, 3), "algorithmic_bytes": 2 * n * S,
+                                   "gbps": round(2 * n * S / (unp_ms * 1e-3) / 1e9, 2) if unp_ms else None,
+                                   "frac_of_hbm_peak": round(2 * n * S / (unp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if unp_ms else None}},
+            "bit_exact": True}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -295,6 +439,8 @@ def main():
     ap.add_argument("--level", type=int, default=9, help="encode mode: DEFLATE level (BASELINE configs[3]: 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="decode mode: skip the copy ceiling, configs[3] / configs[4] and file -> pixels legs")
+    ap.add_argument("--encode-images", type=int, default=64, help="decode mode: images of the bounded configs[3] leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -339,12 +485,14 @@ def main():
         kernels = kernel_report(m, pmc_traffic(args.streams, args.images, args.unique) if world == 1 else {})
         dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
         d = kernels[dominant]
-        infl_ms = sum(m["per_step_ms"][k] for k in ("pinf_find", "pinf_count", "pinf_emit", "pinf_resolve", "inflate"))
+        infl_ms = sum(m["per_step_ms"][k] for k in ("pinf_find", "pinf_decode", "pinf_resolve", "inflate"))
         out = {
             "metric": "decoded_mpixels_per_s",
             "value": round(args.images * (world if weak else 1) * MPIX / (m["dt"] / args.steps), 1),
             "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak" if weak else "strong",
+            "ms_per_step": round(ms, 3), "higher_is_better": True,
+            # (N = 1 is the first point of the strong-scaling series the driver assembles: the same 1024 images)
+            "scaling": "weak" if (weak and world > 1) else "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.images} x 4096x4096 RGBA8 PNG decode (inflate+unfilter), mixed filters "
                                    f"(reference heuristic), level 6 ({args.streams} encoder); BASELINE configs[1]"
@@ -360,7 +508,9 @@ def main():
                                  "gbps": round((m["total_c"] + n * m["U"]) / (infl_ms * 1e-3) / 1e9, 2)},
             "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": d.get("gbps"),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d.get("frac_of_hbm_peak"),
-                         "traffic": d.get("traffic"), "ms_per_launch": d["ms_per_step"]},
+                         "traffic": d.get("traffic"), "ms_per_launch": d["ms_per_step"],
+                         **({"traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                               "workload, not measured in this run)"} if d.get("traffic") else {})},
             "kernels": kernels,
         }
         if other:
@@ -369,7 +519,7 @@ def main():
             out[alt + "_streams"] = other[1]
         elif other:
             ko = kernel_report(mo, pmc_traffic(alt, args.images, args.swiftpng_unique))
-            io = sum(mo["per_step_ms"][k] for k in ("pinf_find", "pinf_count", "pinf_emit", "pinf_resolve", "inflate"))
+            io = sum(mo["per_step_ms"][k] for k in ("pinf_find", "pinf_decode", "pinf_resolve", "inflate"))
             out[alt + "_streams"] = {
                 "value": round(args.images * MPIX / (mo["dt"] / args.steps), 1), "unit": "MPixels/s",
                 "ms_per_step": round(mo["dt"] / args.steps * 1e3, 3), "unique_images": args.swiftpng_unique,
@@ -377,6 +527,26 @@ def main():
                 "inflate_gbps": round(mo["n"] * mo["U"] / (io * 1e-3) / 1e9, 2), "kernels": ko}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m["streams"], m["images"], m["rows"], cores)
+        if world == 1 and not args.no_extras:
+            # the other BASELINE configs and the path's neighbours, each on a bounded workload (never lose the headline to one)
+            def leg(name, fn):
+                try:
+                    torch.cuda.empty_cache()
+                    out[name] = fn()
+                except Exception as exc:                       # noqa: BLE001
+                    out[name] = {"error": repr(exc)[:300]}
+            leg("copy_ceiling", lambda: copy_ceiling(torch, s))
+            if isinstance(out["copy_ceiling"].get("gbps"), float) and "unfilter" in kernels:
+                kernels["unfilter"]["frac_of_copy_ceiling"] = round(kernels["unfilter"]["gbps"] / out["copy_ceiling"]["gbps"], 4)
+            leg("config5", lambda: run_config5(torch, spng, s, 3))
+            leg("file_to_pixels", lambda: run_file_to_pixels(torch, spng, s, m["streams"][:8], m["images"][:8], min(256, args.images), 2))
+
+            def enc():
+                from bench_encode import run_encode
+                ea = argparse.Namespace(**vars(args))
+                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), 1, 1, args.no_cpu_baseline
+                return run_encode(ea, torch, dist, spng, s, rank, world)
+            leg("encode", enc)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -9,7 +9,9 @@ committed level-9 outputs)."""
 from __future__ import annotations
 
 import ctypes
+import json
 import os
+import subprocess
 import sys
 import time
 import zlib
@@ -22,6 +24,24 @@ W = H = 4096
 DEPTH, CHANNELS = 8, 4
 MPIX = W * H / 1e6
 HBM_PEAK_GBPS = 8000.0
+
+
+def encode_cpu_all_cores(rows: bytes, level: int, cores: int):
+    """all host cores, the oracle's deflate at `level` on 1 MiB slices of the scanlines (one worker process per core)"""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="spng_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        (Path(tmp) / "rows").write_bytes(rows[:64 << 20])
+        out = subprocess.run([sys.executable, str(ROOT / "bench_cpu.py"), "deflate", str(Path(tmp) / "rows"), str(cores), str(level),
+                              str(1 << 20)], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-400:]
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": round(r["tasks"] * r["slice"] / 4 / 1e6 / r["wall_s"], 2), "unit": "MPixels/s", "cores": cores, "kind": "port",
+            "sample": f"{r['tasks']} slices of 1 MiB of the same scanlines, oracle deflate level {level}, one worker process per core, "
+                      f"{r['wall_s']:.1f} s wall, {r['task_s']:.2f} s per slice (filter excluded)"}
 
 
 def run_encode(args, torch, dist, spng, s, rank, world):
@@ -121,4 +141,10 @@ def run_encode(args, torch, dist, spng, s, rank, world):
                                "sample": f"oracle deflate level {args.level} of the first {len(sample)} scanline bytes of "
                                          f"stream 0 (filter excluded), {dtc:.1f} s; the device stream of the same bytes is "
                                          f"identical"}
+        try:
+            allc = encode_cpu_all_cores(rows, args.level, os.cpu_count() or 1)
+            allc["one_core"] = out["cpu_baseline"]
+            out["cpu_baseline"] = allc
+        except Exception as exc:                                   # noqa: BLE001
+            out["cpu_baseline"]["all_cores_error"] = repr(exc)[:200]
     return out

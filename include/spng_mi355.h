@@ -128,22 +128,20 @@ int32_t spng_sync(spng_ctx *ctx);                               /* hipStreamSync
 enum { SPNG_CFG_INFLATE_MODE = 0,   /* SPNG_INFLATE_AUTO: parallel pipeline, serial kernel for what it declines;
                                        SPNG_INFLATE_SERIAL: serial kernel only */
        SPNG_CFG_SEGMENT_BYTES = 1,  /* parallel inflate: nominal segment length in compressed bytes */
-       SPNG_CFG_TOKEN_BYTES = 2,    /* parallel inflate: size limit of the token buffer in bytes */
+       SPNG_CFG_TOKEN_BYTES = 2,    /* parallel inflate: size limit of the token page pool in bytes */
        SPNG_CFG_UNFILTER_PIECE_ROWS = 3,   /* unfilter: rows per piece a scanline chain is cut into */
        SPNG_CFG_COUNT = 4 };
-enum { SPNG_INFLATE_AUTO = 0, SPNG_INFLATE_SERIAL = 1,
-       SPNG_INFLATE_LEGACY = 2 };   /* round 2's count / emit / resolve kernels (kept for comparison runs) */
+enum { SPNG_INFLATE_AUTO = 0, SPNG_INFLATE_SERIAL = 1 };
 int32_t spng_configure(spng_ctx *ctx, int key, int64_t value);
 
 /* Per-kernel timing with HIP events recorded on the context's stream around every launch. */
 enum { SPNG_K_INFLATE = 0,          /* the serial inflate kernel (streams the parallel pipeline left to it) */
        SPNG_K_UNFILTER = 1, SPNG_K_SCATTER = 2, SPNG_K_FILTER = 3,
        SPNG_K_DEFLATE = 4, SPNG_K_ADLER = 5,
-       SPNG_K_PINFLATE = 6,         /* the parallel inflate pipeline as a whole: find + count + scan + emit + resolve */
+       SPNG_K_PINFLATE = 6,         /* the parallel inflate pipeline as a whole: find + decode + scan + resolve */
        SPNG_K_UNPACK = 7,
        SPNG_K_LEX = 12,             /* chunk lexing + CRC-32 / IDAT chunk emission */
        SPNG_K_PINF_FIND = 8, SPNG_K_PINF_DECODE = 9, SPNG_K_PINF_RESOLVE = 11,   /* its stages */
-       SPNG_K_PINF_COUNT = 9, SPNG_K_PINF_EMIT = 10,   /* (SPNG_INFLATE_LEGACY: count and emit were two kernels) */
        SPNG_K_COUNT = 16 };
 int32_t spng_profile(spng_ctx *ctx, int enable);                /* enable/disable + reset counters  */
 int32_t spng_profile_get(spng_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);

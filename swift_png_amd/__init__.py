@@ -34,10 +34,10 @@ E_OUTPUT_CAPACITY, E_ARGUMENT, E_DEVICE, E_REFERENCE_UNDEFINED = 64, 65, 66, 67
 FORMAT_ZLIB, FORMAT_IOS, FORMAT_GZIP = 0, 1, 2
 K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER, K_PINFLATE = 0, 1, 2, 3, 4, 5, 6
 K_UNPACK = 7
-K_PINF_FIND, K_PINF_COUNT, K_PINF_EMIT, K_PINF_RESOLVE = 8, 9, 10, 11
-K_PINF_DECODE = 9
+K_LEX = 12
+K_PINF_FIND, K_PINF_DECODE, K_PINF_RESOLVE = 8, 9, 11
 CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES, CFG_UNFILTER_PIECE_ROWS = 0, 1, 2, 3
-INFLATE_AUTO, INFLATE_SERIAL, INFLATE_LEGACY = 0, 1, 2
+INFLATE_AUTO, INFLATE_SERIAL = 0, 1
 
 EXPORTS = [
     "spng_version", "spng_status_string", "spng_last_error_string", "spng_inflated_size",
@@ -76,6 +76,13 @@ class Lexed(ctypes.Structure):
                 ("ios", ctypes.c_uint8), ("pad", ctypes.c_uint8 * 2), ("idat_len", ctypes.c_uint64),
                 ("plte_off", ctypes.c_uint64), ("trns_off", ctypes.c_uint64), ("plte_len", ctypes.c_uint32),
                 ("trns_len", ctypes.c_uint32), ("consumed", ctypes.c_uint64)]
+
+
+class UnpackDesc(ctypes.Structure):
+    _fields_ = [("d_storage", ctypes.c_void_p), ("d_out", ctypes.c_void_p), ("d_palette", ctypes.c_void_p),
+                ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("palette_count", ctypes.c_uint32),
+                ("key", ctypes.c_uint16 * 3), ("depth", ctypes.c_uint8), ("channels", ctypes.c_uint8), ("indexed", ctypes.c_uint8),
+                ("bgr", ctypes.c_uint8), ("has_key", ctypes.c_uint8), ("target", ctypes.c_uint8)]
 
 
 class ChunkingDesc(ctypes.Structure):

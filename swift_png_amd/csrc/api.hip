@@ -73,7 +73,7 @@ struct spng_ctx {
     void *h_ws = nullptr;                 // the slab of the call in progress
     Slab *cur = nullptr;
     void *d_ring = nullptr; size_t ring_cap = 0;     // deflate link rings
-    // parallel inflate (pinflate.hip): chunk-record slab, token buffer, knobs (spng_configure)
+    // parallel inflate (pinflate2.hip): chunk-record slab, token buffer, knobs (spng_configure)
     void *d_graph = nullptr; size_t graph_cap = 0;   // deflate levels >= 8: match graphs
     void *d_log = nullptr;  size_t log_cap = 0;
     void *d_tok = nullptr;  size_t tok_cap = 0;      // bytes
@@ -441,23 +441,21 @@ static int32_t launch_plan(spng_ctx *c, const UnfilterPlan &plan, Arena &a, cons
     return SPNG_DONE;
 }
 
-// ---- inflate stage: the parallel pipeline (pinflate.hip) in front of the serial kernel (inflate.hip) ----
+// ---- inflate stage: the parallel pipeline (pinflate2.hip) in front of the serial kernel (inflate.hip) ----
 struct InflatePlan {
     std::vector<InflateJob> jobs;
     std::vector<PStream> streams;
     std::vector<PSeg> segs;
     size_t log_bytes = 0;
-    uint64_t tok_cap = 0;            // tokens
-    uint32_t passes = 0;
     bool parallel = false;
-    bool legacy = false;             // SPNG_INFLATE_LEGACY: round 2's count / emit / resolve kernels (pinflate.hip)
     // pinflate2: the token pool and the groups of streams that share it, one after the other
     uint32_t pool_pages = 0;
     struct Group { uint32_t s0, s1, g0, g1; };
     std::vector<Group> groups;
     size_t next_at = 0;
     bool gzip = false;               // some stream is SPNG_FORMAT_GZIP: header kernel in front, CRC-32 check behind
-    std::vector<uint64_t> state;     // spng_inflate_resume_batch: {bit, written} per stream (else empty)
+    std::vector<uint64_t> state;     // {bit, written} per stream: spng_inflate_resume_batch's, else the library's own zeros
+    bool internal = true;            // (the latter)
     size_t jobs_at = 0, streams_at = 0, segs_at = 0, done_at = 0, gz_at = 0, gzparts_at = 0, state_at = 0, sumparts_at = 0;
     size_t bytes() const
     {
@@ -479,35 +477,37 @@ struct InflatePlan {
 // gives its stream to the serial kernel.
 static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
 {
+    p.internal = p.state.empty();
+    if (p.internal) p.state.assign(p.jobs.size() * 2, 0);
+    for (auto &j : p.jobs) j.internal = p.internal ? 1 : 0;
     p.parallel = c->cfg[SPNG_CFG_INFLATE_MODE] != SPNG_INFLATE_SERIAL && !p.jobs.empty();
-    p.legacy = c->cfg[SPNG_CFG_INFLATE_MODE] == SPNG_INFLATE_LEGACY;
     for (auto &j : p.jobs) p.gzip = p.gzip || j.format == SPNG_FORMAT_GZIP;
     if (!p.parallel) return SPNG_DONE;
     uint64_t total = 0;
     for (auto &j : p.jobs) total += j.src_len;
     uint64_t seg_bytes = (uint64_t)c->cfg[SPNG_CFG_SEGMENT_BYTES];
     if (!seg_bytes) {
-        // (pinflate2: ~9 rounds of resident waves, so that the last, partly filled one costs little; the search costs 7 ms per 10^4 segments)
-        seg_bytes = total / (p.legacy ? 8192 : 32768);
+        // (~9 rounds of resident waves, so that the last, partly filled one costs little; the search costs 7 ms per 10^4 segments)
+        seg_bytes = total / 32768;
         if (seg_bytes < (256u << 10)) seg_bytes = 256u << 10;
     }
     seg_bytes = (seg_bytes + 255) & ~(uint64_t)255;
     p.streams.resize(p.jobs.size());
     // what the last batch taught about token volume (its page count comes back behind its kernels: when the planning
     // figure would cut THIS batch into groups, waiting for that number is cheaper than not knowing it)
-    if (!p.legacy && c->pool_pending && c->pool_ratio == 0 && hipEventQuery(c->pool_ev) != hipSuccess) {
+    if (c->pool_pending && c->pool_ratio == 0 && hipEventQuery(c->pool_ev) != hipSuccess) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
         uint64_t room = c->cfg[SPNG_CFG_TOKEN_BYTES] ? (uint64_t)c->cfg[SPNG_CFG_TOKEN_BYTES] : (uint64_t)(free_b + c->tok_cap) / 2;
         if ((double)total * 3.2 > (double)room) HIP_TRY(hipEventSynchronize(c->pool_ev));
     }
-    if (!p.legacy && c->pool_pending && hipEventQuery(c->pool_ev) == hipSuccess) {
+    if (c->pool_pending && hipEventQuery(c->pool_ev) == hipSuccess) {
         c->pool_pending = false;
         const uint64_t used = c->h_pool_used[1];
         if (c->h_pool_used[2]) c->pool_ratio = 0;                                   // it ran dry: back to the default
         else if (c->pool_src_bytes > (1u << 20)) c->pool_ratio = (double)used * 65536.0 / (double)c->pool_src_bytes;
     }
-    const double per_byte = p.legacy ? 0 : (c->pool_ratio > 0 ? (c->pool_ratio * 1.25 < 1.0 ? 1.0 : c->pool_ratio * 1.25) : 3.2);
+    const double per_byte = c->pool_ratio > 0 ? (c->pool_ratio * 1.25 < 1.0 ? 1.0 : c->pool_ratio * 1.25) : 3.2;
     std::vector<uint64_t> est(p.jobs.size(), 0);
     size_t log = 0;
     for (size_t i = 0; i < p.jobs.size(); ++i) {
@@ -527,27 +527,19 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
             memset(&sg, 0, sizeof sg);
             sg.stream = (uint32_t)i; sg.index = (uint32_t)q;
             const uint64_t len = q + 1 < k ? seg_bytes : j.src_len - q * seg_bytes;
-            if (p.legacy) {
-                // chunk records: 272 bytes per 2304 bytes of Huffman data, one partial chunk and a 352-byte block
-                // record per block on top (swift-png's own level-6 streams: a block every ~3 KB)
-                sg.log_cap = ((len / 2 + 16384) + 15) & ~(uint64_t)15;
-            } else {
-                // page-table entries: 16 token bytes per compressed byte at most, and never more than two per output byte
-                uint64_t most = 16 * len;
-                if (most > 2 * (j.dst_cap + 64)) most = 2 * (j.dst_cap + 64);
-                sg.log_cap = (most >> 16) + 2;
-            }
+            // page-table entries: 16 token bytes per compressed byte at most, and never more than two per output byte
+            uint64_t most = 16 * len;
+            if (most > 2 * (j.dst_cap + 64)) most = 2 * (j.dst_cap + 64);
+            sg.log_cap = (most >> 16) + 2;
             sg.log_off = log; log += sg.log_cap;
             sg.start_bit = ~0ull;
             p.segs.push_back(sg);
         }
-        if (!p.legacy) {
-            uint64_t e = (uint64_t)(per_byte * (double)j.src_len);
-            if (e > 2 * (j.dst_cap + 64)) e = 2 * (j.dst_cap + 64);
-            est[i] = e + k * 65536 + 65536;                                        // (every segment ends inside a page)
-        }
+        uint64_t e = (uint64_t)(per_byte * (double)j.src_len);
+        if (e > 2 * (j.dst_cap + 64)) e = 2 * (j.dst_cap + 64);
+        est[i] = e + k * 65536 + 65536;                                            // (every segment ends inside a page)
     }
-    if (!p.legacy) log *= 4;
+    log *= 4;
     p.log_bytes = log;
     if (log > c->log_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -556,20 +548,7 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         c->log_cap = log + log / 8;
     }
     uint64_t want = 0, largest = 0;
-    if (p.legacy) {
-        // Tokens: 0.6 per compressed byte from zlib on PNG scanlines, 1.3 from swift-png's own level-6
-        // streams (more literals).  Two per byte, but never more than one per output byte, is the planning
-        // figure; the budget caps the buffer and the batch then takes several passes over it.  The buffer
-        // must hold the largest stream whole.
-        for (auto &j : p.jobs) {
-            uint64_t t = 2 * j.src_len + 65536;
-            if (t > j.dst_cap + 64) t = j.dst_cap + 64;
-            want += t * 4;
-            if (t * 4 > largest) largest = t * 4;
-        }
-    } else {
-        for (auto e : est) { want += e; if (e > largest) largest = e; }
-    }
+    for (auto e : est) { want += e; if (e > largest) largest = e; }
     uint64_t budget = (uint64_t)c->cfg[SPNG_CFG_TOKEN_BYTES];
     if (!budget) {
         size_t free_b = 0, total_b = 0;
@@ -579,7 +558,7 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
     }
     if (budget < 2 * largest && !c->cfg[SPNG_CFG_TOKEN_BYTES]) budget = 2 * largest;
     uint64_t need = want < budget ? want : budget;
-    if (!p.legacy && need < largest) need = largest;                               // (a stream is never split over groups)
+    if (need < largest) need = largest;                                            // (a stream is never split over groups)
     need = (need + 65535) & ~(uint64_t)65535;
     if (need > c->tok_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -592,12 +571,6 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
             return SPNG_DONE;
         }
         c->tok_cap = need;
-    }
-    if (p.legacy) {
-        p.tok_cap = c->tok_cap / 4;
-        uint64_t passes = (want + c->tok_cap - 1) / c->tok_cap + 1;
-        p.passes = (uint32_t)(passes > 8 ? 8 : passes);
-        return SPNG_DONE;
     }
     // groups of consecutive streams whose estimates fit the pool together
     const uint64_t pool = c->tok_cap & ~(uint64_t)65535;
@@ -640,7 +613,7 @@ static void stage_inflate(InflatePlan &p, Arena &a)
         memcpy(a.host<PStream>(p.streams_at), p.streams.data(), n * sizeof(PStream));
         memcpy(a.host<PSeg>(p.segs_at), p.segs.data(), p.segs.size() * sizeof(PSeg));
     }
-    if (p.parallel && !p.legacy) {
+    if (p.parallel) {
         p.next_at = a.take(64);
         memset(a.host<uint32_t>(p.next_at), 0, 64);
     }
@@ -658,7 +631,7 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
     if (p.gzip)   // (slots behind the uploaded part of the arena: the header kernel fills them)
         HIP_TRY(launch_gzip_pre(a.dev<InflateJob>(p.jobs_at), p.parallel ? a.dev<PStream>(p.streams_at) : nullptr, dr,
                                 a.dev<uint64_t>(p.gz_at), a.dev<int32_t>(p.done_at), n, c->stream));
-    if (p.parallel && !p.legacy) {
+    if (p.parallel) {
         Timed whole(c, SPNG_K_PINFLATE);
         PStream *ds = a.dev<PStream>(p.streams_at);
         PSeg *dg = a.dev<PSeg>(p.segs_at);
@@ -681,20 +654,6 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
             HIP_TRY(hipMemcpyAsync(c->h_pool_used, dnext, 16, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipEventRecord(c->pool_ev, c->stream));
             c->pool_pending = true;
-        }
-    }
-    if (p.parallel && p.legacy) {
-        Timed whole(c, SPNG_K_PINFLATE);
-        PStream *ds = a.dev<PStream>(p.streams_at);
-        PSeg *dg = a.dev<PSeg>(p.segs_at);
-        int32_t *dd = a.dev<int32_t>(p.done_at);
-        const uint32_t ng = (uint32_t)p.segs.size();
-        { Timed t(c, SPNG_K_PINF_FIND); HIP_TRY(launch_pinf_find(ds, n, dg, ng, dd, c->stream)); }
-        { Timed t(c, SPNG_K_PINF_COUNT); HIP_TRY(launch_pinf_count(ds, dg, ng, (uint8_t *)c->d_log, c->stream)); }
-        HIP_TRY(launch_pinf_scan(ds, n, dg, p.tok_cap, p.passes, c->stream));
-        for (uint32_t pass = 0; pass < p.passes; ++pass) {
-            { Timed t(c, SPNG_K_PINF_EMIT); HIP_TRY(launch_pinf_emit(ds, dg, ng, (uint8_t *)c->d_log, (uint32_t *)c->d_tok, pass, c->stream)); }
-            { Timed t(c, SPNG_K_PINF_RESOLVE); HIP_TRY(launch_pinf_resolve(ds, n, (uint32_t *)c->d_tok, dr, dd, pass, c->stream)); }
         }
     }
     if (p.parallel && getenv("SPNG_TRACE_PINFLATE")) {
@@ -775,7 +734,7 @@ static int32_t inflate_batch(spng_ctx *c, const spng_stream_desc *descs, const u
         if ((!descs[i].d_src && descs[i].src_len) || (!descs[i].d_dst && descs[i].dst_cap) || descs[i].format < SPNG_FORMAT_ZLIB ||
             descs[i].format > (resume ? SPNG_FORMAT_IOS : SPNG_FORMAT_GZIP)) return SPNG_E_ARGUMENT;
         plan.jobs[i] = InflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst,
-                                  descs[i].src_len, descs[i].dst_cap, descs[i].format, i, nullptr, nullptr};
+                                  descs[i].src_len, descs[i].dst_cap, descs[i].format, i, nullptr, nullptr, 0, 0};
         if (resume && h_state) {
             plan.state[2 * i] = h_state[2 * i]; plan.state[2 * i + 1] = h_state[2 * i + 1];
             // (a state is only ever what an earlier call handed out: inside the input and the output)
@@ -789,7 +748,7 @@ static int32_t inflate_batch(spng_ctx *c, const spng_stream_desc *descs, const u
     const size_t upload = a.off;
     const size_t res = a.take(count * sizeof(spng_result));
     if (plan.gzip) { plan.gz_at = a.take(count * 8); plan.gzparts_at = a.take((size_t)count * 4 * gzip_pieces()); }
-    if (resume) plan.sumparts_at = a.take((size_t)count * 8 * gzip_pieces());
+    plan.sumparts_at = a.take((size_t)count * 8 * gzip_pieces());
     if (int32_t st = c->upload(0, upload)) return st;
     spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
     poison_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, count);
@@ -866,7 +825,7 @@ int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
     for (uint32_t i = 0; i < count; ++i) {
         const spng_image_desc &d = descs[i];
         if ((!d.d_idat && d.idat_len) || (d.format != SPNG_FORMAT_ZLIB && d.format != SPNG_FORMAT_IOS)) return SPNG_E_ARGUMENT;
-        ip.jobs[i] = InflateJob{(const uint8_t *)d.d_idat, (uint8_t *)d.d_rows, d.idat_len, d.rows_cap, d.format, i, nullptr, nullptr};
+        ip.jobs[i] = InflateJob{(const uint8_t *)d.d_idat, (uint8_t *)d.d_rows, d.idat_len, d.rows_cap, d.format, i, nullptr, nullptr, 0, 0};
     }
     if (int32_t st = plan_inflate(c, ip)) return st;
     // two-phase: we need the device address of the results before planning
@@ -887,7 +846,9 @@ int32_t spng_decode_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t co
     stage_plan(plan, a, slots);
     // upload everything except the results region at the front
     const size_t first = (res_bytes + 255) & ~(size_t)255;
-    if (int32_t st = c->upload(first, a.off)) return st;
+    const size_t staged = a.off;
+    ip.sumparts_at = a.take((size_t)count * 8 * gzip_pieces());
+    if (int32_t st = c->upload(first, staged)) return st;
     poison_results_kernel<<<(count + 255) / 256, 256, 0, c->stream>>>(dr, count);
     HIP_TRY(hipGetLastError());
     if (int32_t st = launch_inflate_plan(c, ip, a, dr)) return st;

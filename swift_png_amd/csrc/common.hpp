@@ -84,12 +84,15 @@ struct InflateJob {
     int32_t        format;
     uint32_t       image;
     const int32_t *skip;          // device flag: non-zero = the parallel pipeline already produced this stream
-    // spng_inflate_resume_batch: {first bit of the first block not decoded completely yet, inflated bytes in front
-    // of it}; the pipeline moves it forward, the serial kernel starts there.  Null: a whole stream from bit 0.
+    // {first bit of the first block not decoded completely yet, inflated bytes in front of it}: the pipeline moves it
+    // forward, the serial kernel starts there.  spng_inflate_resume_batch: what the previous call returned; every other
+    // call: the library's own slot, {0, 0} (`internal`), so that a stream the pipeline cannot finish -- truncated,
+    // corrupt -- costs the serial kernel one block, not the whole stream.
     uint64_t      *state;
+    uint32_t       internal, pad;
 };
 
-// ---- the parallel inflate pipeline (pinflate.hip) -----------------------------------------------
+// ---- the parallel inflate pipeline (pinflate2.hip) -----------------------------------------------
 // One stream of a batch.  The host fills the first group of fields, the kernels the second.
 struct PStream {
     const uint8_t *src;
@@ -113,11 +116,11 @@ enum { PSEG_FAIL = 0, PSEG_CONT = 1, PSEG_FINAL = 2, PSEG_PARTIAL = 3, PSEG_NOPA
 // One segment: the blocks that start in [index * seg_bytes, (index + 1) * seg_bytes).
 struct PSeg {
     uint32_t stream, index;
-    uint64_t log_off, log_cap;             // pinflate2: its page table (first entry, entries); legacy: its chunk records in the log slab (bytes)
+    uint64_t log_off, log_cap;             // its page table in the slab (first entry, entries)
     // device side
     uint64_t start_bit;                    // find: first block header at or after the nominal start (~0: none)
     uint64_t end_bit;                      // count: where decoding stopped (start of the next block)
-    uint64_t ntok;                         // decode: token halfwords (legacy count: tokens)
+    uint64_t ntok;                         // decode: token halfwords
     uint64_t tok_base;                     // scan: first token, relative to the stream's
     int32_t  status;                       // count: PSEG_*
     uint32_t used;                         // scan: part of the chain
@@ -148,14 +151,7 @@ hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32
                           const spng_result *d_results, uint32_t blocks_x, hipStream_t stream);
 hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results,
                           hipStream_t stream);
-hipError_t launch_pinf_find(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t nsegs, int32_t *d_done, hipStream_t stream);
-hipError_t launch_pinf_count(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint8_t *d_logs, hipStream_t stream);
-hipError_t launch_pinf_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint64_t tok_cap, uint32_t passes, hipStream_t stream);
-hipError_t launch_pinf_emit(PStream *d_streams, PSeg *d_segs, uint32_t nsegs, uint8_t *d_logs, uint32_t *d_tokens, uint32_t pass,
-                            hipStream_t stream);
-hipError_t launch_pinf_resolve(PStream *d_streams, uint32_t nstreams, uint32_t *d_tokens, spng_result *d_results, int32_t *d_done,
-                               uint32_t pass, hipStream_t stream);
-// pinflate2.hip
+// pinflate2.hip: the parallel inflate pipeline
 hipError_t launch_pinf2_find(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t retry, hipStream_t stream);
 hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t *d_pt, uint8_t *d_pool, uint32_t *d_next,
                                uint32_t pages, uint32_t retry, hipStream_t stream);

@@ -158,7 +158,7 @@ __device__ __attribute__((always_inline)) bool build(uint32_t *hist, uint32_t *r
         if (my) {
             const uint32_t e = KIND == 0 ? litlen_entry(sym, my) : KIND == 1 ? dist_entry(sym, my) : meta_entry(sym, my);
             if (sorted) sorted[o + rank] = (uint16_t)sym;
-            if (ext) ext[o + rank] = e;                       // (pinflate.hip: entries in canonical order)
+            if (ext) ext[o + rank] = e;                       // (entries in canonical order)
             if ((int)my <= lbits) {
                 const uint32_t rev = __brev(f + rank) >> (32 - my);
                 for (int j = rev; j < size; j += 1 << my) lut[j] = e;

@@ -331,7 +331,7 @@ __device__ __forceinline__ void copy_match(Lds &s, const Out &o, uint64_t pos, u
 // ------------------------------------------------------------------------------------------------
 // wave 1: the resolver
 // ------------------------------------------------------------------------------------------------
-__device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint64_t dst_cap, uint64_t src_len, bool resumed,
+__device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint64_t dst_cap, uint64_t src_len, bool resumed, bool internal,
                                                         uint64_t start_bit, uint64_t out_pos, spng_result *__restrict__ result, int lane)
 {
 #ifndef SPNG_B_PRIO
@@ -472,7 +472,7 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint
         res.written = o.pos;
         res.consumed = (bits + 7) / 8 > src_len ? src_len : (bits + 7) / 8;
         res.aux[0] = aux0; res.aux[1] = aux1;
-        if (resumed && status == SPNG_NEED_MORE_INPUT) { res.aux[0] = start_bit; res.aux[1] = out_pos; }   // where the next call starts
+        if (resumed && !internal && status == SPNG_NEED_MORE_INPUT) { res.aux[0] = start_bit; res.aux[1] = out_pos; }   // where the next call starts
     }
 }
 
@@ -991,7 +991,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
         if (boundary + 32 > total) goto done;
         TAKE((uint32_t)(boundary - bitpos(r)));
         for (int k = 0; k < 4; ++k) declared = declared << 8 | TAKE(8);
-        check = resumed ? 0 : 1;                               // (resumed: the sum over ALL bytes is taken afterwards, gzip.hip)
+        check = resumed ? 0 : 1;                               // (started in mid-stream: the sum over ALL bytes is taken afterwards, gzip.hip)
     }
     status = SPNG_DONE;
 done:
@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256) void inflate_kernel(const InflateJob *__restri
     // job fields are wave-uniform: pin them to scalar registers so that everything derived from
     // them (positions, loop conditions) stays on the scalar unit
     const InflateJob *job = jobs + blockIdx.x;
-    // streams the parallel pipeline (pinflate.hip) has already decoded and verified are not touched
+    // streams the parallel pipeline (pinflate2.hip) has already decoded and verified are not touched
     {
         const int32_t *skip = (const int32_t *)uni64((uint64_t)job->skip);
         if (skip && UNI(*skip)) return;
@@ -1030,8 +1030,10 @@ __global__ __launch_bounds__(256) void inflate_kernel(const InflateJob *__restri
     const uint32_t image = UNI(job->image);
     typedef uint64_t __attribute__((address_space(1))) gstate;
     const gstate *state = (const gstate *)uni64((uint64_t)job->state);
-    const bool resumed = state != nullptr;
-    const uint64_t start_bit = resumed ? uni64(state[0]) : 0, out_pos = resumed ? uni64(state[1]) : 0;
+    const uint64_t start_bit = state ? uni64(state[0]) : 0, out_pos = state ? uni64(state[1]) : 0;
+    const bool internal = UNI(job->internal) != 0;
+    // (a slot of the library's own that still reads {0, 0}: the pipeline got nowhere, this is a whole stream)
+    const bool resumed = state != nullptr && !(internal && start_bit == 0 && out_pos == 0);
     if (threadIdx.x == 0) {
         s.c.tail = 0; s.c.head = 0; s.c.a_done = 0; s.c.b_fail = 0; s.c.a_wait = 0;
         s.c.w_gen = 0; s.c.w_stop = 0; s.c.w_idle = 0; s.c.w_quit = 0; s.c.w_prod = 0; s.c.w_cons = 0;
@@ -1040,7 +1042,7 @@ __global__ __launch_bounds__(256) void inflate_kernel(const InflateJob *__restri
     const int lane = threadIdx.x & 63;
     const uint32_t role = UNI(threadIdx.x >> 6);
     if (role == 0)      decoder(s, src, src_len, format, resumed, start_bit, lane);
-    else if (role == 1) resolver(s, dst, dst_cap, src_len, resumed, start_bit, out_pos, results + image, lane);
+    else if (role == 1) resolver(s, dst, dst_cap, src_len, resumed, internal, start_bit, out_pos, results + image, lane);
     else if (role == 2) scout(s, src, src_len, lane);
     // (wave 3 has nothing to do.  It is there because the dispatcher places 256-thread workgroups
     //  evenly -- exactly four per CU, all 1024 streams of a batch resident at once -- and 192-thread

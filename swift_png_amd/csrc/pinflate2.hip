@@ -1330,12 +1330,14 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
         uint32_t S = 0, I = 0;
         for (int w = 0; w < (int)(RT2 / 64); ++w) { S += s.part[w]; I += s.part[8 + w]; }
         S %= 65521; I %= 65521;
+        // what was in front of this call (spng_inflate_resume_batch): the sum above then lacks those bytes
+        const bool whole = uni64(st.start_bit) == 0 && uni64(st.out_pos) == 0;
         if (tid == 0 && st.ok == 2) {
-            // resumable, and the chain stopped in front of a block the input does not hold (or that is not
-            // acceptable): the serial kernel goes on from there
+            // the chain stopped in front of a block the input does not hold completely (or that is not acceptable): the
+            // serial kernel goes on from there
             state[0] = st.end_bit; state[1] = pos;
-        } else if (tid == 0 && state) {
-            // resumable and complete: the trailer must be there; the sum over ALL bytes is compared afterwards (gzip.hip)
+        } else if (tid == 0 && !whole) {
+            // resumed and complete: the trailer must be there; the sum over ALL bytes is compared afterwards (gzip.hip)
             const uint64_t endb = (st.end_bit + 7) / 8, consumed = endb + (st.format == SPNG_FORMAT_ZLIB ? 4 : 0);
             spng_result &res = results[st.image];
             if (consumed <= n) {
@@ -1346,28 +1348,25 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
             }   // (else: the serial kernel, from where this call started, reports "need more input")
         } else if (tid == 0) {
             const uint64_t endb = (st.end_bit + 7) / 8;
-            bool good = true;
-            uint64_t consumed = endb;
-            if (st.format != SPNG_FORMAT_IOS) {
-                // .checksum (InflatorBuffers.swift:112-130; Stream.swift:402-429)
-                if (endb + 4 > n) good = false;
-                else {
-                    const uint32_t declared = (uint32_t)src[endb] << 24 | (uint32_t)src[endb + 1] << 16 |
-                                              (uint32_t)src[endb + 2] << 8 | (uint32_t)src[endb + 3];
-                    // Adler-32 from S and I: a = 1 + S, b = N + N * S - I  (i counted from 0)
-                    const uint32_t N = (uint32_t)(pos % 65521);
-                    const uint32_t computed = (uint32_t)((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
-                    good = declared == computed;
-                    consumed = endb + 4;
-                }
-            }
-            if (good) {
-                spng_result &res = results[st.image];
+            spng_result &res = results[st.image];
+            if (st.format == SPNG_FORMAT_IOS) {
                 res.status = SPNG_DONE; res.reserved = 1;
-                res.written = pos; res.consumed = consumed;
+                res.written = pos; res.consumed = endb;
                 res.aux[0] = res.aux[1] = 0;
                 done[blockIdx.x] = 1;
-            }
+            } else if (endb + 4 <= n) {
+                // .checksum (InflatorBuffers.swift:112-130; Stream.swift:402-429): Adler-32 from S and I:
+                // a = 1 + S, b = N + N * S - I  (i counted from 0)
+                const uint32_t declared = (uint32_t)src[endb] << 24 | (uint32_t)src[endb + 1] << 16 |
+                                          (uint32_t)src[endb + 2] << 8 | (uint32_t)src[endb + 3];
+                const uint32_t N = (uint32_t)(pos % 65521);
+                const uint32_t computed = (uint32_t)((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
+                // every block was taken: a checksum that differs is the stream's own (invalidStreamChecksum(declared:computed:))
+                res.status = declared == computed ? SPNG_DONE : SPNG_E_STREAM_CHECKSUM; res.reserved = 1;
+                res.written = pos; res.consumed = endb + 4;
+                res.aux[0] = declared == computed ? 0 : declared; res.aux[1] = declared == computed ? 0 : computed;
+                done[blockIdx.x] = 1;
+            }   // (else the trailer is cut off: the serial kernel says so)
         }
     }
 }

@@ -3,8 +3,9 @@
 // expected output.  Built and used by tests/test_emu_pinflate.py; never part of the product.
 //
 //   emu_pinflate2 <stream file> <expected output file> <format 0|1> <segment bytes> [pool pages] [resume: start_bit out_pos]
-//   exit code 0: the pipeline produced SPNG_DONE and identical bytes;  3: the pipeline declined the stream (serial
-//   kernel's turn);  1: wrong bytes / wrong result
+//   exit code 0: the pipeline produced SPNG_DONE and identical bytes;  3: the pipeline left the whole stream to the serial
+//   kernel;  4: it decoded a prefix (printed: the block boundary and byte count the serial kernel would start from) and that
+//   prefix is right;  5: it reported an error of its own (printed);  1: wrong bytes / wrong result
 #include "../../swift_png_amd/csrc/pinflate2.hip"
 
 #include <fstream>
@@ -36,11 +37,12 @@ int main(int argc, char **argv)
     st.src = src.data(); st.dst = dst.data(); st.src_len = src.size(); st.dst_cap = want.size();
     st.format = format; st.image = 0;
     uint64_t state[2] = {0, 0};
+    st.state = state;                                          // (api.hip: every stream has a state slot, {0, 0} unless resumed)
     if (argc > 7) {
-        st.start_bit = strtoull(argv[6], nullptr, 10); st.out_pos = strtoull(argv[7], nullptr, 10);
-        st.state = state;
+        state[0] = st.start_bit = strtoull(argv[6], nullptr, 10); state[1] = st.out_pos = strtoull(argv[7], nullptr, 10);
         memcpy(dst.data(), want.data(), st.out_pos);
     }
+    const bool resumed = argc > 7;
     uint64_t k = (src.size() + seg_bytes - 1) / seg_bytes;
     if (k < 1) k = 1;
     st.seg_first = 0; st.seg_count = (uint32_t)k; st.seg_bytes = seg_bytes;
@@ -99,12 +101,22 @@ int main(int argc, char **argv)
     }
     emu::launch(1, RT2, [&] { pinf2_resolve_kernel(&st, segs.data(), pt.data(), pool, &res, &done, 0); });
 
-    if (st.state) {
-        // resumable: report what the pipeline did
+    if (resumed) {
+        // report what the pipeline did
         printf("resume ok=%d done=%d state=%llu,%llu\n", st.ok, done, (unsigned long long)state[0], (unsigned long long)state[1]);
         const uint64_t upto = st.ok == 2 ? state[1] : (done ? res.written : 0);
         if (memcmp(dst.data(), want.data(), upto) != 0) { printf("MISMATCH in the resumed prefix\n"); return 1; }
         return 0;
+    }
+    if (!done && (state[0] || state[1])) {
+        printf("partial: the serial kernel starts at bit %llu with %llu bytes in front of it\n", (unsigned long long)state[0], (unsigned long long)state[1]);
+        if (state[1] > want.size() || memcmp(dst.data(), want.data(), state[1]) != 0) { printf("MISMATCH in the prefix\n"); return 1; }
+        return 4;
+    }
+    if (done && res.status != SPNG_DONE) {
+        printf("error %d aux %llx %llx written %llu consumed %llu\n", res.status, (unsigned long long)res.aux[0], (unsigned long long)res.aux[1],
+               (unsigned long long)res.written, (unsigned long long)res.consumed);
+        return 5;
     }
     if (!done) {
         size_t i = 0;

@@ -1,5 +1,5 @@
 """Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one bench.py step into
-profiles/r02_pmc_traffic.json (the file bench.py reads `roofline.traffic` / `kernels.*.traffic` from).
+profiles/r03_pmc_traffic.json (the file bench.py reads `roofline.traffic` / `kernels.*.traffic` from).
 
     python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <kind> <images> <unique> <out.json>
 
@@ -8,12 +8,12 @@ workload of the headline line, one decode step; every launch of a kernel inside 
 per step; the parallel inflate stages launch once per token-buffer pass).
 Corrections as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: both counters are in KiB; FETCH_SIZE reports
 half of the bytes of wide (16 B/lane) coalesced reads, so corrected fetch = 2 x raw for the kernels whose reads are
-16 B/lane streams (unfilter, count / emit staging, the serial kernel); the resolve kernel reads its tokens as dwords
-(uncalibrated width): its raw and doubled figures are both given and the doubled one is used, as an upper bound."""
+16 B/lane streams: every kernel of the decode step now is (decode stages its chunks and writes its tokens in 16-byte
+units, resolve reads tokens and writes bytes in 16-byte units, unfilter as before); raw figures are kept next to them."""
 import csv, glob, json, os, sys
 
-NAMES = {"pinf_find_kernel": "pinf_find", "pinf_count_kernel": "pinf_count", "pinf_emit_kernel": "pinf_emit",
-         "pinf_resolve_kernel": "pinf_resolve", "inflate_kernel": "inflate", "unfilter_kernel": "unfilter"}
+NAMES = {"pinf2_find_kernel": "pinf_find", "pinf2_decode_kernel": "pinf_decode", "pinf2_resolve_kernel": "pinf_resolve",
+         "::inflate_kernel": "inflate", "unfilter_kernel": "unfilter"}
 
 
 def collect(d, counter):

@@ -20,7 +20,7 @@ for it in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     res = s.decode_batch([desc])
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    names = ["pinf_find", "pinf_count", "pinf_emit", "pinf_resolve", "inflate", "unfilter", "scatter"]
+    names = ["pinf_find", "pinf_decode", "pinf_resolve", "inflate", "unfilter", "scatter"]
     prof = {k: round(s.profile_get(getattr(spng, "K_" + k.upper()))[0], 2) for k in names}
     s.profile(False)
     print(f"decode {dt*1e3:.1f} ms status {res[0].status} path {res[0].reserved}", prof, flush=True)

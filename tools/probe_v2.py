@@ -1,7 +1,8 @@
-"""Probe: the inflate pipeline of round 3 (pinflate2.hip: find / decode / resolve) next to round 2's (count / emit /
-resolve, SPNG_INFLATE_LEGACY) on the bench workload, per stage, for zlib-made and swift-png-made level-6 streams.
+"""Probe: the inflate pipeline (pinflate2.hip: find / decode / resolve) on the bench workload, per stage, for zlib-made
+and swift-png-made level-6 streams, over segment sizes; with a -DSPNG_D_PROF build (SPNG_LIB=...) the kernels print their
+phase cycle counters.
 
-    python tools/probe_v2.py [--images 1024] [--unique 8] [--steps 3] [--kinds zlib,swiftpng] [--modes auto,legacy]
+    python tools/probe_v2.py [--images 1024] [--unique 8] [--steps 3] [--kinds zlib,swiftpng] [--segments 0,900000]
 """
 import argparse
 import json
@@ -20,7 +21,7 @@ def main():
     ap.add_argument("--unique", type=int, default=8)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--kinds", default="zlib,swiftpng")
-    ap.add_argument("--modes", default="auto,legacy")
+    ap.add_argument("--modes", default="auto")
     ap.add_argument("--segments", default="0", help="comma list of SPNG_CFG_SEGMENT_BYTES values to try (auto mode)")
     args = ap.parse_args()
     import torch
@@ -34,7 +35,7 @@ def main():
         print(f"[{kind}] inputs in {time.time() - t0:.1f} s, ratio {sum(len(r) for r in rows) / sum(len(z) for z in streams):.3f}", flush=True)
         ref = [s.to_device(img.reshape(-1)) for img in images]
         for mode, segb in [(m, int(sb)) for m in args.modes.split(",") for sb in (args.segments.split(",") if m == "auto" else ["0"])]:
-            s.configure(spng.CFG_INFLATE_MODE, {"auto": spng.INFLATE_AUTO, "legacy": spng.INFLATE_LEGACY}[mode])
+            s.configure(spng.CFG_INFLATE_MODE, {"auto": spng.INFLATE_AUTO, "serial": spng.INFLATE_SERIAL}[mode])
             s.configure(spng.CFG_SEGMENT_BYTES, segb)
             job = bench.DecodeJob(spng, s, torch, d_streams, args.images, 0, args.unique, 1)
             for _ in range(2):
