@@ -64,6 +64,25 @@ def build_inputs(session, unique: int, threads: int, encoder: str):
     return images, rows, streams
 
 
+def host_cores() -> int:
+    """cores this process may really use: the affinity mask, cut down by a cgroup CPU quota if there is one (a container
+    that sees 256 CPUs and may burn 12 of them runs 12 workers, and says so)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            p = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                n = max(1, min(n, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(streams, images, rows, cores: int):
     """The CPU oracle (restatement of swift-png's CPU path: inflate + defilter + assign) on a bounded sample of the
     same streams: all host cores -- one worker PROCESS per core, library loaded and buffers touched before the clock
@@ -282,8 +301,8 @@ def copy_ceiling(torch, s):
     """Measured device copy next to the 8 TB/s spec peak: read + write bytes per second of a
     plain 16-bytes-per-lane HBM-to-HBM copy of 8 GiB."""
     n = 8 << 30
-    a = torch.empty(n, dtype=torch.uint8, device=s.tdev)
-    b = torch.empty(n, dtype=torch.uint8, device=s.tdev)
+    a = torch.empty(n // 8, dtype=torch.int64, device=s.tdev)
+    b = torch.empty(n // 8, dtype=torch.int64, device=s.tdev)
     a.zero_(); b.copy_(a)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -296,7 +315,7 @@ def copy_ceiling(torch, s):
     del a, b
     torch.cuda.empty_cache()
     return {"gbps": round(2 * n / (ms * 1e-3) / 1e9, 1), "ms": round(ms, 3), "bytes": 2 * n,
-            "how": "torch uint8 tensor copy of 8 GiB, read + write counted, HIP events, 5 repeats"}
+            "how": "torch tensor copy of 8 GiB (int64 elements), read + write counted, HIP events, 5 repeats"}
 
 
 def parallel_zlib(rows: bytes, level: int, threads: int) -> bytes:
@@ -440,7 +459,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="decode mode: skip the copy ceiling, configs[3] / configs[4] and file -> pixels legs")
-    ap.add_argument("--encode-images", type=int, default=64, help="decode mode: images of the bounded configs[3] leg")
+    ap.add_argument("--encode-images", type=int, default=256,
+                    help="decode mode: images of the bounded configs[3] leg (one wave per stream: fewer leave the chip idle)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -460,7 +480,7 @@ def main():
 
     import swift_png_amd as spng
     s = spng.load(local)
-    cores = os.cpu_count() or 1
+    cores = host_cores()
 
     if args.mode == "encode":
         from bench_encode import run_encode
@@ -544,7 +564,7 @@ def main():
             def enc():
                 from bench_encode import run_encode
                 ea = argparse.Namespace(**vars(args))
-                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), 1, 1, args.no_cpu_baseline
+                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), 1, 0, args.no_cpu_baseline
                 return run_encode(ea, torch, dist, spng, s, rank, world)
             leg("encode", enc)
         print(json.dumps(out))

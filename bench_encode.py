@@ -142,7 +142,8 @@ def run_encode(args, torch, dist, spng, s, rank, world):
                                          f"stream 0 (filter excluded), {dtc:.1f} s; the device stream of the same bytes is "
                                          f"identical"}
         try:
-            allc = encode_cpu_all_cores(rows, args.level, os.cpu_count() or 1)
+            from bench import host_cores
+            allc = encode_cpu_all_cores(rows, args.level, host_cores())
             allc["one_core"] = out["cpu_baseline"]
             out["cpu_baseline"] = allc
         except Exception as exc:                                   # noqa: BLE001

@@ -228,6 +228,16 @@ int32_t spng_write_idat_batch(spng_ctx *ctx, const spng_chunking_desc *descs, ui
 /* CRC-32 of a host buffer computed on the device (swift-hash CRC32 as used by chunk()) */
 int32_t spng_crc32(spng_ctx *ctx, const void *data, uint64_t n, uint32_t *out);
 
+/* A stream that arrives in pieces (PNG.Context.push(data:) per IDAT chunk): defilters and assigns the
+ * scanlines that became complete between h_prev_len[i] and h_now_len[i] inflated bytes -- what PNG.Decoder.row / pass keep
+ * track of (Sources/PNG/Decoding/PNG.Decoder.swift:20-21, 88-94, 121-135) -- each row once, with the defiltered row above it
+ * as an earlier call left it (in d_storage for 8 / 16-bit non-interlaced images; in d_work[i], a buffer of the size and layout
+ * of d_rows, for interlaced and sub-byte ones: d_rows itself stays as inflated, it is the LZ77 window of the next push).
+ * results: written = scanline bytes defiltered by this call, consumed = inflated bytes that are whole rows by now. */
+int32_t spng_unfilter_resume_batch(spng_ctx *ctx, const spng_image_desc *descs, void *const *d_work,
+                                   const uint64_t *h_prev_len, const uint64_t *h_now_len, uint32_t count,
+                                   spng_result *d_results, spng_result *h_results);
+
 /* ---- pixels: the step behind the decode path ----------------------------------------------------- */
 /* One image to unpack.  palette: indexed formats only, palette_count x 4 bytes (r, g, b, a): PLTE with the
  * tRNS alphas folded in, as PNG.Format keeps it.  key: the tRNS chroma key of a v / rgb / bgr format. */
@@ -242,16 +252,29 @@ typedef struct spng_unpack_desc {
     uint8_t     indexed;                        /* PNG.Format.indexed1/2/4/8                         */
     uint8_t     bgr;                            /* PNG.Format.bgr8 / bgra8 (CgBI)                    */
     uint8_t     has_key;
-    uint8_t     target;                         /* 8 or 16: PNG.RGBA<UInt8> / PNG.RGBA<UInt16>       */
+    uint8_t     target;                         /* 8 or 16: T = UInt8 / UInt16                        */
+    uint8_t     layout;                         /* SPNG_TARGET_RGBA: PNG.RGBA<T>, SPNG_TARGET_VA: PNG.VA<T> (v = the grey value or
+                                                   the red channel, a) -- d_out holds width * height (v, a) pairs then */
+    uint8_t     premultiply;                    /* 0: straight;  SPNG_PREMULTIPLY: .premultiplied (PNG.RGBA.swift:121-127,
+                                                   PNG.VA.swift:57-60);  SPNG_PREMULTIPLY_AS_U8 (target 16 only):
+                                                   .premultiplied(as: UInt8.self) (PNG.RGBA.swift:146-158), the form the
+                                                   reference's iOS goldens are compared in (Roundtripping.swift:206-215) */
+    uint8_t     reserved[6];
 } spng_unpack_desc;
-/* replaces PNG.RGBA<T>.unpack(_:of:deindexer:) with the default deindexer, T = UInt8 / UInt16
+enum { SPNG_TARGET_RGBA = 0, SPNG_TARGET_VA = 1 };
+enum { SPNG_PREMULTIPLY = 1, SPNG_PREMULTIPLY_AS_U8 = 2 };
+/* replaces PNG.RGBA<T>.unpack(_:of:deindexer:) / PNG.VA<T>.unpack(_:of:deindexer:) with the default deindexers, T = UInt8 / UInt16
  * (Sources/PNG/ColorTargets/PNG.RGBA.swift:259-365, depth rescaling Sources/PNG/PNG.swift:255-312,
- * 495-524); what PNG.Image.unpack(as: PNG.RGBA<T>.self) returns.  All descs of a call share `target`.
- * Output: r, g, b, a per pixel in host byte order. */
+ * 495-524; PNG.VA.swift:184-290; premultiplication PNG.swift:55-66); what PNG.Image.unpack(as:) returns.  All descs
+ * of a call share `target`.  Output: r, g, b, a (or v, a) per pixel in host byte order. */
 int32_t spng_unpack_batch(spng_ctx *ctx, const spng_unpack_desc *descs, uint32_t count);
 int32_t spng_unpack(spng_ctx *ctx, const void *storage, uint32_t w, uint32_t h, int depth, int channels,
                     int indexed, int bgr, int target, const void *palette, uint32_t palette_count,
                     const uint16_t *key, void *out);
+/* the same with a colour-target layout (SPNG_TARGET_*) and premultiplication (0 / SPNG_PREMULTIPLY*) */
+int32_t spng_unpack_as(spng_ctx *ctx, const void *storage, uint32_t w, uint32_t h, int depth, int channels,
+                       int indexed, int bgr, int target, int layout, int premultiply, const void *palette,
+                       uint32_t palette_count, const uint16_t *key, void *out);
 
 /* ---- encode -------------------------------------------------------------------------------- */
 /* replaces PNG.Encoder.filter (PNG.Encoder.swift:132-204) + PNG.Image.collect

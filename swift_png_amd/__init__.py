@@ -34,6 +34,8 @@ E_OUTPUT_CAPACITY, E_ARGUMENT, E_DEVICE, E_REFERENCE_UNDEFINED = 64, 65, 66, 67
 FORMAT_ZLIB, FORMAT_IOS, FORMAT_GZIP = 0, 1, 2
 K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER, K_PINFLATE = 0, 1, 2, 3, 4, 5, 6
 K_UNPACK = 7
+TARGET_RGBA, TARGET_VA = 0, 1
+PREMULTIPLY, PREMULTIPLY_AS_U8 = 1, 2
 K_LEX = 12
 K_PINF_FIND, K_PINF_DECODE, K_PINF_RESOLVE = 8, 9, 11
 CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES, CFG_UNFILTER_PIECE_ROWS = 0, 1, 2, 3
@@ -42,9 +44,10 @@ INFLATE_AUTO, INFLATE_SERIAL = 0, 1
 EXPORTS = [
     "spng_version", "spng_status_string", "spng_last_error_string", "spng_inflated_size",
     "spng_storage_size", "spng_create", "spng_destroy", "spng_stream", "spng_sync", "spng_profile",
-    "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_inflate_resume_batch", "spng_unfilter_batch", "spng_decode_batch",
+    "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_inflate_resume_batch", "spng_unfilter_batch",
+    "spng_unfilter_resume_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
-    "spng_lex_batch", "spng_write_idat_batch", "spng_crc32", "spng_unpack_batch", "spng_unpack", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
+    "spng_lex_batch", "spng_write_idat_batch", "spng_crc32", "spng_unpack_batch", "spng_unpack", "spng_unpack_as", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
 ]
 
 
@@ -82,7 +85,8 @@ class UnpackDesc(ctypes.Structure):
     _fields_ = [("d_storage", ctypes.c_void_p), ("d_out", ctypes.c_void_p), ("d_palette", ctypes.c_void_p),
                 ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("palette_count", ctypes.c_uint32),
                 ("key", ctypes.c_uint16 * 3), ("depth", ctypes.c_uint8), ("channels", ctypes.c_uint8), ("indexed", ctypes.c_uint8),
-                ("bgr", ctypes.c_uint8), ("has_key", ctypes.c_uint8), ("target", ctypes.c_uint8)]
+                ("bgr", ctypes.c_uint8), ("has_key", ctypes.c_uint8), ("target", ctypes.c_uint8), ("layout", ctypes.c_uint8),
+                ("premultiply", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 6)]
 
 
 class ChunkingDesc(ctypes.Structure):
@@ -191,6 +195,8 @@ def load_library():
     lib.spng_inflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), u32, vp, rp]
     lib.spng_inflate_resume_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), ctypes.POINTER(ctypes.c_uint64), u32, vp, rp]
     lib.spng_unfilter_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, vp, rp]
+    lib.spng_unfilter_resume_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(u64),
+                                               ctypes.POINTER(u64), u32, vp, rp]
     lib.spng_decode_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, rp]
     lib.spng_filter_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, rp]
     lib.spng_inflate.argtypes = [vp, vp, u64, i32, vp, u64, rp]
@@ -204,6 +210,8 @@ def load_library():
     lib.spng_unpack_batch.argtypes = [vp, vp, u32]
     lib.spng_unpack.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                 vp, u32, vp, vp]
+    lib.spng_unpack_as.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, vp, u32, vp, vp]
     lib.spng_deflate_bound.restype = u64
     lib.spng_deflate_bound.argtypes = [u64]
     lib.spng_deflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), ctypes.POINTER(i32), u32, vp, rp]
@@ -320,6 +328,17 @@ class Session:
         r = res[0]
         return r, ((r.aux[0], r.aux[1]) if r.status == NEED_MORE_INPUT else tuple(state))
 
+    def unfilter_resume(self, desc, work, prev_len, now_len):
+        """The scanlines of one image that became complete between prev_len and now_len inflated bytes are defiltered and
+        assigned (spng_unfilter_resume_batch); work: device scratch of the size of the scanline buffer (interlaced and
+        sub-byte images), or None.  -> Result (written = scanline bytes defiltered by this call)"""
+        arr = (ImageDesc * 1)(desc)
+        wp = (ctypes.c_void_p * 1)(self._ptr(work) if work is not None else None)
+        prev, now = (ctypes.c_uint64 * 1)(int(prev_len)), (ctypes.c_uint64 * 1)(int(now_len))
+        res = (Result * 1)()
+        _check(self.lib, self.lib.spng_unfilter_resume_batch(self.ctx, arr, wp, prev, now, 1, None, res))
+        return res[0]
+
     def image_desc(self, idat, rows, storage, w, h, depth, channels, interlaced, fmt=FORMAT_ZLIB, rows_cap=None):
         return ImageDesc(self._ptr(idat), idat.numel() if idat is not None else 0, self._ptr(rows),
                          int(rows_cap if rows_cap is not None else rows.numel()), self._ptr(storage),
@@ -433,16 +452,18 @@ class Session:
         _check(self.lib, self.lib.spng_crc32(self.ctx, src, len(data), ctypes.byref(out)))
         return out.value
 
-    def unpack(self, storage: bytes, w, h, depth, channels, indexed=False, bgr=False, target=16, palette=None, key=None):
-        """PNG.Image.unpack(as: PNG.RGBA<UInt8 / UInt16>.self): -> bytes of r, g, b, a per pixel (host order).
-        palette: bytes of (r, g, b, a) quadruplets (PLTE with the tRNS alphas folded in); key: tRNS chroma key."""
-        n = w * h * 4 * (target // 8)
+    def unpack(self, storage: bytes, w, h, depth, channels, indexed=False, bgr=False, target=16, palette=None, key=None,
+               layout=0, premultiply=0):
+        """PNG.Image.unpack(as: PNG.RGBA<UInt8 / UInt16>.self) (layout = TARGET_VA: PNG.VA<T>): -> bytes of r, g, b, a
+        (v, a) per pixel (host order).  palette: bytes of (r, g, b, a) quadruplets (PLTE with the tRNS alphas folded in);
+        key: tRNS chroma key; premultiply: 0, PREMULTIPLY (.premultiplied) or PREMULTIPLY_AS_U8 (.premultiplied(as: UInt8.self))."""
+        n = w * h * (2 if layout else 4) * (target // 8)
         src = (ctypes.c_uint8 * max(len(storage), 1)).from_buffer_copy(bytes(storage) or b"\0")
         out = (ctypes.c_uint8 * max(n, 1))()
         pal = (ctypes.c_uint8 * max(len(palette or b""), 1)).from_buffer_copy(bytes(palette or b"\0"))
         k = (ctypes.c_uint16 * 3)(*(list(key) + [0, 0, 0])[:3]) if key is not None else None
-        _check(self.lib, self.lib.spng_unpack(self.ctx, src, w, h, depth, channels, int(bool(indexed)), int(bool(bgr)), target,
-                                              pal if palette else None, len(palette or b"") // 4, k, out))
+        _check(self.lib, self.lib.spng_unpack_as(self.ctx, src, w, h, depth, channels, int(bool(indexed)), int(bool(bgr)), target,
+                                                 int(layout), int(premultiply), pal if palette else None, len(palette or b"") // 4, k, out))
         return bytes(out[:n])
 
     def deflate(self, data: bytes, level: int, fmt=FORMAT_ZLIB, exponent: int = 15) -> bytes:

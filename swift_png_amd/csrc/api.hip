@@ -363,7 +363,7 @@ static int32_t plan_unfilter(const spng_image_desc *descs, uint32_t count, Unfil
             else        { j.out = (uint8_t *)d.d_rows + off + 1; j.out_stride = p[z].pitch + 1; }
             j.stream_off = off;
             j.rows_len = rows_len_of(user, i);
-            j.pitch = (uint32_t)p[z].pitch; j.rows = p[z].h; j.image = i; j.bpp = bpp;
+            j.pitch = (uint32_t)p[z].pitch; j.rows = p[z].h; j.image = i; j.bpp = bpp; j.has_prev = 0; j.pad = 0;
             plan.unf[bpp].push_back(j);
             if (!direct) {
                 ScatterJob s;
@@ -732,7 +732,7 @@ static int32_t inflate_batch(spng_ctx *c, const spng_stream_desc *descs, const u
     if (resume) plan.state.assign((size_t)count * 2, 0);
     for (uint32_t i = 0; i < count; ++i) {
         if ((!descs[i].d_src && descs[i].src_len) || (!descs[i].d_dst && descs[i].dst_cap) || descs[i].format < SPNG_FORMAT_ZLIB ||
-            descs[i].format > (resume ? SPNG_FORMAT_IOS : SPNG_FORMAT_GZIP)) return SPNG_E_ARGUMENT;
+            descs[i].format > SPNG_FORMAT_GZIP) return SPNG_E_ARGUMENT;
         plan.jobs[i] = InflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst,
                                   descs[i].src_len, descs[i].dst_cap, descs[i].format, i, nullptr, nullptr, 0, 0};
         if (resume && h_state) {
@@ -805,6 +805,80 @@ int32_t spng_unfilter_batch(spng_ctx *c, const spng_image_desc *descs, uint32_t 
     HIP_TRY(hipGetLastError());
     if (h_results) {
         HIP_TRY(hipMemcpyAsync(h_results, dr, count * sizeof(spng_result), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SPNG_DONE;
+}
+
+int32_t spng_unfilter_resume_batch(spng_ctx *c, const spng_image_desc *descs, void *const *d_work, const uint64_t *h_prev_len,
+                                   const uint64_t *h_now_len, uint32_t count, spng_result *d_results, spng_result *h_results)
+{
+    if (!c || (!descs && count) || !h_prev_len || !h_now_len) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    UnfilterPlan plan;
+    std::vector<spng_result> res(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        const spng_image_desc &d = descs[i];
+        if (!valid_format(d.depth, d.channels) || !d.d_rows || !d.d_storage || h_prev_len[i] > h_now_len[i]) return SPNG_E_ARGUMENT;
+        const int volume = d.depth * d.channels;
+        const uint32_t bpp = (uint32_t)(volume + 7) >> 3;
+        const uint64_t u = spng_inflated_size(d.width, d.height, d.depth, d.channels, d.interlaced);
+        if (d.rows_cap < u) return SPNG_E_ARGUMENT;
+        const bool direct = !d.interlaced && volume >= 8;       // rows land in storage as they are
+        if (!direct && (!d_work || !d_work[i])) return SPNG_E_ARGUMENT;
+        Pass p[7];
+        const int np = passes(d.width, d.height, volume, d.interlaced, p);
+        uint64_t off = 0, fresh = 0, upto = 0;
+        for (int z = 0; z < np; ++z) {
+            const uint64_t stride = p[z].pitch + 1, end = off + stride * p[z].h;
+            // rows of this sub-image complete before / with this push (PNG.Decoder.row / pass, PNG.Decoder.swift:20-21, 88-94)
+            const uint64_t r0 = h_prev_len[i] <= off ? 0 : (h_prev_len[i] >= end ? p[z].h : (h_prev_len[i] - off) / stride);
+            const uint64_t r1 = h_now_len[i] <= off ? 0 : (h_now_len[i] >= end ? p[z].h : (h_now_len[i] - off) / stride);
+            upto = off + r1 * stride > upto && r1 ? off + r1 * stride : upto;
+            if (r1 > r0) {
+                UnfJob j;
+                j.in = (const uint8_t *)d.d_rows + off + r0 * stride;
+                j.in_stride = stride;
+                if (direct) { j.out = (uint8_t *)d.d_storage + r0 * p[z].pitch; j.out_stride = p[z].pitch; }
+                else        { j.out = (uint8_t *)d_work[i] + off + r0 * stride + 1; j.out_stride = stride; }
+                j.stream_off = off; j.rows_len = nullptr;
+                j.pitch = (uint32_t)p[z].pitch; j.rows = (uint32_t)(r1 - r0); j.image = i; j.bpp = bpp;
+                j.has_prev = r0 ? 1 : 0; j.pad = 0;
+                plan.unf[bpp].push_back(j);
+                if (!direct) {
+                    ScatterJob s;
+                    s.rows = (const uint8_t *)d_work[i] + off + r0 * stride + 1;
+                    s.storage = (uint8_t *)d.d_storage;
+                    s.row_stride = stride; s.stream_off = off; s.rows_len = nullptr;
+                    s.sub_w = p[z].w; s.sub_h = (uint32_t)(r1 - r0); s.width = d.width;
+                    s.bx = p[z].bx; s.by = p[z].by + (uint32_t)r0 * p[z].sy; s.sx = p[z].sx; s.sy = p[z].sy;
+                    s.depth = d.depth; s.channels = d.channels;
+                    plan.scat.push_back(s);
+                    plan.scat_image.push_back(i);
+                }
+                fresh += (r1 - r0) * stride;
+            }
+            off = end;
+        }
+        res[i].status = SPNG_DONE; res[i].reserved = 0;
+        res[i].written = fresh;                                // scanline bytes defiltered by THIS call
+        res[i].consumed = upto;                                // inflated bytes that are whole rows by now
+        res[i].aux[0] = res[i].aux[1] = 0;
+    }
+    const size_t need = plan_bytes(plan) + count * sizeof(spng_result) + 1024;
+    if (int32_t st = c->reserve(need)) return st;
+    Arena a{c};
+    PlanSlots slots;
+    stage_plan(plan, a, slots);
+    const size_t rslot = a.take(count * sizeof(spng_result));
+    memcpy(a.host<spng_result>(rslot), res.data(), count * sizeof(spng_result));
+    if (int32_t st = c->upload(0, a.off)) return st;
+    if (int32_t st = launch_plan(c, plan, a, slots, nullptr)) return st;
+    if (d_results) HIP_TRY(hipMemcpyAsync(d_results, a.dev<spng_result>(rslot), count * sizeof(spng_result), hipMemcpyDeviceToDevice, c->stream));
+    if (h_results) {
+        memcpy(h_results, res.data(), count * sizeof(spng_result));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return SPNG_DONE;
@@ -1039,18 +1113,36 @@ int32_t spng_lex_batch(spng_ctx *c, const spng_file_desc *files, uint32_t count,
     if (!count) return SPNG_DONE;
     HIP_TRY(hipSetDevice(c->device));
     std::lock_guard<std::mutex> g(c->mu);
-    if (int32_t st = c->reserve(count * (sizeof(spng_file_desc) + sizeof(spng_lexed)) + 1024)) return st;
-    Arena a{c};
-    const size_t fslot = a.take(count * sizeof(spng_file_desc));
+    // the chunk lists: a file of `len` bytes holds at most len / 12 chunks; 64 KiB IDATs are the usual case, so a list of
+    // len / 2048 + 64 entries (at most 8192) is plenty, and a file with more is finished by its own wave
+    std::vector<uint64_t> at(count + 1, 0);
+    uint32_t max_listed = 1;
     for (uint32_t i = 0; i < count; ++i) {
         if ((!files[i].d_png && files[i].len) || (!files[i].d_idat && files[i].idat_cap)) return SPNG_E_ARGUMENT;
-        a.host<spng_file_desc>(fslot)[i] = files[i];
+        uint64_t k = files[i].len / 2048 + 64;
+        if (k > files[i].len / 12 + 1) k = files[i].len / 12 + 1;
+        if (k > 8192) k = 8192;
+        at[i + 1] = at[i] + k;
+        max_listed = k > max_listed ? (uint32_t)k : max_listed;
     }
+    const size_t table_bytes = (size_t)at[count] * lex_chunk_bytes();
+    if (int32_t st = c->reserve(count * (sizeof(spng_file_desc) + sizeof(spng_lexed) + 8 + lex_walk_bytes()) + table_bytes + 2048)) return st;
+    Arena a{c};
+    const size_t fslot = a.take(count * sizeof(spng_file_desc));
+    for (uint32_t i = 0; i < count; ++i) a.host<spng_file_desc>(fslot)[i] = files[i];
+    const size_t atslot = a.take((count + 1) * 8);
+    memcpy(a.host<uint64_t>(atslot), at.data(), (count + 1) * 8);
     const size_t upload = a.off;
     const size_t oslot = a.take(count * sizeof(spng_lexed));
+    const size_t wslot = a.take(count * lex_walk_bytes());
+    const size_t tslot = a.take(table_bytes);
     if (int32_t st = c->upload(0, upload)) return st;
     spng_lexed *dout = d_infos ? d_infos : a.dev<spng_lexed>(oslot);
-    { Timed t(c, SPNG_K_LEX); HIP_TRY(launch_lex(a.dev<spng_file_desc>(fslot), count, dout, c->stream)); }
+    {
+        Timed t(c, SPNG_K_LEX);
+        HIP_TRY(launch_lex(a.dev<spng_file_desc>(fslot), count, dout, a.dev<uint8_t>(tslot), a.dev<uint64_t>(atslot), a.dev<uint8_t>(wslot),
+                           max_listed, c->stream));
+    }
     if (h_infos) {
         HIP_TRY(hipMemcpyAsync(h_infos, dout, count * sizeof(spng_lexed), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1122,7 +1214,8 @@ int32_t spng_unpack_batch(spng_ctx *c, const spng_unpack_desc *descs, uint32_t c
     for (uint32_t i = 0; i < count; ++i) {
         const spng_unpack_desc &d = descs[i];
         if (!valid_format(d.depth, d.channels) || !d.d_storage || !d.d_out || d.target != target ||
-            (d.indexed && (d.channels != 1 || d.depth > 8 || (!d.d_palette && d.palette_count))))
+            (d.indexed && (d.channels != 1 || d.depth > 8 || (!d.d_palette && d.palette_count))) ||
+            d.layout > SPNG_TARGET_VA || d.premultiply > SPNG_PREMULTIPLY_AS_U8 || (d.premultiply == SPNG_PREMULTIPLY_AS_U8 && target != 16))
             return SPNG_E_ARGUMENT;
         UnpackJob j;
         memset(&j, 0, sizeof j);
@@ -1130,25 +1223,26 @@ int32_t spng_unpack_batch(spng_ctx *c, const spng_unpack_desc *descs, uint32_t c
         j.width = d.width; j.height = d.height; j.palette_count = d.palette_count;
         j.key[0] = d.key[0]; j.key[1] = d.key[1]; j.key[2] = d.key[2];
         j.depth = d.depth; j.channels = d.channels; j.indexed = d.indexed; j.bgr = d.bgr; j.has_key = d.has_key;
+        j.layout = d.layout; j.premultiply = d.premultiply;
         a.host<UnpackJob>(jslot)[i] = j;
         const uint64_t px = (uint64_t)d.width * d.height;
         maxpix = px > maxpix ? px : maxpix;
     }
     if (int32_t st = c->upload(0, a.off)) return st;
-    uint64_t bx = (maxpix + 1023) / 1024;
+    uint64_t bx = (maxpix + 4095) / 4096;                      // (four pixels per thread, 256 threads, a few rounds)
     if (bx > 4096) bx = 4096;
     Timed t(c, SPNG_K_UNPACK);
     HIP_TRY(launch_unpack(a.dev<UnpackJob>(jslot), count, (uint32_t)bx, target, c->stream));
     return SPNG_DONE;
 }
 
-int32_t spng_unpack(spng_ctx *c, const void *storage, uint32_t w, uint32_t h, int depth, int channels,
-                    int indexed, int bgr, int target, const void *palette, uint32_t palette_count,
-                    const uint16_t *key, void *out)
+int32_t spng_unpack_as(spng_ctx *c, const void *storage, uint32_t w, uint32_t h, int depth, int channels,
+                       int indexed, int bgr, int target, int layout, int premultiply, const void *palette,
+                       uint32_t palette_count, const uint16_t *key, void *out)
 {
     if (!c || !storage || !out || !valid_format(depth, channels) || (target != 8 && target != 16)) return SPNG_E_ARGUMENT;
     HIP_TRY(hipSetDevice(c->device));
-    const uint64_t s = spng_storage_size(w, h, depth, channels), o = (uint64_t)w * h * 4 * (target / 8);
+    const uint64_t s = spng_storage_size(w, h, depth, channels), o = (uint64_t)w * h * (layout == SPNG_TARGET_VA ? 2 : 4) * (target / 8);
     DevBuf ds, dout, dp;
     HIP_TRY(ds.alloc(s)); HIP_TRY(dout.alloc(o)); HIP_TRY(dp.alloc((size_t)palette_count * 4));
     HIP_TRY(hipMemcpyAsync(ds.p, storage, s, hipMemcpyHostToDevice, c->stream));
@@ -1158,11 +1252,18 @@ int32_t spng_unpack(spng_ctx *c, const void *storage, uint32_t w, uint32_t h, in
     d.width = w; d.height = h; d.palette_count = palette_count;
     if (key) { d.key[0] = key[0]; d.key[1] = key[1]; d.key[2] = key[2]; d.has_key = 1; }
     d.depth = (uint8_t)depth; d.channels = (uint8_t)channels; d.indexed = (uint8_t)(indexed != 0); d.bgr = (uint8_t)(bgr != 0);
-    d.target = (uint8_t)target;
+    d.target = (uint8_t)target; d.layout = (uint8_t)layout; d.premultiply = (uint8_t)premultiply;
     if (int32_t st = spng_unpack_batch(c, &d, 1)) return st;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (o) HIP_TRY(hipMemcpy(out, dout.p, o, hipMemcpyDeviceToHost));
     return SPNG_DONE;
+}
+
+int32_t spng_unpack(spng_ctx *c, const void *storage, uint32_t w, uint32_t h, int depth, int channels,
+                    int indexed, int bgr, int target, const void *palette, uint32_t palette_count,
+                    const uint16_t *key, void *out)
+{
+    return spng_unpack_as(c, storage, w, h, depth, channels, indexed, bgr, target, SPNG_TARGET_RGBA, 0, palette, palette_count, key, out);
 }
 
 uint64_t spng_deflate_bound(uint64_t n) { return n + n / 4 + 4096; }   // (covers the 18 bytes of a gzip wrapper too)

@@ -36,6 +36,8 @@ struct UnfJob {
     uint32_t       rows;
     uint32_t       image;         // index into the result array
     uint32_t       bpp;           // "delay": ceil(volume / 8)
+    uint32_t       has_prev;      // spng_unfilter_resume_batch: the defiltered row above row 0 is at out - out_stride
+    uint32_t       pad;
 };
 
 // One scatter job: defiltered rows of one (sub-)image -> PNG.Image.storage (PNG.Image.assign,
@@ -74,6 +76,7 @@ struct UnpackJob {
     uint32_t       palette_count;
     uint16_t       key[3];        // tRNS chroma key, at the source depth
     uint8_t        depth, channels, indexed, bgr, has_key, pad;
+    uint8_t        layout, premultiply;      // spng_unpack_desc.layout / .premultiply
 };
 
 struct InflateJob {
@@ -175,7 +178,10 @@ hipError_t launch_deflate_density(const DeflateJob *d_jobs, uint32_t count, uint
 uint64_t deflate_graph_vertices(uint64_t n);
 uint64_t deflate_graph_bytes(uint64_t vertices);
 hipError_t launch_unpack(const UnpackJob *d_jobs, uint32_t count, uint32_t blocks_x, int target, hipStream_t stream);
-hipError_t launch_lex(const spng_file_desc *d_files, uint32_t count, spng_lexed *d_out, hipStream_t stream);
+size_t lex_chunk_bytes();
+size_t lex_walk_bytes();
+hipError_t launch_lex(const spng_file_desc *d_files, uint32_t count, spng_lexed *d_out, void *d_table, const uint64_t *d_table_at,
+                      void *d_walks, uint32_t max_listed, hipStream_t stream);
 hipError_t launch_write_idat(const spng_chunking_desc *d_descs, uint32_t count, uint32_t blocks_x, spng_result *d_results, hipStream_t stream);
 hipError_t launch_crc_partial(const uint8_t *d, uint64_t n, uint64_t piece, uint32_t *d_partial, uint32_t pieces, hipStream_t stream);
 uint32_t crc32_fold(const uint32_t *partial, uint64_t pieces, uint64_t n, uint64_t piece);

@@ -29,6 +29,9 @@ __host__ __device__ inline uint32_t xpow8(uint64_t n)
     return r;
 }
 
+// Four 256-entry tables for slicing-by-4 (tab[0] is the plain byte table; tab[k][i] = the CRC register after byte i
+// and k zero bytes): four independent LDS lookups per input dword instead of four dependent ones.
+static constexpr int CRC_TAB = 4 * 256;
 __device__ __forceinline__ void crc_table(uint32_t *tab, int lane)
 {
     for (int i = lane; i < 256; i += 64) {
@@ -37,16 +40,36 @@ __device__ __forceinline__ void crc_table(uint32_t *tab, int lane)
         tab[i] = c;
     }
     LSYNC();
+    for (int t = 1; t < 4; ++t) {
+        for (int i = lane; i < 256; i += 64) { const uint32_t c = tab[(t - 1) * 256 + i]; tab[t * 256 + i] = (c >> 8) ^ tab[c & 0xff]; }
+        LSYNC();
+    }
 }
 
-// standard CRC-32 of p[0 .. n), continuing from `crc` (a finished CRC-32 value; 0 for a fresh one); wave-uniform result
+typedef uint32_t crc_v4u __attribute__((ext_vector_type(4)));
+struct __attribute__((packed)) CrcPV4 { crc_v4u v; };
+typedef CrcPV4 __attribute__((address_space(1))) gCrcPV4;
+
+// standard CRC-32 of p[0 .. n), continuing from `crc` (a finished CRC-32 value; 0 for a fresh one); wave-uniform result.
+// 64 equal pieces, one per lane (16 bytes per load, slicing-by-4), folded with crc(A || B) = crc(A) * x^(8 |B|) + crc(B)
+// in GF(2)[x] / P (the raw, zero-initialised CRC is linear), the per-level shift factor being the previous one squared;
+// the < 64 leftover bytes go through the byte table.
 __device__ __forceinline__ uint32_t wave_crc32(const uint32_t *tab, const gbyte *p, uint64_t n, uint32_t crc, int lane)
 {
     const uint64_t L = n / 64;
     uint32_t c = 0;
     if (L) {
         const gbyte *q = p + (uint64_t)lane * L;
-        for (uint64_t i = 0; i < L; ++i) c = tab[(c ^ q[i]) & 0xff] ^ (c >> 8);
+        uint64_t i = 0;
+        for (; i + 16 <= L; i += 16) {
+            const crc_v4u v = ((const gCrcPV4 *)(q + i))->v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                c ^= v[k];
+                c = tab[768 + (c & 0xff)] ^ tab[512 + ((c >> 8) & 0xff)] ^ tab[256 + ((c >> 16) & 0xff)] ^ tab[c >> 24];
+            }
+        }
+        for (; i < L; ++i) c = tab[(c ^ q[i]) & 0xff] ^ (c >> 8);
         uint32_t pw = xpow8(L);
 #pragma unroll
         for (int k = 0; k < 6; ++k) {

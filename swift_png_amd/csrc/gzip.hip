@@ -108,7 +108,7 @@ __device__ __forceinline__ uint32_t fold_pieces(const uint32_t *part, uint64_t n
 __global__ __launch_bounds__(64) void gzip_inflate_crc_kernel(const InflateJob *__restrict__ jobs, const spng_result *__restrict__ results,
                                                               const uint64_t *__restrict__ gz, uint32_t *__restrict__ parts)
 {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[CRC_TAB];
     const int lane = threadIdx.x;
     const uint32_t i = blockIdx.y;
     if (uni64(gz[i]) == GZ_NONE) return;
@@ -144,7 +144,7 @@ __global__ void gzip_inflate_post_kernel(const InflateJob *__restrict__ jobs, sp
 // deflate: CRC-32 of the input, then the trailer behind the stream the kernel wrote
 __global__ __launch_bounds__(64) void gzip_deflate_crc_kernel(const DeflateJob *__restrict__ jobs, uint32_t *__restrict__ parts)
 {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[CRC_TAB];
     const int lane = threadIdx.x;
     const uint32_t i = blockIdx.y;
     if ((int32_t)UNI(jobs[i].format) != SPNG_FORMAT_GZIP) return;

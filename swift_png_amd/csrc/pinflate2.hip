@@ -519,7 +519,7 @@ __device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *
 // decodes the token that starts at staged bit q.  -> bits | kind << 8 with kind 0 literal, 2 back-reference, 1 end
 // of block, 3 not a token the fast path takes (undefined code, zero run or distance, past the end of the input
 // `lim`).  FULL also produces the token's halfwords (h0, and h1 for a reference).
-static constexpr uint32_t D2_LIT = C_LIT, D2_EOB = C_EOB, D2_REF = C_REF, D2_BAD = C_BAD;   // (the entry's class as it is)
+static constexpr uint32_t D2_EOB = C_EOB, D2_REF = C_REF, D2_BAD = C_BAD;   // (the entry's class as it is; 0: a literal)
 template <bool FULL>
 __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32_t lim, uint32_t &h0, uint32_t &h1)
 {

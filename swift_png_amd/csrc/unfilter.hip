@@ -246,6 +246,9 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
     // look at the row above (PNG.Decoder.swift:160-168), so a piece may start there as if it were a first
     // row.  Workgroup y owns the rows from the first such row at or after y * sb_rows up to the first one at
     // or after (y + 1) * sb_rows.  (The filter bytes are never written, also when rows are defiltered in place.)
+    // (rows that arrived with a later push, spng_unfilter_resume_batch: the row above the first one was defiltered by an
+    //  earlier call and sits in front of `out`)
+    bool has_top = job.has_prev != 0;
     if (gridDim.y > 1) {
         auto cut = [&](uint64_t x) -> uint32_t {
             if (x == 0) return 0;
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         const uint32_t first = cut((uint64_t)blockIdx.y * sb_rows);
         const uint32_t last = blockIdx.y + 1 == gridDim.y ? rows : cut((uint64_t)(blockIdx.y + 1) * sb_rows);
         if (first >= last) return;
+        if (first) has_top = false;                            // (a piece behind the first starts on a row that looks at nothing above)
         job.in += (uint64_t)first * job.in_stride;
         job.out += (uint64_t)first * job.out_stride;
         rows = last - first;
@@ -284,8 +288,8 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
             R[m] = v;
         }
         Rtop = u32x4{0, 0, 0, 0};
-        if (band && lane < C::CPR)
-            Rtop = load_window_l2(job.out + (uint64_t)(band * 64 - 1) * job.out_stride,
+        if ((band || has_top) && lane < C::CPR)
+            Rtop = load_window_l2(job.out + ((int64_t)band * 64 - 1) * (int64_t)job.out_stride,
                                   (int64_t)T * C::TB + 16 * lane, pitch);
     };
     auto commit = [&]() {

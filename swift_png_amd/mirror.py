@@ -25,14 +25,15 @@ class LZ77:
         Streaming like the original: the compressed bytes pushed so far and the bytes inflated so far stay on the
         device, and a push goes on where the previous one stopped (spng_inflate_resume_batch: blocks the input now
         holds completely are decoded once, by the parallel pipeline; only the block the input ends in is decoded
-        again by the next push).  gzip members (Gzip.Inflator) still re-run from their header."""
+        again by the next push).  gzip members (Gzip.Inflator) too: their few header bytes are parsed again by every
+        push (LZ77.InflatorBuffers.swift:139-230), their DEFLATE payload is not."""
 
         def __init__(self, format=FORMAT_ZLIB, session=None):
             from . import load
             self._s = session or load()
             self._format = format
-            self._streaming = format != FORMAT_GZIP
-            self._in = bytearray()                # gzip only
+            self._streaming = True
+            self._in = bytearray()
             self._d_in, self._n_in = None, 0      # device: all compressed bytes so far
             self._d_out = None                    # device: all inflated bytes so far
             self._state = (0, 0)
@@ -251,19 +252,36 @@ class PNG:
             self._s = session or load()
             self.size, self.depth, self.channels = tuple(size), depth, channels
             self.interlaced, self.standard = bool(interlaced), standard
-            self.storage = bytes(storage_size(size[0], size[1], depth, channels))
+            self._storage_bytes = storage_size(size[0], size[1], depth, channels)
+            self._storage = bytes(self._storage_bytes)
+            self._stale = False                  # the device raster is ahead of the host copy
             self._continue = True                # PNG.Decoder.continue (:22-23)
-            # device state kept between pushes: the IDAT bytes so far, the inflated scanlines so far, the raster
+            # device state kept between pushes: the IDAT bytes so far, the inflated scanlines so far (they are the next
+            # push's LZ77 window: never defiltered in place), the defiltered scanlines of interlaced / sub-byte images, the
+            # raster; and PNG.Decoder.row / pass as the number of inflated bytes already defiltered
             s = self._s
             self._U = inflated_size(size[0], size[1], depth, channels, self.interlaced)
             self._d_idat, self._n_idat = None, 0
             self._d_rows = s.empty(self._U + 64)     # (64 bytes of slack: a little too much data shows as `written > U`)
-            self._d_storage = s.to_device(self.storage) if len(self.storage) else s.empty(1)
+            direct = not self.interlaced and depth * channels >= 8
+            self._d_work = None if direct else s.empty(self._U + 64)
+            self._d_storage = s.to_device(self._storage) if self._storage_bytes else s.empty(1)
             self._state = (0, 0)
+            self._defiltered = 0
+            self.defiltered_total = 0            # scanline bytes handed to the defilter over all pushes (each row once: == U at the end)
+
+        @property
+        def storage(self) -> bytes:
+            """PNG.Image.storage so far (fetched from the device when it is asked for)"""
+            if self._stale:
+                self._storage = bytes(self._d_storage[:self._storage_bytes].cpu().numpy())
+                self._stale = False
+            return self._storage
 
         def push(self, data: bytes):
             """push(data:) (:88-102): one call per IDAT chunk.  The inflate goes on where the previous chunk stopped
-            (spng_inflate_resume_batch); the rows available so far are defiltered into the raster."""
+            (spng_inflate_resume_batch); the scanlines that became complete with this chunk -- and only those -- are defiltered
+            and assigned (spng_unfilter_resume_batch, PNG.Decoder.swift:88-94, 121-135)."""
             from . import raise_for, E_EXTRANEOUS_IMAGE_DATA
             if not self._continue:
                 raise DecodingError(E_EXTRANEOUS_COMPRESSED_DATA)     # PNG.Decoder.swift:51-55
@@ -285,13 +303,15 @@ class PNG:
             raise_for(status, (res.aux[0], res.aux[1]))
             self._state = state
             w, h = self.size
-            # (on a copy: the defilter may reconstruct in place, and the inflated bytes are the next push's window)
-            scratch = self._d_rows.clone()
-            desc = s.image_desc(None, scratch, self._d_storage, w, h, self.depth, self.channels, self.interlaced,
-                                self.standard, rows_cap=scratch.numel())
-            ures = s.unfilter_batch([desc], [res.written])
-            raise_for(ures[0].status, (ures[0].aux[0], ures[0].aux[1]))
-            self.storage = bytes(self._d_storage[:len(self.storage)].cpu().numpy())
+            now = min(res.written, self._U)
+            if now > self._defiltered:
+                desc = s.image_desc(None, self._d_rows, self._d_storage, w, h, self.depth, self.channels, self.interlaced,
+                                    self.standard, rows_cap=self._d_rows.numel())
+                ures = s.unfilter_resume(desc, self._d_work, self._defiltered, now)
+                raise_for(ures.status, (ures.aux[0], ures.aux[1]))
+                self.defiltered_total += ures.written
+                self._defiltered = now
+                self._stale = self._stale or ures.written > 0
             self._continue = status == NEED_MORE_INPUT
 
         def push_ancillary_iend(self):

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import pnghelp as ph
+import swift_png_amd as spng
 from test_oracle_decode import _dynamic_header, _payloads
 
 pytestmark = pytest.mark.gpu
@@ -440,6 +441,55 @@ def test_unpack_rgba_vs_reference_goldens(gpu, name):
     assert hashlib.sha256(got16).hexdigest() == TABLE[name]["rgba16_sha256"], name
     got8 = s.unpack(storage, png.width, png.height, png.depth, png.channels, target=8, **kw)
     assert got8 == (np.frombuffer(got16, dtype="<u2") >> 8).astype(np.uint8).tobytes()
+
+
+IOS_NAMES = sorted(n.split("/", 1)[1] for n in TABLE if n.startswith("ios/"))
+
+
+@pytest.mark.parametrize("name", IOS_NAMES)
+def test_unpack_premultiplied_vs_the_ios_goldens(gpu, name):
+    """f3: RGBA<UInt16>.premultiplied(as: UInt8.self) (PNG.RGBA.swift:146-158) on the device, pinned on the reference's
+    goldens: the iOS set holds CgBI versions of PngSuite images, whose pixels are premultiplied, and the reference compares
+    them with its straight golden premultiplied in 8 bits (Roundtripping.swift:206-215) -- so the COMMON version of the
+    same image, unpacked and premultiplied by the device, must have the digest pngsuite.json keeps for the iOS one."""
+    import struct
+    s = gpu.load()
+    png = ph.parse_png((ph.GOLDEN / "pngsuite" / "common" / name).read_bytes())
+    st, storage, _ = s.decode(png.idat, png.width, png.height, png.depth, png.channels, png.interlaced, png.fmt)
+    assert st == 0
+    key = None
+    if png.trns and png.color in (0, 2):
+        key = struct.unpack(">" + "H" * (1 if png.color == 0 else 3), png.trns[:2 if png.color == 0 else 6])
+    kw = dict(indexed=png.color == 3, palette=_palette_quads(png) if png.color == 3 else None, key=key)
+    got = s.unpack(storage, png.width, png.height, png.depth, png.channels, target=16, premultiply=spng.PREMULTIPLY_AS_U8, **kw)
+    assert hashlib.sha256(got).hexdigest() == TABLE["ios/" + name]["rgba16_sha256"], name
+
+
+@pytest.mark.parametrize("name", sorted(TABLE)[::7])
+def test_unpack_va_and_premultiplied_targets(gpu, name):
+    """f3: PNG.VA<T>.unpack (PNG.VA.swift:184-290: the grey value or the red channel, and alpha) and the .premultiplied
+    forms (PNG.swift:55-66: (c * a + (T.max >> 1)) / T.max) of both targets, against the RGBA<T> pixels the goldens pin."""
+    import struct
+    s = gpu.load()
+    png = ph.parse_png((ph.GOLDEN / "pngsuite" / name).read_bytes())
+    st, storage, _ = s.decode(png.idat, png.width, png.height, png.depth, png.channels, png.interlaced, png.fmt)
+    assert st == 0
+    key = None
+    if png.trns and png.color in (0, 2):
+        key = struct.unpack(">" + "H" * (1 if png.color == 0 else 3), png.trns[:2 if png.color == 0 else 6])
+    kw = dict(indexed=png.color == 3, bgr=png.ios and png.color in (2, 6), palette=_palette_quads(png) if png.color == 3 else None,
+              key=key)
+    args = (storage, png.width, png.height, png.depth, png.channels)
+    for target, dt, tmax in ((16, "<u2", 65535), (8, "u1", 255)):
+        rgba = np.frombuffer(s.unpack(*args, target=target, **kw), dtype=dt).reshape(-1, 4).astype(np.uint64)
+        va = np.frombuffer(s.unpack(*args, target=target, layout=spng.TARGET_VA, **kw), dtype=dt).reshape(-1, 2)
+        assert (va[:, 0] == rgba[:, 0]).all() and (va[:, 1] == rgba[:, 3]).all()
+        pre = np.frombuffer(s.unpack(*args, target=target, premultiply=spng.PREMULTIPLY, **kw), dtype=dt).reshape(-1, 4)
+        want = rgba.copy()
+        want[:, :3] = (rgba[:, :3] * rgba[:, 3:4] + (tmax >> 1)) // tmax
+        assert (pre == want).all()
+        vap = np.frombuffer(s.unpack(*args, target=target, layout=spng.TARGET_VA, premultiply=spng.PREMULTIPLY, **kw), dtype=dt).reshape(-1, 2)
+        assert (vap[:, 0] == want[:, 0]).all() and (vap[:, 1] == want[:, 3]).all()
 
 
 # ------------------------------------------------------------------------------------------ deflate

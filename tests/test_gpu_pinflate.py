@@ -140,10 +140,13 @@ def test_damaged_streams_cost_one_block_not_the_batch(gpu):
         assert s.lib.spng_inflate_batch(s.ctx, descs, n, None, res) == 0              # warm-up (pool sizing)
         torch.cuda.synchronize()
         best = 1e9
+        s.profile(True)
         for _ in range(3):
             t0 = time.perf_counter()
             assert s.lib.spng_inflate_batch(s.ctx, descs, n, None, res) == 0
             best = min(best, time.perf_counter() - t0)
+        print({k: round(s.profile_get(getattr(spng, "K_" + k))[0] / 3, 2) for k in ("PINF_FIND", "PINF_DECODE", "PINF_RESOLVE", "INFLATE")})
+        s.profile(False)
         return best, list(res)
 
     clean = [good[i % 2] for i in range(n)]
