@@ -498,4 +498,4 @@ class Session:
         return out.value
 
 
-from .mirror import LZ77, PNG  # noqa: E402,F401
+from .mirror import LZ77, PNG, Gzip  # noqa: E402,F401

@@ -1000,7 +1000,10 @@ __global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ st
 {
     const int lane = threadIdx.x;
     PStream &st = streams[blockIdx.x];
-    if (retry && UNI(st.pass) != 1) return;
+    if (retry && UNI(st.pass) != 1) {
+        if (lane == 0) st.ok = 0;                               // (resolved, or given up, by the first pass: not again)
+        return;
+    }
     const uint32_t first = UNI(st.seg_first), count = UNI(st.seg_count);
     bool ok = false, partial = false, dry = false;
     uint64_t tok = 0, end_bit = 0;

@@ -148,7 +148,11 @@ def test_resume_argument_checks(gpu):
     with pytest.raises(spng.SpngError):
         s.inflate_resume(d_in, len(z), d_out, spng.FORMAT_ZLIB, (len(z) * 8 + 1, 0))
     with pytest.raises(spng.SpngError):
-        s.inflate_resume(d_in, len(z), d_out, spng.FORMAT_GZIP, (0, 0))
+        s.inflate_resume(d_in, len(z), d_out, spng.FORMAT_GZIP + 1, (0, 0))
+    with pytest.raises(spng.SpngError):
+        s.inflate_resume(d_in, len(z), d_out, spng.FORMAT_ZLIB, (0, 4097))           # (more output than the buffer holds)
+    res, _ = s.inflate_resume(d_in, len(z), d_out, spng.FORMAT_GZIP, (0, 0))         # a zlib stream is no gzip member
+    assert res.status == spng.E_GZIP_SIGIL
     res, _ = s.inflate_resume(d_in, len(z), d_out, spng.FORMAT_ZLIB, (0, 0))
     assert res.status == 0 and bytes(d_out[:300].cpu().numpy()) == b"abc" * 100
 
