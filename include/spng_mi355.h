@@ -130,8 +130,12 @@ enum { SPNG_CFG_INFLATE_MODE = 0,   /* SPNG_INFLATE_AUTO: parallel pipeline, ser
        SPNG_CFG_SEGMENT_BYTES = 1,  /* parallel inflate: nominal segment length in compressed bytes */
        SPNG_CFG_TOKEN_BYTES = 2,    /* parallel inflate: size limit of the token page pool in bytes */
        SPNG_CFG_UNFILTER_PIECE_ROWS = 3,   /* unfilter: rows per piece a scanline chain is cut into */
-       SPNG_CFG_COUNT = 4 };
+       SPNG_CFG_INFLATE_OVERLAP = 4,       /* parallel inflate: SPNG_OVERLAP_ALWAYS = every batch of >= 2 streams in two halves
+                                              on two streams, the decode of one beside the resolve of the other
+                                              (an experiment: slower than one pass on MI355X, so never by default) */
+       SPNG_CFG_COUNT = 5 };
 enum { SPNG_INFLATE_AUTO = 0, SPNG_INFLATE_SERIAL = 1 };
+enum { SPNG_OVERLAP_AUTO = 0, SPNG_OVERLAP_ALWAYS = 1, SPNG_OVERLAP_NEVER = 2 };
 int32_t spng_configure(spng_ctx *ctx, int key, int64_t value);
 
 /* Per-kernel timing with HIP events recorded on the context's stream around every launch. */

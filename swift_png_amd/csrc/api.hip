@@ -83,7 +83,10 @@ struct spng_ctx {
     uint32_t *h_pool_used = nullptr;
     uint64_t pool_pages_planned = 0, pool_src_bytes = 0;
     hipEvent_t pool_ev = nullptr; bool pool_pending = false;
-    int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0, 0};
+    // second stream of the pipeline: the decode of one half of a batch runs beside the resolve of the other
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
+    int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0, 0, 0};
     // profiling
     bool profiling = false;
     struct Span { int kernel; hipEvent_t a, b; };
@@ -135,9 +138,9 @@ struct spng_ctx {
 };
 
 struct Timed {            // records a pair of events around a launch when profiling is on
-    spng_ctx *c; int k; hipEvent_t a = nullptr;
-    Timed(spng_ctx *c_, int k_) : c(c_), k(k_) { if (c->profiling) { a = c->event(); (void)hipEventRecord(a, c->stream); } }
-    ~Timed() { if (a) { hipEvent_t b = c->event(); (void)hipEventRecord(b, c->stream); c->spans.push_back({k, a, b}); } }
+    spng_ctx *c; int k; hipEvent_t a = nullptr; hipStream_t s;
+    Timed(spng_ctx *c_, int k_, hipStream_t s_ = nullptr) : c(c_), k(k_), s(s_ ? s_ : c_->stream) { if (c->profiling) { a = c->event(); (void)hipEventRecord(a, s); } }
+    ~Timed() { if (a) { hipEvent_t b = c->event(); (void)hipEventRecord(b, s); c->spans.push_back({k, a, b}); } }
 };
 
 // simple bump allocator over the paired pinned/device workspaces
@@ -249,6 +252,8 @@ void spng_destroy(spng_ctx *c)
     if (c->d_tok) (void)hipFree(c->d_tok);
     if (c->h_pool_used) (void)hipHostFree(c->h_pool_used);
     if (c->pool_ev) (void)hipEventDestroy(c->pool_ev);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    for (hipEvent_t e : {c->ev_fork, c->ev_mid, c->ev_join}) if (e) (void)hipEventDestroy(e);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -450,8 +455,9 @@ struct InflatePlan {
     bool parallel = false;
     // pinflate2: the token pool and the groups of streams that share it, one after the other
     uint32_t pool_pages = 0;
-    struct Group { uint32_t s0, s1, g0, g1; };
+    struct Group { uint32_t s0, s1, g0, g1, page0, pages; };   // streams, segments, its pages of the pool
     std::vector<Group> groups;
+    bool overlap = false;            // two groups, each with its own half of the pool, on two streams (see launch_inflate_plan)
     size_t next_at = 0;
     bool gzip = false;               // some stream is SPNG_FORMAT_GZIP: header kernel in front, CRC-32 check behind
     std::vector<uint64_t> state;     // {bit, written} per stream: spng_inflate_resume_batch's, else the library's own zeros
@@ -503,8 +509,8 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
     }
     if (c->pool_pending && hipEventQuery(c->pool_ev) == hipSuccess) {
         c->pool_pending = false;
-        const uint64_t used = c->h_pool_used[1];
-        if (c->h_pool_used[2]) c->pool_ratio = 0;                                   // it ran dry: back to the default
+        const uint64_t used = c->h_pool_used[0];
+        if (c->h_pool_used[1]) c->pool_ratio = 0;                                   // it ran dry: back to the default
         else if (c->pool_src_bytes > (1u << 20)) c->pool_ratio = (double)used * 65536.0 / (double)c->pool_src_bytes;
     }
     const double per_byte = c->pool_ratio > 0 ? (c->pool_ratio * 1.25 < 1.0 ? 1.0 : c->pool_ratio * 1.25) : 3.2;
@@ -576,7 +582,7 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
     const uint64_t pool = c->tok_cap & ~(uint64_t)65535;
     p.pool_pages = (uint32_t)(pool >> 16 > 0xfffffff0ull ? 0xfffffff0ull : pool >> 16);
     uint64_t run = 0;
-    InflatePlan::Group g{0, 0, 0, 0};
+    InflatePlan::Group g{0, 0, 0, 0, 0, p.pool_pages};
     for (size_t i = 0; i < p.jobs.size(); ++i) {
         if (run + est[i] > pool && g.s1 > g.s0) {
             p.groups.push_back(g);
@@ -586,6 +592,29 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         g.s1 = (uint32_t)i + 1; g.g1 = p.streams[i].seg_first + p.streams[i].seg_count;
     }
     p.groups.push_back(g);
+    // On request (SPNG_CFG_INFLATE_OVERLAP) a batch that fits the pool at once goes in two halves, each with its share of
+    // the pool, the decode of the second beside the resolve of the first on a second stream.  Not by default: both
+    // kernels live on LDS (14 x 11 KB decode waves or 2 x 61 KB resolve workgroups fill a CU), so side by side they
+    // only displace each other -- 1024 x 4K images: 635 ms per step instead of 526 (profiles/r03_inflate_tuning.md).
+    const int64_t ovl = c->cfg[SPNG_CFG_INFLATE_OVERLAP];
+    if (p.groups.size() == 1 && p.jobs.size() >= 2 && ovl == SPNG_OVERLAP_ALWAYS) {
+        uint64_t half = 0, sum = 0;
+        size_t cut = 0;
+        for (auto e : est) sum += e;
+        while (cut + 1 < p.jobs.size() && 2 * (half + est[cut]) <= sum + est[cut]) half += est[cut++];
+        if (cut >= 1 && cut < p.jobs.size()) {
+            InflatePlan::Group a = p.groups[0], b = p.groups[0];
+            a.s1 = b.s0 = (uint32_t)cut;
+            a.g1 = b.g0 = p.streams[cut].seg_first;
+            uint64_t pa = (uint64_t)((double)p.pool_pages * ((double)half / (double)sum));
+            if (pa < 1) pa = 1;
+            if (pa >= p.pool_pages) pa = p.pool_pages - 1;
+            a.page0 = 0; a.pages = (uint32_t)pa;
+            b.page0 = (uint32_t)pa; b.pages = p.pool_pages - (uint32_t)pa;
+            p.groups = {a, b};
+            p.overlap = true;
+        }
+    }
     c->pool_pages_planned = p.pool_pages;
     c->pool_src_bytes = total;
     if (!c->h_pool_used) {
@@ -638,20 +667,40 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
         int32_t *dd = a.dev<int32_t>(p.done_at);
         uint32_t *dnext = a.dev<uint32_t>(p.next_at);
         // every group of streams in turn, then once more those whose segments found the pool empty (a batch unlike the
-        // one the pool was sized by): they get a second pass instead of the serial kernel
+        // one the pool was sized by): they get a second pass instead of the serial kernel.  Two overlapping groups: the
+        // first on the context's stream, the second on stream2 with its decode held back until the first one's is done
+        // (the two decodes side by side would only share the issue slots; decode beside resolve fills what either leaves).
+        if (p.overlap && !c->stream2) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            for (hipEvent_t *e : {&c->ev_fork, &c->ev_mid, &c->ev_join}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        if (p.overlap) {
+            HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        }
         for (size_t gi = 0; gi <= p.groups.size(); ++gi) {
             const bool retry = gi == p.groups.size();
-            const InflatePlan::Group g = retry ? InflatePlan::Group{0, n, 0, (uint32_t)p.segs.size()} : p.groups[gi];
-            if (gi) HIP_TRY(hipMemsetAsync(dnext, 0, 4, c->stream));
-            { Timed t(c, SPNG_K_PINF_FIND); HIP_TRY(launch_pinf2_find(ds, dg, g.g0, g.g1 - g.g0, retry, c->stream)); }
-            { Timed t(c, SPNG_K_PINF_DECODE); HIP_TRY(launch_pinf2_decode(ds, dg, g.g0, g.g1 - g.g0, (uint32_t *)c->d_log, (uint8_t *)c->d_tok, dnext, p.pool_pages, retry, c->stream)); }
-            HIP_TRY(launch_pinf2_scan(ds + g.s0, g.s1 - g.s0, dg, retry, c->stream));
-            { Timed t(c, SPNG_K_PINF_RESOLVE); HIP_TRY(launch_pinf2_resolve(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, (uint8_t *)c->d_tok, p.pool_pages, dr, dd + g.s0, retry, c->stream)); }
-            HIP_TRY(launch_pinf2_account(dnext, p.pool_pages, c->stream));
+            const InflatePlan::Group g = retry ? InflatePlan::Group{0, n, 0, (uint32_t)p.segs.size(), 0, p.pool_pages} : p.groups[gi];
+            const bool second = p.overlap && gi == 1;
+            hipStream_t q = second ? c->stream2 : c->stream;
+            uint32_t *ctr = dnext + 4 * (second ? 1 : 0);       // {page counter} of the pass; dnext[8 ..] = the batch's totals
+            uint8_t *pool = (uint8_t *)c->d_tok + ((uint64_t)g.page0 << 16);
+            if (p.overlap && retry) {
+                HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+                HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            }
+            if (gi && !second) HIP_TRY(hipMemsetAsync(ctr, 0, 4, q));
+            { Timed t(c, SPNG_K_PINF_FIND, q); HIP_TRY(launch_pinf2_find(ds, dg, g.g0, g.g1 - g.g0, retry, q)); }
+            if (second) HIP_TRY(hipStreamWaitEvent(q, c->ev_mid, 0));
+            { Timed t(c, SPNG_K_PINF_DECODE, q); HIP_TRY(launch_pinf2_decode(ds, dg, g.g0, g.g1 - g.g0, (uint32_t *)c->d_log, pool, ctr, g.pages, retry, q)); }
+            if (p.overlap && gi == 0) HIP_TRY(hipEventRecord(c->ev_mid, q));
+            HIP_TRY(launch_pinf2_scan(ds + g.s0, g.s1 - g.s0, dg, retry, q));
+            { Timed t(c, SPNG_K_PINF_RESOLVE, q); HIP_TRY(launch_pinf2_resolve(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, pool, g.pages, dr, dd + g.s0, retry, q)); }
+            HIP_TRY(launch_pinf2_account(ctr, dnext + 8, g.pages, q));
         }
         if (!c->pool_pending) {
             // pages this batch took: read at the start of the next one (never waited for)
-            HIP_TRY(hipMemcpyAsync(c->h_pool_used, dnext, 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->h_pool_used, dnext + 8, 16, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipEventRecord(c->pool_ev, c->stream));
             c->pool_pending = true;
         }

@@ -161,7 +161,7 @@ hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t seg0, 
 hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t retry, hipStream_t stream);
 hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
                                 spng_result *d_results, int32_t *d_done, uint32_t retry, hipStream_t stream);
-hipError_t launch_pinf2_account(uint32_t *d_ctr, uint32_t pages, hipStream_t stream);
+hipError_t launch_pinf2_account(const uint32_t *d_ctr, uint32_t *d_totals, uint32_t pages, hipStream_t stream);
 hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 // gzip.hip
 static constexpr uint64_t GZ_NONE = ~0ull;

@@ -57,6 +57,9 @@ typedef uint8_t AS_GLOBAL g8;
 typedef uint16_t AS_GLOBAL g16;
 typedef uint32_t AS_GLOBAL g32;
 typedef PV4 AS_GLOBAL gPV4;
+typedef uint32_t v2u __attribute__((vector_size(8)));
+struct __attribute__((packed)) PV2 { v2u v; };
+typedef PV2 AS_GLOBAL gPV2;
 
 static constexpr int LB = 9, DB = 8, MB = 7;         // LUT index bits: lit/len, distance, code-length code
 static constexpr int SDW_MAX = 9;                      // dwords per lane subsequence (odd: conflict-free LDS stride)
@@ -1028,8 +1031,16 @@ __global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ st
 }
 
 // ---- resolve: tokens -> bytes -------------------------------------------------------------------------------
-static constexpr uint32_t RT2 = 512;                 // threads per stream
-static constexpr uint32_t TILE2 = 8192;              // output bytes resolved per step (16 per thread)
+#ifndef SPNG_R_THREADS
+#define SPNG_R_THREADS 512        // (1024 threads, two workgroups per CU: 213 ms instead of 202 per 1024 x 64 MiB)
+#define SPNG_R_WAVES 4
+#endif
+static constexpr uint32_t RT2 = SPNG_R_THREADS;      // threads per stream
+static constexpr uint32_t NW2 = RT2 / 64;            // (waves)
+static constexpr uint32_t TILE2 = 8192;              // output bytes resolved per step
+static constexpr uint32_t BPT2 = TILE2 / RT2;        // of them per thread: byte j of the tile belongs to thread j mod RT2
+static constexpr uint32_t HPT2 = 4096 / RT2;         // token halfwords per thread in a window of 4096
+static constexpr uint32_t EB2 = BPT2 < 8 ? BPT2 : 8; // bytes of a thread expanded together
 static constexpr uint32_t MAXM2 = 1024;              // back-references per tile
 static constexpr uint32_t WINDOW2 = 32768;           // the DEFLATE window
 static constexpr uint32_t R2_DONE = 0x8000;          // state: R2_DONE | byte, or the tile index of an earlier byte
@@ -1042,27 +1053,32 @@ struct RLds2 {
     uint32_t bitmap[TILE2 / 32];       // their first bytes
     uint16_t h0[RT2 + 8];              // every thread's first halfword (the second half of its neighbour's last reference)
     uint32_t pt[PTC];
-    uint32_t part[40];
+    uint32_t part[3 * NW2];
     uint32_t again[3];                 // pointer jumping: somebody still has an unknown byte (flag of round r: r mod 3)
+    uint32_t cut[2];                   // where the tile ends when the window holds more than a tile: bytes, halfword
 };
 
-// exclusive prefix sum over the workgroup (8 waves); every thread gets the grand total too
+// exclusive prefix sum over the workgroup; every thread gets the grand total too.  One barrier: s.part is not touched
+// again before the next barrier of the caller.
 __device__ __forceinline__ uint32_t block_excl_scan2(RLds2 &s, uint32_t v, uint32_t &total, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t wt;
     const uint32_t off = wave_excl_scan(v, wt, lane);
-    __syncthreads();
     if (lane == 0) s.part[wave] = wt;
     __syncthreads();
     uint32_t before = 0, all = 0;
 #pragma unroll
-    for (int w = 0; w < (int)(RT2 / 64); ++w) { const uint32_t p = s.part[w]; before += w < wave ? p : 0u; all += p; }
+    for (int w4 = 0; w4 < (int)NW2; w4 += 4) {
+        const v4u p = *(const v4u *)(s.part + w4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { before += w4 + c < wave ? p[c] : 0u; all += p[c]; }
+    }
     total = all;
     return off + before;
 }
 
-__global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__restrict__ streams, const PSeg *__restrict__ segs,
+__global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const PStream *__restrict__ streams, const PSeg *__restrict__ segs,
                                                                const uint32_t *__restrict__ pt_slab, DPool pool,
                                                                spng_result *__restrict__ results, int32_t *__restrict__ done, uint32_t retry)
 {
@@ -1076,6 +1092,7 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
     const uint64_t n = uni64(st.src_len);
     uint64_t pos = uni64(st.out_pos);                  // (resumable streams: the bytes earlier calls produced are in dst)
     uint32_t accS = 0, accI = 0;                     // Adler-32 partial sums (inflate.hip: struct Out)
+    uint32_t pmod = (uint32_t)(pos % 65521);          // pos mod 65521, kept along
     bool bad = false, over = false;
     uint64_t *state = (uint64_t *)uni64((uint64_t)st.state);
     if (pos) {
@@ -1095,6 +1112,7 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
 #define RP2(k)
 #define RPN2(k, v)
 #endif
+    constexpr uint32_t NULL2 = TK_NULL | TK_NULL << 16;
     for (uint32_t hops = 0; hops < seg_count && !over; ++hops) {
         const PSeg &sg = segs[seg_first + sk];
         const uint64_t nhw = uni64(sg.ntok);
@@ -1105,111 +1123,107 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
         __syncthreads();
         for (uint32_t i = (uint32_t)tid; i < PTC; i += RT2) s.pt[i] = (pt_lo + i) * PAGE_UNITS * 8 < nhw + 8 ? ptg[pt_lo + i] : 0u;
         __syncthreads();
-        // a thread's unit of the token window that starts at halfword `from`
-        auto load_unit = [&](uint64_t from) -> v4u {
-            const uint64_t u = (from >> 3) + (uint32_t)tid;
-            v4u v = {TK_NULL | TK_NULL << 16, TK_NULL | TK_NULL << 16, TK_NULL | TK_NULL << 16, TK_NULL | TK_NULL << 16};
-            if (u * 8 < nhw) {
+        // a thread's HPT2 halfwords of the token window that holds halfword `from` (windows start on multiples of HPT2)
+        uint32_t tv[HPT2 / 2];
+        auto load_window = [&](uint64_t from) {
+            const uint64_t h = (from & ~(uint64_t)(HPT2 - 1)) + (uint64_t)tid * HPT2;
+#pragma unroll
+            for (int k = 0; k < (int)(HPT2 / 2); ++k) tv[k] = NULL2;
+            if (h < nhw) {
+                const uint64_t u = h >> 3;
                 const uint32_t pid = s.pt[(u >> (PAGE_SHIFT - 4)) - pt_lo];
-                v = ((const gPV4 *)((const g8 *)pool.base + ((uint64_t)pid << PAGE_SHIFT) + ((u & (PAGE_UNITS - 1)) << 4)))->v;
+                const g8 *q = (const g8 *)pool.base + ((uint64_t)pid << PAGE_SHIFT) + ((u & (PAGE_UNITS - 1)) << 4) + ((h & 7) << 1);
+                if constexpr (HPT2 == 8) { const v4u v = ((const gPV4 *)q)->v; tv[0] = v[0]; tv[1] = v[1]; tv[2] = v[2]; tv[3] = v[3]; }
+                else { const v2u v = ((const gPV2 *)q)->v; tv[0] = v[0]; tv[1] = v[1]; }
             }
-            return v;
         };
-        v4u tv = load_unit(0);
+        load_window(0);
         while (cursor < nhw) {
             RP2(0);
-            // ---- the window: eight halfwords per thread
-            const uint64_t ub = cursor >> 3;
-            const uint32_t hskip = (uint32_t)(cursor & 7);
-            uint32_t hh[8];
+            // ---- the window: HPT2 halfwords per thread (a window starts on a multiple of HPT2: see the cut below)
+            const uint64_t wb = cursor;
+            uint32_t hh[HPT2];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t idx = (uint32_t)tid * 8 + j;
+            for (int j = 0; j < (int)HPT2; ++j) {
+                const uint32_t idx = (uint32_t)tid * HPT2 + j;
                 const uint32_t v = (tv[j >> 1] >> (16 * (j & 1))) & 0xffff;
-                hh[j] = (idx >= hskip && ub * 8 + idx < nhw) ? v : TK_NULL;
+                hh[j] = wb + idx < nhw ? v : TK_NULL;
             }
             s.h0[tid] = (uint16_t)hh[0];
+            if (tid == 0) s.cut[1] = 0xffffffffu;                  // (read behind the take's barrier of the tile before)
             uint32_t bytes = 0, refs = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < (int)HPT2; ++j) {
                 const uint32_t v = hh[j];
                 const bool lit = !(v & 0x8000), m0 = (v & 0xC000) == 0x8000;
                 bytes += lit ? 1u : m0 ? (v & 0xff) + 3 : 0u;
                 refs += m0 ? 1u : 0u;
             }
             uint32_t total;
-            const uint32_t offp = block_excl_scan2(s, refs << 20 | bytes, total, tid);      // (barriers inside: h0 is visible)
+            const uint32_t offp = block_excl_scan2(s, refs << 20 | bytes, total, tid);      // (barrier inside: h0 is visible)
             RP2(1);
+            // take tokens while the tile has room, a thread's all or none: the totals in front of a thread never
+            // decrease, so the threads that fit are the first F, and thread F -- the one that does not fit although
+            // everything in front of it does -- says where the tile ends (nobody: the whole window fits).  The last
+            // thread also stays out when its last halfword is the first half of a back-reference.
             uint32_t curb = offp & 0xfffff, curm = offp >> 20;
             const uint32_t hnext = tid + 1 < (int)RT2 ? s.h0[tid + 1] : TK_NULL;
-            // take tokens while the tile has room
-            uint32_t taken = 0, stop = 0xffffffffu;
+            const bool front = curb <= TILE2 && curm <= MAXM2;
+            const bool fits = curb + bytes <= TILE2 && curm + refs <= MAXM2 &&
+                              !(tid == (int)RT2 - 1 && (hh[HPT2 - 1] & 0xC000) == 0x8000);
+            if (front && !fits) { s.cut[0] = curb; s.cut[1] = (uint32_t)tid * HPT2; }
+            if (fits) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t v = hh[j];
-                const bool lit = !(v & 0x8000), m0 = (v & 0xC000) == 0x8000;
-                if (lit || m0) {
-                    const uint32_t len = lit ? 1u : (v & 0xff) + 3;
-                    const bool fits = curb + len <= TILE2 && curm + (m0 ? 1u : 0u) <= MAXM2 && !(m0 && j == 7 && tid == (int)RT2 - 1);
-                    if (fits) {
-                        if (lit) s.state[curb] = (uint16_t)(R2_DONE | v);
-                        else {
-                            const uint32_t h1 = j < 7 ? hh[j < 7 ? j + 1 : 7] : hnext;
-                            const uint32_t dd = (((v >> 8) & 63) | (h1 & 0x1ff) << 6) + 1;
-                            atomicOr(&s.bitmap[curb >> 5], 1u << (curb & 31));
-                            s.rec[curm][0] = curb | len << 16;
-                            s.rec[curm][1] = dd;
-                        }
-                        taken += len;
-                    } else if (stop == 0xffffffffu) stop = (uint32_t)tid * 8 + j;
-                    curb += len; curm += m0 ? 1u : 0u;
+                for (int j = 0; j < (int)HPT2; ++j) {
+                    const uint32_t v = hh[j];
+                    if (!(v & 0x8000)) { s.state[curb] = (uint16_t)(R2_DONE | v); curb += 1; }
+                    else if ((v & 0xC000) == 0x8000) {
+                        const uint32_t len = (v & 0xff) + 3;
+                        const uint32_t h1 = j < (int)HPT2 - 1 ? hh[j < (int)HPT2 - 1 ? j + 1 : (int)HPT2 - 1] : hnext;
+                        const uint32_t dd = (((v >> 8) & 63) | (h1 & 0x1ff) << 6) + 1;
+                        atomicOr(&s.bitmap[curb >> 5], 1u << (curb & 31));
+                        s.rec[curm][0] = curb | len << 16;
+                        s.rec[curm][1] = dd;
+                        curb += len; curm += 1;
+                    }
                 }
             }
-            // bytes taken, first halfword left
-            {
-                const uint32_t wt = wave_sum(taken);
-                uint32_t ws = stop;
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)ws, m, 64); ws = o < ws ? o : ws; }
-                if (lane == 0) { s.part[16 + wave] = wt; s.part[24 + wave] = ws; }
-            }
             __syncthreads();
-            uint32_t tlen = 0, stopall = 0xffffffffu;
-#pragma unroll
-            for (int w = 0; w < (int)(RT2 / 64); ++w) { tlen += s.part[16 + w]; const uint32_t o = s.part[24 + w]; stopall = o < stopall ? o : stopall; }
-            const uint64_t wend = nhw - ub * 8 < (uint64_t)RT2 * 8 ? nhw - ub * 8 : (uint64_t)RT2 * 8;      // window end (halfwords from ub * 8)
-            const uint32_t wlast = stopall != 0xffffffffu ? stopall : (uint32_t)wend;
+            const uint32_t cut0 = s.cut[0], cut1 = s.cut[1];
+            const uint64_t wend = nhw - wb < (uint64_t)RT2 * HPT2 ? nhw - wb : (uint64_t)RT2 * HPT2;      // window end (halfwords from wb)
+            const uint32_t tlen = cut1 != 0xffffffffu ? cut0 : total & 0xfffff;
+            const uint32_t wlast = cut1 != 0xffffffffu ? cut1 : (uint32_t)wend;
             if (pos + tlen > cap) { over = true; break; }
             // the next window travels while this tile is resolved
-            const uint64_t cursor_next = ub * 8 + wlast;
-            if ((((cursor_next >> 3) + 2 * RT2) >> (PAGE_SHIFT - 4)) >= pt_lo + PTC) {
+            const uint64_t cursor_next = wb + wlast;
+            if ((((cursor_next + 2 * RT2 * HPT2) >> 3) >> (PAGE_SHIFT - 4)) >= pt_lo + PTC) {
                 __syncthreads();
                 pt_lo = (cursor_next >> 3) >> (PAGE_SHIFT - 4);     // page of the next window's first unit
                 for (uint32_t i = (uint32_t)tid; i < PTC; i += RT2) s.pt[i] = (pt_lo + i) * PAGE_UNITS * 8 < nhw + 8 ? ptg[pt_lo + i] : 0u;
                 __syncthreads();
             }
-            tv = load_unit(cursor_next);
+            load_window(cursor_next);
             RP2(2);
             // ---- expand: the reference (if any) that covers each of my bytes
             const uint32_t rbase = (uint32_t)pos & (WINDOW2 - 1);
-            uint32_t sv[16];
+            uint32_t sv[BPT2];
             {
                 // back-references that start in front of each row: prefix sum over the bitmap (lane l: rows 2l, 2l + 1)
                 const v4u bw = *(const v4u *)(s.bitmap + 4 * lane);
                 const uint32_t ca = (uint32_t)__popc(bw[0]) + (uint32_t)__popc(bw[1]), cbb = (uint32_t)__popc(bw[2]) + (uint32_t)__popc(bw[3]);
                 uint32_t tt;
                 const uint32_t rb = wave_excl_scan(ca + cbb, tt, lane);
-                // (row = wave + 8 k: its parity is the wave's)
+                // (row = wave + NW2 k: its parity is the wave's)
                 const bool odd = wave & 1;
                 const uint32_t srclo = odd ? bw[2] : bw[0], srchi = odd ? bw[3] : bw[1], srcbase = odd ? rb + ca : rb;
-                // eight rows at a time, so that the record reads and then the ring reads of a batch travel together
+                // EB2 rows at a time, so that the record reads and then the ring reads of a batch travel together
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    uint32_t r0v[8], r1v[8];
+                for (int part = 0; part < (int)(BPT2 / EB2); ++part) {
+                    uint32_t r0v[EB2], r1v[EB2];
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const int k = half * 8 + kk;
-                        const uint32_t row = (uint32_t)wave + 8u * k;
+                    for (int kk = 0; kk < (int)EB2; ++kk) {
+                        const int k = part * (int)EB2 + kk;
+                        const uint32_t row = (uint32_t)wave + NW2 * k;
                         const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)srclo, (int)(row >> 1));
                         const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)srchi, (int)(row >> 1));
                         const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)srcbase, (int)(row >> 1));
@@ -1218,25 +1232,25 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
                         r0v[kk] = id ? s.rec[id - 1][0] : 0u;          // (no reference in front of this byte: run 0)
                         r1v[kk] = id ? s.rec[id - 1][1] : 1u;
                     }
-                    uint32_t siv[8], farv[8];
+                    uint32_t siv[EB2], farv[EB2];
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const int k = half * 8 + kk;
-                        const uint32_t j = ((uint32_t)wave + 8u * k) * 64 + (uint32_t)lane;
+                    for (int kk = 0; kk < (int)EB2; ++kk) {
+                        const int k = part * (int)EB2 + kk;
+                        const uint32_t j = ((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane;
                         const uint32_t startb = r0v[kk] & 0xffff, len = r0v[kk] >> 16, d = r1v[kk];
                         uint32_t kk2 = j - startb;
                         const bool inside = kk2 < len && j < tlen;
                         // A run longer than its distance repeats its first `distance` bytes: a byte beyond the first
                         // period copies the period in front of the run (same value, chain one level deep instead of
                         // run / distance levels).
-                        if (inside && kk2 >= d) kk2 -= d * (uint32_t)__fdividef((float)kk2 + 0.5f, (float)d);     // kk2 mod d, kk2 < 258
+                        if (inside && kk2 >= d) kk2 -= d * (uint32_t)(((float)kk2 + 0.5f) * __builtin_amdgcn_rcpf((float)d));   // kk2 mod d (kk2 < 258: the quotient is exact)
                         siv[kk] = inside ? startb - d + kk2 : 0x7fffffffu;                     // >= 0x80000000: before the tile
                         farv[kk] = s.ring[(rbase + siv[kk]) & (WINDOW2 - 1)];
                     }
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const int k = half * 8 + kk;
-                        const uint32_t j = ((uint32_t)wave + 8u * k) * 64 + (uint32_t)lane;
+                    for (int kk = 0; kk < (int)EB2; ++kk) {
+                        const int k = part * (int)EB2 + kk;
+                        const uint32_t j = ((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane;
                         const uint32_t si = siv[kk];
                         sv[k] = R2_DONE;
                         if (si != 0x7fffffffu) {
@@ -1251,15 +1265,17 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
             __syncthreads();
             RP2(3);
             if (tid < (int)(TILE2 / 32)) s.bitmap[tid] = 0;          // (read above; next written after the next scan's barriers)
-            // ---- pointer jumping
+            // ---- pointer jumping: all of a thread's reads of a round travel together
             for (uint32_t round = 0;; ++round) {
                 bool more = false;
+                uint32_t gv[BPT2];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
+                for (int k = 0; k < (int)BPT2; ++k) { gv[k] = R2_DONE; if (!(sv[k] & R2_DONE)) gv[k] = s.state[sv[k]]; }
+#pragma unroll
+                for (int k = 0; k < (int)BPT2; ++k) {
                     if (!(sv[k] & R2_DONE)) {
-                        const uint32_t j = ((uint32_t)wave + 8u * k) * 64 + (uint32_t)lane;
-                        const uint32_t g = s.state[sv[k]];
-                        sv[k] = g; s.state[j] = (uint16_t)g; more = more || !(g & R2_DONE);
+                        const uint32_t j = ((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane;
+                        sv[k] = gv[k]; s.state[j] = (uint16_t)gv[k]; more = more || !(gv[k] & R2_DONE);
                     }
                 }
                 // one barrier per round.  Three flags in rotation: the one cleared here was last read before
@@ -1274,10 +1290,15 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
             }
             RP2(4);
             // ---- the bytes: into the ring, then to the output in whole 16-byte units of the position
+            {
+                uint32_t bv[BPT2];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t j = ((uint32_t)wave + 8u * k) * 64 + (uint32_t)lane;
-                if (j < tlen) s.ring[(rbase + j) & (WINDOW2 - 1)] = (uint8_t)s.state[j];
+                for (int k = 0; k < (int)BPT2; ++k) bv[k] = s.state[((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane];
+#pragma unroll
+                for (int k = 0; k < (int)BPT2; ++k) {
+                    const uint32_t j = ((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane;
+                    if (j < tlen) s.ring[(rbase + j) & (WINDOW2 - 1)] = (uint8_t)bv[k];
+                }
             }
             __syncthreads();
             {
@@ -1292,12 +1313,14 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
                     J = __builtin_amdgcn_udot4(v[1], 0x07060504u, J, false);
                     J = __builtin_amdgcn_udot4(v[2], 0x0b0a0908u, J, false);
                     J = __builtin_amdgcn_udot4(v[3], 0x0f0e0d0cu, J, false);
-                    const uint32_t g = (uint32_t)((u << 4) % 65521);
-                    accS = (accS + A) % 65521;
-                    accI = (uint32_t)((accI + (uint64_t)g * A + J) % 65521);
+                    // (position of the unit mod 65521, from the tile's: 32-bit arithmetic; g * A < 2^29)
+                    const uint32_t g = (pmod + 65521u - ((uint32_t)pos & 15u) + 16u * (uint32_t)(u - u0)) % 65521u;
+                    accS = (accS + A) % 65521u;
+                    accI = (accI + g * A + J) % 65521u;
                 }
             }
             pos += tlen;
+            pmod = (pmod + tlen) % 65521u;
             cursor = cursor_next;
             RP2(5);
             RPN2(8, 1); RPN2(10, tlen);
@@ -1328,10 +1351,10 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
         // S = sum b_i, I = sum i * b_i (mod 65521) over the workgroup
         const uint32_t S1 = wave_sum(accS) % 65521, I1 = wave_sum(accI % 65521) % 65521;
         __syncthreads();
-        if (lane == 0) { s.part[wave] = S1; s.part[8 + wave] = I1; }
+        if (lane == 0) { s.part[wave] = S1; s.part[NW2 + wave] = I1; }
         __syncthreads();
         uint32_t S = 0, I = 0;
-        for (int w = 0; w < (int)(RT2 / 64); ++w) { S += s.part[w]; I += s.part[8 + w]; }
+        for (int w = 0; w < (int)NW2; ++w) { S += s.part[w]; I += s.part[NW2 + w]; }
         S %= 65521; I %= 65521;
         // what was in front of this call (spng_inflate_resume_batch): the sum above then lacks those bytes
         const bool whole = uni64(st.start_bit) == 0 && uni64(st.out_pos) == 0;
@@ -1374,12 +1397,12 @@ __global__ __launch_bounds__(RT2, 4) void pinf2_resolve_kernel(const PStream *__
     }
 }
 
-// pages a group took: ctr = {page counter, total over the groups of the batch, some group ran dry}
-__global__ void pinf2_account_kernel(uint32_t *ctr, uint32_t pages)
+// pages a pass took: its page counter into the batch's totals = {pages, some pass ran dry}
+__global__ void pinf2_account_kernel(const uint32_t *ctr, uint32_t *totals, uint32_t pages)
 {
     const uint32_t used = ctr[0];
-    ctr[1] += used < pages ? used : pages;
-    if (used >= pages) ctr[2] = 1;
+    atomicAdd(&totals[0], used < pages ? used : pages);
+    if (used >= pages) atomicOr(&totals[1], 1u);
 }
 
 // ---- host ------------------------------------------------------------------------------------------------
@@ -1408,9 +1431,9 @@ hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_s
     pinf2_resolve_kernel<<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, retry);
     return hipGetLastError();
 }
-hipError_t launch_pinf2_account(uint32_t *d_ctr, uint32_t pages, hipStream_t stream)
+hipError_t launch_pinf2_account(const uint32_t *d_ctr, uint32_t *d_totals, uint32_t pages, hipStream_t stream)
 {
-    pinf2_account_kernel<<<1, 1, 0, stream>>>(d_ctr, pages);
+    pinf2_account_kernel<<<1, 1, 0, stream>>>(d_ctr, d_totals, pages);
     return hipGetLastError();
 }
 #endif

@@ -249,6 +249,7 @@ inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long
 inline int __ffs(int v) { return __builtin_ffs(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline float __fdividef(float a, float b) { return a / b; }
+inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
 inline unsigned long long __builtin_readcyclecounter_emu() { return 0; }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
 #define __HIP_MEMORY_SCOPE_AGENT 1

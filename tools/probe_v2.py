@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--kinds", default="zlib,swiftpng")
     ap.add_argument("--modes", default="auto")
+    ap.add_argument("--overlap", default="auto", help="comma list of auto,always,never (SPNG_CFG_INFLATE_OVERLAP)")
     ap.add_argument("--segments", default="0", help="comma list of SPNG_CFG_SEGMENT_BYTES values to try (auto mode)")
     args = ap.parse_args()
     import torch
@@ -34,8 +35,10 @@ def main():
         d_streams = [s.to_device(z) for z in streams]
         print(f"[{kind}] inputs in {time.time() - t0:.1f} s, ratio {sum(len(r) for r in rows) / sum(len(z) for z in streams):.3f}", flush=True)
         ref = [s.to_device(img.reshape(-1)) for img in images]
-        for mode, segb in [(m, int(sb)) for m in args.modes.split(",") for sb in (args.segments.split(",") if m == "auto" else ["0"])]:
+        for mode, segb, ovl in [(m, int(sb), o) for m in args.modes.split(",") for sb in (args.segments.split(",") if m == "auto" else ["0"])
+                                for o in args.overlap.split(",")]:
             s.configure(spng.CFG_INFLATE_MODE, {"auto": spng.INFLATE_AUTO, "serial": spng.INFLATE_SERIAL}[mode])
+            s.configure(spng.CFG_INFLATE_OVERLAP, {"auto": spng.OVERLAP_AUTO, "always": spng.OVERLAP_ALWAYS, "never": spng.OVERLAP_NEVER}[ovl])
             s.configure(spng.CFG_SEGMENT_BYTES, segb)
             job = bench.DecodeJob(spng, s, torch, d_streams, args.images, 0, args.unique, 1)
             for _ in range(2):
@@ -54,8 +57,8 @@ def main():
             bad = [r.status for r in res if r.status or r.written != job.U][:4]
             okay = all(torch.equal(job.d_out[j * job.S:(j + 1) * job.S], ref[job.src[j]]) for j in range(0, args.images, max(1, args.images // 64)))
             line = {"ms_per_step": round(dt * 1e3, 2), "stages": prof, "pipeline_streams": fast, "bad": bad, "bit_exact": okay}
-            out[f"{kind}/{mode}/{segb}"] = line
-            print(kind, mode, segb, json.dumps(line), flush=True)
+            out[f"{kind}/{mode}/{segb}/{ovl}"] = line
+            print(kind, mode, segb, ovl, json.dumps(line), flush=True)
             del job
             torch.cuda.empty_cache()
         s.configure(spng.CFG_INFLATE_MODE, spng.INFLATE_AUTO)
