@@ -581,10 +581,19 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
     // groups of consecutive streams whose estimates fit the pool together
     const uint64_t pool = c->tok_cap & ~(uint64_t)65535;
     p.pool_pages = (uint32_t)(pool >> 16 > 0xfffffff0ull ? 0xfffffff0ull : pool >> 16);
+    // (as many groups as the estimates need, of equal share: 730 + 294 streams cost resolve three rounds of resident
+    // workgroups where 512 + 512 cost two)
+    uint64_t share = pool;
+    if (want > pool) {
+        const uint64_t ng = (want + pool - 1) / pool;
+        share = (want + ng - 1) / ng;
+        if (share < largest) share = largest;
+        if (share > pool) share = pool;
+    }
     uint64_t run = 0;
     InflatePlan::Group g{0, 0, 0, 0, 0, p.pool_pages};
     for (size_t i = 0; i < p.jobs.size(); ++i) {
-        if (run + est[i] > pool && g.s1 > g.s0) {
+        if (run + est[i] > share && g.s1 > g.s0) {
             p.groups.push_back(g);
             g.s0 = g.s1; g.g0 = g.g1; run = 0;
         }

@@ -64,10 +64,6 @@ typedef PV2 AS_GLOBAL gPV2;
 static constexpr int LB = 9, DB = 8, MB = 7;         // LUT index bits: lit/len, distance, code-length code
 static constexpr int SDW_MAX = 9;                      // dwords per lane subsequence (odd: conflict-free LDS stride)
 static constexpr int STAGE2_DW = 592;                  // staged compressed data: a chunk (2304 B) + alignment + a token's reach
-#ifndef SPNG_HWCAP
-#define SPNG_HWCAP 1920
-#endif
-static constexpr uint32_t HWCAP = SPNG_HWCAP;          // halfwords the LDS token buffer holds
 static constexpr uint32_t PAGE_SHIFT = 16;             // token pages: 64 KiB
 static constexpr uint32_t PAGE_UNITS = 1u << (PAGE_SHIFT - 4);
 static constexpr uint64_t NONE2 = ~0ull;
@@ -147,7 +143,6 @@ struct DLds {
             uint16_t flag[64], mpos[64];   // lanes on the true chain; where it merges into their chains
             uint32_t ent[64];              // where it enters each subsequence | halfwords it decodes there before merging << 16
         } c;
-        uint16_t hw[HWCAP];            // the chunk's tokens on their way to HBM
     };
 };
 
@@ -623,14 +618,14 @@ __global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restric
 }
 
 // ---- decode: tokens of a segment ----------------------------------------------------------------------------
-// Where a segment's tokens go: whole 16-byte units (8 halfwords) in pages of the pool, the page numbers in the
-// segment's page table; the halfwords of the last, incomplete unit wait in `carry`.
+// Where a segment's tokens go: halfword x of the segment lives in page x >> 15 of its page table, at byte 2 (x & 32767).
+// Every lane stores its own tokens straight there (neighbouring lanes write neighbouring runs of ~30 halfwords; the
+// lines fill up in the L2 long before they leave it).
+static constexpr uint32_t PAGE_HW = 1u << (PAGE_SHIFT - 1);      // halfwords per page
 struct Cursor {
-    uint64_t units;                    // units stored
+    uint64_t nhw;                      // halfwords stored
     uint32_t npages;                   // pages taken
-    uint32_t carry_n;                  // halfwords in carry (0 .. 7)
-    v4u      carry;
-    g8      *ptr;                      // page of unit `units` (when npages > units >> 12)
+    g8      *pa;                       // page of halfword nhw (when npages > nhw >> 15)
     bool     dry;                      // a page was wanted and none was left
 };
 
@@ -647,39 +642,28 @@ __device__ __forceinline__ g8 *take_page(const DPool &pool, g32 *pt, uint32_t pt
     return (g8 *)(pool.base + ((uint64_t)id << PAGE_SHIFT));
 }
 
-// s.hw[0 .. carry_n + filled) = the carry and `filled` new halfwords: stores the whole units, keeps the rest.
-__device__ __forceinline__ bool flush_tokens(DLds &s, const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &c, uint32_t filled, int lane)
+// Room for halfwords [c.nhw, c.nhw + count), count <= PAGE_HW: afterwards c.pa is the page of halfword c.nhw and pb the
+// page behind it where the range reaches into one (else pa).  false: no page.
+__device__ __forceinline__ bool reserve_tokens(const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &c, uint32_t count, g8 *&pb, int lane)
 {
-    const uint32_t total = c.carry_n + filled;
-    const uint32_t nu = total >> 3;
-    if (nu) {
-        const uint64_t first_pg = c.units >> (PAGE_SHIFT - 4), last_pg = (c.units + nu - 1) >> (PAGE_SHIFT - 4);
-        if (first_pg == c.npages) { c.ptr = take_page(pool, pt, pt_cap, c, lane); if (!c.ptr) return false; }
-        g8 *pa = c.ptr, *pb = c.ptr;
-        if (last_pg != first_pg) { pb = take_page(pool, pt, pt_cap, c, lane); if (!pb) return false; }
-        for (uint32_t k = 0; k * 64 < nu; ++k) {
-            const uint32_t i = k * 64 + (uint32_t)lane;
-            if (i < nu) {
-                const uint64_t abs = c.units + i;
-                g8 *p = (abs >> (PAGE_SHIFT - 4)) == first_pg ? pa : pb;
-                ((gPV4 *)(p + ((abs & (PAGE_UNITS - 1)) << 4)))->v = *(const v4u *)(s.hw + i * 8);
-            }
-        }
-        c.units += nu;
-        c.ptr = pb;
-    }
-    WSYNC();
-    {
-        const v4u v = *(const v4u *)(s.hw + nu * 8);          // (uniform address)
-        c.carry[0] = UNI(v[0]); c.carry[1] = UNI(v[1]); c.carry[2] = UNI(v[2]); c.carry[3] = UNI(v[3]);
-    }
-    c.carry_n = total & 7;
-    WSYNC();
+    pb = c.pa;
+    if (!count) return true;
+    const uint64_t first_pg = c.nhw >> (PAGE_SHIFT - 1), last_pg = (c.nhw + count - 1) >> (PAGE_SHIFT - 1);
+    if (first_pg == c.npages) { c.pa = take_page(pool, pt, pt_cap, c, lane); if (!c.pa) return false; }
+    pb = c.pa;
+    if (last_pg != first_pg) { pb = take_page(pool, pt, pt_cap, c, lane); if (!pb) return false; }
     return true;
 }
-__device__ __forceinline__ void put_carry(DLds &s, const Cursor &c, int lane)
+// the address of halfword r counted from the start of page pa (r < 2 PAGE_HW)
+__device__ __forceinline__ g16 *token_at(g8 *pa, g8 *pb, uint32_t r)
 {
-    if (lane == 0) *(v4u *)s.hw = c.carry;
+    return (g16 *)((r < PAGE_HW ? pa : pb) + ((uint64_t)(r & (PAGE_HW - 1)) << 1));
+}
+__device__ __forceinline__ void advance_tokens(Cursor &c, uint32_t count, g8 *pb)
+{
+    const uint64_t pg = c.nhw >> (PAGE_SHIFT - 1);
+    c.nhw += count;
+    if ((c.nhw >> (PAGE_SHIFT - 1)) != pg) c.pa = pb;            // (on a page boundary exactly: replaced by the next reserve)
 }
 
 // One chunk (64 subsequences of sdw dwords) of a Huffman block.  `cb` = absolute first bit of the chunk, `entry`
@@ -826,43 +810,27 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, SR2 &sr, const g8 *src
     if (ste == 2) return 2;
     DP(4);
     DPN(20, 1); DPN(21, tot);
-    // ---- replay: the tokens, window after window of the LDS buffer.  A lane takes part in the window its next
-    // halfword falls in and stops where a token would cross the window's end (a lane that stands for a long unmerged
-    // stretch of the chain may need several windows).
-    uint32_t base = 0, done = 0, qq = e & 0xffff;
-    while (base < tot) {
-        const uint32_t wend = base + (HWCAP - 8);
-        const bool in = done < mine && off + done >= base && off + done < wend;
-        WSYNC();                                                // (everybody is done with what the buffer overlays)
-        put_carry(s, cur, lane);
-        WSYNC();
-        if (in) {
-            const uint32_t o = cur.carry_n + off - base;
-            while (done < mine) {
-                DPN(18, 1);
-                uint32_t h0 = 0, h1 = 0;
-                const uint32_t t = decode_at2<true>(s, qq, 0xffffffffu, h0, h1);
-                const uint32_t two = (t >> 8) == D2_REF ? 1u : 0u;
-                if (off + done + 1 + two > wend) break;
-                s.hw[o + done] = (uint16_t)h0;
-                if (two) s.hw[o + done + 1] = (uint16_t)h1;
-                done += 1 + two;
-                qq += t & 255;
-            }
+    // ---- replay: every lane its own tokens, to where the prefix sum puts them
+    g8 *pb;
+    if (!UB(reserve_tokens(pool, pt, pt_cap, cur, tot, pb, lane))) return 2;
+    {
+        g8 *pa = cur.pa;
+        const uint32_t r0 = (uint32_t)(cur.nhw & (PAGE_HW - 1)) + off;
+        uint32_t done = 0, qq = e & 0xffff;
+        while (done < mine) {
+            DPN(18, 1);
+            uint32_t h0 = 0, h1 = 0;
+            const uint32_t t = decode_at2<true>(s, qq, 0xffffffffu, h0, h1);
+            const bool two = (t >> 8) == D2_REF;
+            *token_at(pa, pb, r0 + done) = (uint16_t)h0;
+            if (two) *token_at(pa, pb, r0 + done + 1) = (uint16_t)h1;
+            done += two ? 2u : 1u;
+            qq += t & 255;
         }
-        WSYNC();
-        DP(5);
-        DPN(22, 1);
-        // the window ends where its first unfinished lane stopped, else behind its last lane
-        const unsigned long long inm = __ballot(in), cutm = __ballot(in && done < mine);
-        if (!inm) return 2;
-        const int pick = cutm ? __ffsll((long long)cutm) - 1 : 63 - __clzll((long long)inm);
-        const uint32_t endv = (uint32_t)__shfl((int)(off + done), pick, 64);
-        if (endv <= base) return 2;
-        if (!UB(flush_tokens(s, pool, pt, pt_cap, cur, endv - base, lane))) return 2;
-        DP(6);
-        base = endv;
     }
+    advance_tokens(cur, tot, pb);
+    DP(5);
+    DPN(22, 1);
     return ste;
 }
 
@@ -907,8 +875,7 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
         pt_cap = room > 0xffffff00ull ? 0xffffff00u : (uint32_t)room;
     }
     Cursor cur;
-    cur.units = 0; cur.npages = 0; cur.carry_n = 0; cur.ptr = nullptr; cur.dry = false;
-    cur.carry[0] = cur.carry[1] = cur.carry[2] = cur.carry[3] = 0;
+    cur.nhw = 0; cur.npages = 0; cur.pa = nullptr; cur.dry = false;
     uint64_t pos = start;
     int32_t status = PSEG_FAIL;
     // A resumable stream stops in front of the first block that cannot be taken as it stands -- cut off by the end
@@ -929,7 +896,7 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
             continue;
         }
         Hdr2 h;
-        hw_block = cur.units * 8 + cur.carry_n;
+        hw_block = cur.nhw;
         DP(7);
         const bool hok_ = UB(parse_header2(s, src, n, pos, h, lane));
         DP(8);
@@ -942,14 +909,15 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
             // stored bytes are literal tokens
             const uint64_t from = h.payload / 8;
             bool ok = true;
-            for (uint32_t k = 0; k < h.stored && ok; k += HWCAP - 8) {
-                const uint32_t m = h.stored - k < HWCAP - 8 ? h.stored - k : HWCAP - 8;
-                WSYNC();
-                put_carry(s, cur, lane);
-                WSYNC();
-                for (uint32_t i = (uint32_t)lane; i < m; i += 64) s.hw[cur.carry_n + i] = src[from + k + i];
-                WSYNC();
-                ok = UB(flush_tokens(s, pool, pt, pt_cap, cur, m, lane));
+            for (uint32_t k = 0; k < h.stored && ok; k += PAGE_HW / 2) {
+                const uint32_t m = h.stored - k < PAGE_HW / 2 ? h.stored - k : PAGE_HW / 2;
+                g8 *pb;
+                ok = UB(reserve_tokens(pool, pt, pt_cap, cur, m, pb, lane));
+                if (ok) {
+                    const uint32_t r0 = (uint32_t)(cur.nhw & (PAGE_HW - 1));
+                    for (uint32_t i = (uint32_t)lane; i < m; i += 64) *token_at(cur.pa, pb, r0 + i) = (uint16_t)src[from + k + i];
+                    advance_tokens(cur, m, pb);
+                }
             }
             if (!ok) break;
             pos = h.payload + (uint64_t)h.stored * 8;
@@ -973,18 +941,9 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
         }
         if (h.bfinal) { status = PSEG_FINAL; break; }
     }
-    uint64_t nhw = cur.units * 8 + cur.carry_n;
+    uint64_t nhw = cur.nhw;
     if (status == PSEG_FAIL && resumable) { status = PSEG_PARTIAL; nhw = hw_block; }   // (pos is still the block's first bit)
-    // the last unit, padded
-    if (cur.carry_n) {
-        WSYNC();
-        put_carry(s, cur, lane);
-        WSYNC();
-        if ((uint32_t)lane >= cur.carry_n && lane < 8) s.hw[lane] = (uint16_t)TK_NULL;
-        WSYNC();
-        const uint32_t pad = 8 - cur.carry_n;
-        if (!UB(flush_tokens(s, pool, pt, pt_cap, cur, pad, lane))) status = PSEG_FAIL;
-    }
+    // (no padding: resolve reads whole 16-byte units, inside the last page, and masks what lies behind nhw)
     if (status == PSEG_FAIL && cur.dry) status = PSEG_NOPAGE;
     if (lane == 0) { sg.end_bit = pos; sg.ntok = nhw; sg.status = status; sg.next = nk; }
 #ifdef SPNG_D_PROF
