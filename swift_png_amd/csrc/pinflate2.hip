@@ -82,11 +82,15 @@ struct DPool { uint8_t *base; uint32_t *next; uint32_t pages, pad; };
 #define DP_PASS , dp
 #define DP(k) do { const uint64_t now_ = __builtin_readcyclecounter(); dp[k] += now_ - dp[31]; dp[31] = now_; } while (0)
 #define DPN(k, v) (dp[k] += (v))
+#define HP_ARG , uint64_t *dp = nullptr
+#define HP(k) do { if (dp) DP(k); } while (0)
 #else
 #define DP_ARG
 #define DP_PASS
 #define DP(k)
 #define DPN(k, v)
+#define HP_ARG
+#define HP(k)
 #endif
 
 // ---- per-wave LDS of find / decode ----------------------------------------------------------------------
@@ -100,7 +104,7 @@ static constexpr uint32_t EXT = 480;                   // second-level table spa
 //             tree, symbols 30 / 31), [11:8] code length, [15:12] extra-bit count, [31:16] base distance
 //   link      class C_LINK / bit 7: the code is longer than the root index: [11:8] further index bits, [31:16] where its
 //             second-level table starts in ext
-enum { C_LIT = 0, C_EOB = 1, C_REF = 2, C_BAD = 3, C_LINK = 7 };      // (odd: the chain stops here)
+enum { C_LIT = 0, C_EOB = 1, C_REF = 2, C_BAD = 3, C_LIT2 = 6, C_LINK = 7 };      // (odd: the chain stops here; bit 1: two halfwords)
 __device__ __forceinline__ uint32_t lit_entry2(uint32_t sym, uint32_t len)
 {
     if (sym < 256) return len | C_LIT << 5 | len << 8 | sym << 16;
@@ -205,6 +209,7 @@ struct Hdr2 {
     uint64_t payload;                  // first bit of the compressed data / first BYTE of stored data * 8
     uint32_t stored;                   // stored blocks: LEN
     uint32_t minlen;                   // Huffman blocks: the shortest lit/len code
+    uint32_t pairs;                    //   the lit/len table holds pairs of literals
 };
 
 // The code-length code (readBlockTables, InflatorBuffers.Stream.swift:144-190): 19 lengths of <= 7 bits.  Lane
@@ -355,7 +360,7 @@ __device__ __forceinline__ bool layout_links(uint32_t *lut, uint32_t &used, uint
     return true;
 }
 
-__device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t literals, uint32_t distances, uint32_t &minlen, int lane)
+__device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t literals, uint32_t distances, uint32_t &minlen, uint32_t &pairs, int lane)
 {
     // (the six code lengths of a lane -- five lit/len symbols, one distance symbol -- travel in one register)
     uint32_t packed = 0;
@@ -452,6 +457,25 @@ __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t l
     }
 #undef LL
 #undef DL
+    // ---- pairs of literals: a root index whose bits hold a literal's code and then another one's whole code decodes
+    // both in one step.  (An entry rewritten under a reader still shows the same first literal in the same fields.)
+    bool made = false;
+#pragma unroll
+    for (int k = 0; k < (1 << LB) / 64; ++k) {
+        const uint32_t idx = (uint32_t)k * 64 + (uint32_t)lane;
+        const uint32_t e = s.lit[idx];
+        const uint32_t len0 = (e >> 8) & 15;
+        if (((e >> 5) & 7) == C_LIT && len0 < (uint32_t)LB) {
+            const uint32_t e2 = s.lit[idx >> len0];
+            const uint32_t c2 = (e2 >> 5) & 7, len1 = (e2 >> 8) & 15;
+            if ((c2 == C_LIT || c2 == C_LIT2) && len0 + len1 <= (uint32_t)LB) {
+                s.lit[idx] = (len0 + len1) | C_LIT2 << 5 | len0 << 8 | (e & 0x00ff0000u) | (e2 & 0x00ff0000u) << 8;
+                made = true;
+            }
+        }
+    }
+    pairs = __ballot(made) != 0 ? 1u : 0u;
+    WSYNC();
     return true;
 }
 
@@ -459,16 +483,17 @@ __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t l
 // readBlockTables, InflatorBuffers.Stream.swift:59-263) and, for Huffman blocks, builds the decode
 // tables.  false = anything the reference would not accept as is (errors, truncation): the caller
 // gives the block up.  Wave-uniform.
-__device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *src, uint64_t n, uint64_t pos, Hdr2 &h, int lane)
+__device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *src, uint64_t n, uint64_t pos, Hdr2 &h, int lane HP_ARG)
 {
     const uint64_t total = n * 8;
     if (pos + 3 > total) return false;
     const uint64_t wbyte = (pos >> 5) << 2;
     stage_bytes2(s.stage, src, n, wbyte, 256, lane);
+    HP(24);
     uint32_t rel = (uint32_t)(pos - wbyte * 8);
     const uint32_t first = upeek32_2(s.stage, rel);
     h.bfinal = first & 1; h.type = (first >> 1) & 3;
-    h.stored = 0; h.minlen = 7; h.payload = 0;
+    h.stored = 0; h.minlen = 7; h.payload = 0; h.pairs = 0;
     if (h.type == 0) {
         const uint64_t boundary = (pos + 3 + 7) & ~(uint64_t)7;
         if (boundary + 32 > total) return false;
@@ -503,13 +528,16 @@ __device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *
         const uint32_t at = sym >= 16 ? sym - 16 : sym == 0 ? 3u : sym <= 7 ? 19 - 2 * sym : 2 * sym - 12;
         const uint32_t mylen = (lane < 19 && at < codelengths) ? (uint32_t)((packed >> (3 * (at < 19 ? at : 0))) & 7) : 0u;
         if (!UB(build_clut(s, mylen, lane))) return false;
+        HP(25);
         const uint32_t rel_end = (uint32_t)((total - wbyte * 8) > 0xffffffffull ? 0xffffffffu : (total - wbyte * 8));
         if (!UB(decode_lengths2(s, rel, rel_end, literals + distances, lane))) return false;
         h.payload = wbyte * 8 + rel;
+        HP(26);
     }
-    uint32_t minlen = 7;
-    if (!UB(build_tables2(s, literals, distances, minlen, lane))) return false;
-    h.minlen = UNI(minlen);
+    uint32_t minlen = 7, pairs = 0;
+    if (!UB(build_tables2(s, literals, distances, minlen, pairs, lane))) return false;
+    h.minlen = UNI(minlen); h.pairs = UNI(pairs);
+    HP(27);
     return true;
 }
 
@@ -518,14 +546,18 @@ __device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *
 // of block, 3 not a token the fast path takes (undefined code, zero run or distance, past the end of the input
 // `lim`).  FULL also produces the token's halfwords (h0, and h1 for a reference).
 static constexpr uint32_t D2_EOB = C_EOB, D2_REF = C_REF, D2_BAD = C_BAD;   // (the entry's class as it is; 0: a literal)
-template <bool FULL>
-__device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32_t lim, uint32_t &h0, uint32_t &h1)
+// `bound`: a pair of literals whose second one would start at or behind it counts as its first literal alone (the
+// second belongs to the next subsequence).  -> bits | class << 8 | code length of the (first) literal << 16
+template <bool FULL, bool PAIRS>
+__device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32_t lim, uint32_t bound, uint32_t &h0, uint32_t &h1)
 {
     uint32_t lo, hi;
     fetch2(s.stage, q, lo, hi);
     uint32_t e = s.lit[lo & ((1 << LB) - 1)];
-    if (e & 0x80) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index
-    const uint32_t p2 = e & 31, cls = (e >> 5) & 3;
+    if ((e & 0xe0) == 0xe0) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index
+    uint32_t p2 = e & 31, cls = (e >> 5) & 7;
+    const uint32_t len0 = (e >> 8) & 15;
+    if (PAIRS && cls == C_LIT2 && q + len0 >= bound) { p2 = len0; cls = C_LIT; }
     uint32_t nbits = p2, k = cls;
     if (cls == C_REF) {
         const uint32_t b2 = (uint32_t)(((uint64_t)hi << 32 | lo) >> p2);
@@ -540,10 +572,10 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
             h0 = tk_m0(run, dd); h1 = tk_m1(dd);
         }
     } else if (FULL) {
-        h0 = e >> 16;
+        h0 = PAIRS ? (e >> 16) & 0xff : e >> 16; h1 = e >> 24;   // one literal, or two
     }
     k = q + nbits > lim ? D2_BAD : k;
-    return nbits | k << 8;
+    return PAIRS ? nbits | k << 8 | len0 << 16 : nbits | k << 8;
 }
 
 // ---- segment search ---------------------------------------------------------------------------------------
@@ -684,6 +716,7 @@ __device__ __forceinline__ void advance_tokens(Cursor &c, uint32_t count, g8 *pb
 //   replay    per subsequence the true chain enters it at `e` and `mine` halfwords of tokens start in it: the
 //             crossing chain's, then the owner's marks behind the merge point.  Every lane decodes exactly
 //             those, into the LDS token buffer at its prefix-sum offset; the buffer leaves in 16-byte units.
+template <bool PAIRS>
 __device__ __forceinline__ uint32_t decode_chunk(DLds &s, SR2 &sr, const g8 *src, uint64_t n, uint64_t cb,
                                                  uint64_t entry, uint32_t sdw, const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &cur,
                                                  uint64_t &next, int lane DP_ARG)
@@ -711,16 +744,21 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, SR2 &sr, const g8 *src
     uint32_t ntk = 0;
     while (q < sub1) {
         DPN(16, 1);
-        const uint32_t t = decode_at2<false>(s, q, lim, d0, d1);
-        const uint32_t k = t >> 8;
+        const uint32_t t = decode_at2<false, PAIRS>(s, q, lim, sub1, d0, d1);
+        const uint32_t k = PAIRS ? (t >> 8) & 255 : t >> 8;
         if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
         const uint32_t b = q - sub0;
         atomicOr(&s.c.vmap[(b >> 5) * 64 + lane], 1u << (b & 31));
         {
-            const uint64_t bit = (uint64_t)(k >> 1) << (ntk & 63);
+            const uint64_t bit = (uint64_t)(PAIRS ? (k == D2_REF ? 1u : 0u) : k >> 1) << (ntk & 63);
             mb0 |= ntk < 64 ? bit : 0ull; mb1 |= ntk < 64 ? 0ull : bit;
         }
         ntk += 1;
+        if (PAIRS && k == C_LIT2) {                             // two literals in one step: two tokens, two marks
+            const uint32_t b2 = b + (t >> 16);
+            atomicOr(&s.c.vmap[(b2 >> 5) * 64 + lane], 1u << (b2 & 31));
+            ntk += 1;
+        }
         q += t & 255;
     }
     WSYNC();
@@ -739,11 +777,11 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, SR2 &sr, const g8 *src
             // (the mark's word travels with the token's bits: its test comes behind the decode it may make useless)
             const uint32_t b = q + sb - jb;
             const uint32_t mword = s.c.vmap[(b >> 5) * 64 + j];
-            const uint32_t t = decode_at2<false>(s, q, lim, d0, d1);
+            const uint32_t t = decode_at2<false, PAIRS>(s, q, lim, jb, d0, d1);
             if ((mword >> (b & 31)) & 1) { link = j; break; }
-            const uint32_t k = t >> 8;
+            const uint32_t k = PAIRS ? (t >> 8) & 255 : t >> 8;
             if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
-            cnt2 += 1 + (k >> 1);
+            cnt2 += 1 + (PAIRS ? (k >> 1) & 1 : k >> 1);
             q += t & 255;
             }
     }
@@ -820,8 +858,9 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, SR2 &sr, const g8 *src
         while (done < mine) {
             DPN(18, 1);
             uint32_t h0 = 0, h1 = 0;
-            const uint32_t t = decode_at2<true>(s, qq, 0xffffffffu, h0, h1);
-            const bool two = (t >> 8) == D2_REF;
+            const uint32_t t = decode_at2<true, PAIRS>(s, qq, 0xffffffffu, 0xffffffffu, h0, h1);
+            // (of a pair of literals whose second one starts in the next subsequence only the first is mine)
+            const bool two = PAIRS ? ((t >> 9) & 1) != 0 && done + 2 <= mine : (t >> 8) == D2_REF;
             *token_at(pa, pb, r0 + done) = (uint16_t)h0;
             if (two) *token_at(pa, pb, r0 + done + 1) = (uint16_t)h1;
             done += two ? 2u : 1u;
@@ -898,7 +937,7 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
         Hdr2 h;
         hw_block = cur.nhw;
         DP(7);
-        const bool hok_ = UB(parse_header2(s, src, n, pos, h, lane));
+        const bool hok_ = UB(parse_header2(s, src, n, pos, h, lane DP_PASS));
         DP(8);
         DPN(23, 1);
 #ifdef SPNG_EMU_TRACE
@@ -931,7 +970,9 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
             stage_fetch2(sr, src, n, (cb >> 5) << 2, lane);
             for (;;) {
                 uint64_t next;
-                state = UNI(decode_chunk(s, sr, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS));
+                // (two instances of the loops: without pairs in the table a step skips their bookkeeping)
+                state = h.pairs ? UNI(decode_chunk<true>(s, sr, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS))
+                                : UNI(decode_chunk<false>(s, sr, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS));
                 entry = uni64(next);
                 if (state) break;
                 cb += (uint64_t)sdw * 32 * 64;
@@ -949,8 +990,8 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
 #ifdef SPNG_D_PROF
     if (blockIdx.x == 1 && lane == 0)
         printf("decode: %lu blocks %lu chunks %lu halfwords %lu windows; lane-0 steps r0 %lu r1 %lu replay %lu; cycles: total %lu stage %lu setup %lu round0 %lu "
-               "round1 %lu path %lu replay %lu flush %lu header %lu other %lu\n",
-               dp[23], dp[20], dp[21], dp[22], dp[16], dp[17], dp[18], __builtin_readcyclecounter() - dp_t0, dp[0], dp[1], dp[2], dp[3], dp[4], dp[5], dp[6], dp[8], dp[7]);
+               "round1 %lu path %lu replay %lu flush %lu header %lu (stage %lu clut %lu lengths %lu tables %lu) other %lu\n",
+               dp[23], dp[20], dp[21], dp[22], dp[16], dp[17], dp[18], __builtin_readcyclecounter() - dp_t0, dp[0], dp[1], dp[2], dp[3], dp[4], dp[5], dp[6], dp[8] + dp[24] + dp[25] + dp[26] + dp[27], dp[24], dp[25], dp[26], dp[27], dp[7]);
 #endif
 }
 

@@ -50,6 +50,10 @@ def cases():
     noise = rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
     yield "stored", deflate(noise, 0), noise, 0
     yield "huffonly", deflate(noise, 6, 15, zlib.Z_HUFFMAN_ONLY), noise, 0
+    t16 = rng.integers(0, 16, 60000, dtype=np.uint8).tobytes()
+    yield "text16", deflate(t16, 6, 15, zlib.Z_HUFFMAN_ONLY), t16, 0  # 4-bit codes: every step decodes two literals
+    t3 = rng.integers(0, 3, 60000, dtype=np.uint8).tobytes()
+    yield "text3", deflate(t3, 6, 15, zlib.Z_HUFFMAN_ONLY), t3, 0     # 1- and 2-bit codes: pairs in short subsequences
     yield "zeros", deflate(bytes(200000), 6), bytes(200000), 0     # one-bit codes: short subsequences
     yield "period4", deflate(bytes([1, 2, 3, 255]) * 20000, 9), bytes([1, 2, 3, 255]) * 20000, 0
     co = zlib.compressobj(6)
