@@ -62,8 +62,11 @@ struct __attribute__((packed)) PV2 { v2u v; };
 typedef PV2 AS_GLOBAL gPV2;
 
 static constexpr int LB = 9, DB = 8, MB = 7;         // LUT index bits: lit/len, distance, code-length code
-static constexpr int SDW_MAX = 9;                      // dwords per lane subsequence (odd: conflict-free LDS stride)
-static constexpr int STAGE2_DW = 592;                  // staged compressed data: a chunk (2304 B) + alignment + a token's reach
+#ifndef SPNG_SDW_MAX
+#define SPNG_SDW_MAX 9      // (17: 14.3 KB of LDS per wave, 11 waves per CU instead of 16: decode 291 ms instead of 206 -- the loops are latency-bound)
+#endif
+static constexpr int SDW_MAX = SPNG_SDW_MAX;           // dwords per lane subsequence at most (odd: conflict-free LDS stride)
+static constexpr int STAGE2_DW = SDW_MAX * 64 + 16;    // staged compressed data: a chunk + alignment + a token's reach
 static constexpr uint32_t PAGE_SHIFT = 16;             // token pages: 64 KiB
 static constexpr uint32_t PAGE_UNITS = 1u << (PAGE_SHIFT - 4);
 static constexpr uint64_t NONE2 = ~0ull;
@@ -167,20 +170,6 @@ __device__ __forceinline__ void stage_bytes2(uint32_t *dst, const g8 *src, uint6
 {
     for (int k = 0; k * 256 < dwords; ++k)
         if (k * 256 + lane * 4 < dwords) *(v4u *)(dst + k * 256 + lane * 4) = ld16(src, n, from + (uint64_t)k * 1024 + (uint64_t)lane * 16);
-    WSYNC();
-}
-struct SR2 { v4u v[(STAGE2_DW + 255) / 256]; };
-__device__ __forceinline__ void stage_fetch2(SR2 &r, const g8 *src, uint64_t n, uint64_t from, int lane)
-{
-#pragma unroll
-    for (int k = 0; k < (STAGE2_DW + 255) / 256; ++k)
-        if (k * 256 + lane * 4 < STAGE2_DW) r.v[k] = ld16(src, n, from + (uint64_t)k * 1024 + (uint64_t)lane * 16);
-}
-__device__ __forceinline__ void stage_put2(uint32_t *dst, const SR2 &r, int lane)
-{
-#pragma unroll
-    for (int k = 0; k < (STAGE2_DW + 255) / 256; ++k)
-        if (k * 256 + lane * 4 < STAGE2_DW) *(v4u *)(dst + k * 256 + lane * 4) = r.v[k];
     WSYNC();
 }
 __device__ __forceinline__ void fetch2(const uint32_t *stage, uint32_t q, uint32_t &lo, uint32_t &hi)
@@ -717,15 +706,14 @@ __device__ __forceinline__ void advance_tokens(Cursor &c, uint32_t count, g8 *pb
 //             crossing chain's, then the owner's marks behind the merge point.  Every lane decodes exactly
 //             those, into the LDS token buffer at its prefix-sum offset; the buffer leaves in 16-byte units.
 template <bool PAIRS>
-__device__ __forceinline__ uint32_t decode_chunk(DLds &s, SR2 &sr, const g8 *src, uint64_t n, uint64_t cb,
+__device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_t n, uint64_t cb,
                                                  uint64_t entry, uint32_t sdw, const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &cur,
                                                  uint64_t &next, int lane DP_ARG)
 {
     DP(0);
     const uint32_t sb = sdw * 32, chb = sb * 64;
     const uint64_t sbyte = (cb >> 5) << 2;
-    stage_put2(s.stage, sr, lane);                              // (fetched while the chunk before was decoded)
-    stage_fetch2(sr, src, n, ((cb + chb) >> 5) << 2, lane);
+    stage_bytes2(s.stage, src, n, sbyte, (int)((sdw * 64 + 3 + 3) & ~3u), lane);   // the chunk, the dword it may start in the middle of, a token's reach
     const uint64_t sbit = sbyte * 8;
     const uint64_t left = n * 8 - sbit;
     const uint32_t lim = left > 0xffffffffull ? 0xffffffffu : (uint32_t)left;
@@ -963,19 +951,22 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
         } else {
             // subsequence length: at most 128 tokens may start in one (their kinds are kept in two 64-bit masks), and
             // no token may jump a whole subsequence (it is at most 48 bits long)
-            const uint32_t sdw = h.minlen >= 3 ? 9u : h.minlen == 2 ? 7u : 3u;
+            // (sdw <= 4 minlen; odd; at most what the LDS is laid out for).  A block starts with 9 dwords per lane at most: one
+            // that ends inside its first chunk leaves the lanes behind its end idle.
+            uint32_t big = h.minlen >= 5 ? 17u : h.minlen == 4 ? 15u : h.minlen == 3 ? 11u : h.minlen == 2 ? 7u : 3u;
+            if (big > (uint32_t)SDW_MAX) big = (uint32_t)SDW_MAX;
+            uint32_t sdw = big < 9u ? big : 9u;
             uint64_t entry = h.payload, cb = h.payload;
             uint32_t state = 0;
-            SR2 sr;
-            stage_fetch2(sr, src, n, (cb >> 5) << 2, lane);
             for (;;) {
                 uint64_t next;
                 // (two instances of the loops: without pairs in the table a step skips their bookkeeping)
-                state = h.pairs ? UNI(decode_chunk<true>(s, sr, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS))
-                                : UNI(decode_chunk<false>(s, sr, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS));
+                state = h.pairs ? UNI(decode_chunk<true>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS))
+                                : UNI(decode_chunk<false>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS));
                 entry = uni64(next);
                 if (state) break;
                 cb += (uint64_t)sdw * 32 * 64;
+                sdw = big;
             }
             if (state != 1) break;
             pos = entry;
