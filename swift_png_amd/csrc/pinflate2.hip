@@ -531,23 +531,25 @@ __device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *
 }
 
 // ---- per-lane token decoding ----------------------------------------------------------------------------
-// decodes the token that starts at staged bit q.  -> bits | kind << 8 with kind 0 literal, 2 back-reference, 1 end
-// of block, 3 not a token the fast path takes (undefined code, zero run or distance, past the end of the input
-// `lim`).  FULL also produces the token's halfwords (h0, and h1 for a reference).
+// decodes the token that starts at staged bit q: kind 0 literal, 2 back-reference, 6 two literals, 1 end of block, 3 not a
+// token the fast path takes (undefined code, zero run or distance).  FULL also produces the token's halfwords (h0, and h1
+// for a reference or a second literal).
 static constexpr uint32_t D2_EOB = C_EOB, D2_REF = C_REF, D2_BAD = C_BAD;   // (the entry's class as it is; 0: a literal)
 // `bound`: a pair of literals whose second one would start at or behind it counts as its first literal alone (the
-// second belongs to the next subsequence).  -> bits | class << 8 | code length of the (first) literal << 16
+// second belongs to the next subsequence).  -> the token's bits; k = its class, len0 = the code length of the (first)
+// literal.  Bits behind the end of the input read as zeros: the callers compare where a chain ends with the end.
 template <bool FULL, bool PAIRS>
-__device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32_t lim, uint32_t bound, uint32_t &h0, uint32_t &h1)
+__device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32_t bound, uint32_t &k, uint32_t &len0, uint32_t &h0, uint32_t &h1)
 {
     uint32_t lo, hi;
     fetch2(s.stage, q, lo, hi);
     uint32_t e = s.lit[lo & ((1 << LB) - 1)];
     if ((e & 0xe0) == 0xe0) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index
     uint32_t p2 = e & 31, cls = (e >> 5) & 7;
-    const uint32_t len0 = (e >> 8) & 15;
+    len0 = (e >> 8) & 15;
     if (PAIRS && cls == C_LIT2 && q + len0 >= bound) { p2 = len0; cls = C_LIT; }
-    uint32_t nbits = p2, k = cls;
+    uint32_t nbits = p2;
+    k = cls;
     if (cls == C_REF) {
         const uint32_t b2 = (uint32_t)(((uint64_t)hi << 32 | lo) >> p2);
         uint32_t d = s.dist[b2 & ((1 << DB) - 1)];
@@ -563,8 +565,7 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
     } else if (FULL) {
         h0 = PAIRS ? (e >> 16) & 0xff : e >> 16; h1 = e >> 24;   // one literal, or two
     }
-    k = q + nbits > lim ? D2_BAD : k;
-    return PAIRS ? nbits | k << 8 | len0 << 16 : nbits | k << 8;
+    return nbits;
 }
 
 // ---- segment search ---------------------------------------------------------------------------------------
@@ -732,9 +733,9 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     uint32_t ntk = 0;
     while (q < sub1) {
         DPN(16, 1);
-        const uint32_t t = decode_at2<false, PAIRS>(s, q, lim, sub1, d0, d1);
-        const uint32_t k = PAIRS ? (t >> 8) & 255 : t >> 8;
-        if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
+        uint32_t k, len0;
+        const uint32_t nb = decode_at2<false, PAIRS>(s, q, sub1, k, len0, d0, d1);
+        if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
         const uint32_t b = q - sub0;
         atomicOr(&s.c.vmap[(b >> 5) * 64 + lane], 1u << (b & 31));
         {
@@ -743,12 +744,13 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
         }
         ntk += 1;
         if (PAIRS && k == C_LIT2) {                             // two literals in one step: two tokens, two marks
-            const uint32_t b2 = b + (t >> 16);
+            const uint32_t b2 = b + len0;
             atomicOr(&s.c.vmap[(b2 >> 5) * 64 + lane], 1u << (b2 & 31));
             ntk += 1;
         }
-        q += t & 255;
+        q += nb;
     }
+    if (q > lim) st = 2;                                        // (a chain that runs off the input: zeros from there on)
     WSYNC();
     DP(2);
     uint32_t link = 64, cnt2 = 0, nh = 0;
@@ -765,13 +767,14 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
             // (the mark's word travels with the token's bits: its test comes behind the decode it may make useless)
             const uint32_t b = q + sb - jb;
             const uint32_t mword = s.c.vmap[(b >> 5) * 64 + j];
-            const uint32_t t = decode_at2<false, PAIRS>(s, q, lim, jb, d0, d1);
+            uint32_t k, len0;
+            const uint32_t nb = decode_at2<false, PAIRS>(s, q, jb, k, len0, d0, d1);
             if ((mword >> (b & 31)) & 1) { link = j; break; }
-            const uint32_t k = PAIRS ? (t >> 8) & 255 : t >> 8;
-            if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += t & 255; break; }
+            if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
             cnt2 += 1 + (PAIRS ? (k >> 1) & 1 : k >> 1);
-            q += t & 255;
-            }
+            q += nb;
+        }
+        if (q > lim) st = 2;
     }
     // q: where my chain merged / left the chunk / stopped
     DP(3);
@@ -786,7 +789,8 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
         jump = jump < 64 ? jj : 64;
     }
     if (onpath) {
-        // the subsequences my chain crossed (beyond the fourth crossing they all count for the fourth: rare)
+        // the subsequences my chain crossed (beyond the fourth crossing they all count for the fourth: rare.  Fewer records
+        // cost less per step of round 1 but leave the owner of the last one a replay of several subsequences: slower)
         const uint32_t nrec = nh < 4 ? nh : 4;
         const uint32_t xs[5] = {x0, x1, x2, x3, 0};
 #pragma unroll
@@ -846,13 +850,14 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
         while (done < mine) {
             DPN(18, 1);
             uint32_t h0 = 0, h1 = 0;
-            const uint32_t t = decode_at2<true, PAIRS>(s, qq, 0xffffffffu, 0xffffffffu, h0, h1);
+            uint32_t k, len0;
+            const uint32_t nb = decode_at2<true, PAIRS>(s, qq, 0xffffffffu, k, len0, h0, h1);
             // (of a pair of literals whose second one starts in the next subsequence only the first is mine)
-            const bool two = PAIRS ? ((t >> 9) & 1) != 0 && done + 2 <= mine : (t >> 8) == D2_REF;
+            const bool two = PAIRS ? (k & 2) != 0 && done + 2 <= mine : k == D2_REF;
             *token_at(pa, pb, r0 + done) = (uint16_t)h0;
             if (two) *token_at(pa, pb, r0 + done + 1) = (uint16_t)h1;
             done += two ? 2u : 1u;
-            qq += t & 255;
+            qq += nb;
         }
     }
     advance_tokens(cur, tot, pb);
