@@ -570,8 +570,12 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
 
 // ---- segment search ---------------------------------------------------------------------------------------
 // (retry: only the streams whose first pass ran out of token pages -- PStream.pass == 1 -- are looked at again)
-__global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs, uint32_t seg0, uint32_t retry)
+// (RETRY: the pass for the streams that found the pool empty is launched behind every batch and mostly has nothing to do; as
+// an instantiation of its own it has a name of its own in kernel traces)
+template <uint32_t RETRY>
+__global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs, uint32_t seg0)
 {
+    constexpr uint32_t retry = RETRY;
     __shared__ __attribute__((aligned(16))) DLds s;
     __shared__ __attribute__((aligned(16))) uint32_t win[512 + 16];
     const int lane = threadIdx.x;
@@ -869,9 +873,11 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
 #ifndef SPNG_D_WAVES
 #define SPNG_D_WAVES 4
 #endif
+template <uint32_t RETRY>
 __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs,
-                                                          uint32_t *__restrict__ pt_slab, DPool pool, uint32_t seg0, uint32_t retry)
+                                                          uint32_t *__restrict__ pt_slab, DPool pool, uint32_t seg0)
 {
+    constexpr uint32_t retry = RETRY;
     // (segs = the whole table -- a stream's seg_first counts from its beginning; this launch's segments start at seg0)
     __shared__ __attribute__((aligned(16))) DLds s;
     const int lane = threadIdx.x;
@@ -995,8 +1001,10 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
 // One wave per stream walks the chain: segment 0, then the segment decode says it stopped at, ... up to the
 // first one that saw the final block.  A found start that no chain member stops at (a bit pattern inside
 // stored data or in the middle of a block that happens to parse as a header) is simply not on the chain.
-__global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ streams, PSeg *__restrict__ segs, uint32_t retry)
+template <uint32_t RETRY>
+__global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ streams, PSeg *__restrict__ segs)
 {
+    constexpr uint32_t retry = RETRY;
     const int lane = threadIdx.x;
     PStream &st = streams[blockIdx.x];
     if (retry && UNI(st.pass) != 1) {
@@ -1045,7 +1053,7 @@ static constexpr uint32_t PTC = 256;                 // page-table entries cache
 struct RLds2 {
     uint8_t  ring[WINDOW2];            // the last 32 KiB of output, at position mod 32 KiB
     uint16_t state[TILE2];
-    uint32_t rec[MAXM2][2];            // back-references of the tile: first byte | run << 16; distance
+    uint32_t rec[MAXM2 + 2][2];        // back-references of the tile: first byte | run << 16; distance ([0]: none, run 0; [last]: keeps what follows 16-byte aligned)
     uint32_t bitmap[TILE2 / 32];       // their first bytes
     uint16_t h0[RT2 + 8];              // every thread's first halfword (the second half of its neighbour's last reference)
     uint32_t pt[PTC];
@@ -1074,10 +1082,12 @@ __device__ __forceinline__ uint32_t block_excl_scan2(RLds2 &s, uint32_t v, uint3
     return off + before;
 }
 
+template <uint32_t RETRY>
 __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const PStream *__restrict__ streams, const PSeg *__restrict__ segs,
                                                                const uint32_t *__restrict__ pt_slab, DPool pool,
-                                                               spng_result *__restrict__ results, int32_t *__restrict__ done, uint32_t retry)
+                                                               spng_result *__restrict__ results, int32_t *__restrict__ done)
 {
+    constexpr uint32_t retry = RETRY;
     __shared__ __attribute__((aligned(16))) RLds2 s;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)UNI((uint32_t)tid >> 6);
     const PStream &st = streams[blockIdx.x];
@@ -1097,6 +1107,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
     }
     if (tid < (int)(TILE2 / 32)) s.bitmap[tid] = 0;
     if (tid < 3) s.again[tid] = 0;
+    if (tid == 0) { s.rec[0][0] = 0; s.rec[0][1] = 1; }
     __syncthreads();
     const uint32_t seg_first = UNI(st.seg_first), seg_count = UNI(st.seg_count);
     uint32_t sk = 0;
@@ -1178,8 +1189,8 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         const uint32_t h1 = j < (int)HPT2 - 1 ? hh[j < (int)HPT2 - 1 ? j + 1 : (int)HPT2 - 1] : hnext;
                         const uint32_t dd = (((v >> 8) & 63) | (h1 & 0x1ff) << 6) + 1;
                         atomicOr(&s.bitmap[curb >> 5], 1u << (curb & 31));
-                        s.rec[curm][0] = curb | len << 16;
-                        s.rec[curm][1] = dd;
+                        s.rec[curm + 1][0] = curb | len << 16;
+                        s.rec[curm + 1][1] = dd;
                         curb += len; curm += 1;
                     }
                 }
@@ -1202,6 +1213,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
             RP2(2);
             // ---- expand: the reference (if any) that covers each of my bytes
             const uint32_t rbase = (uint32_t)pos & (WINDOW2 - 1);
+            const bool early = pos < WINDOW2;                        // (only there can a distance reach in front of the output)
             uint32_t sv[BPT2];
             {
                 // back-references that start in front of each row: prefix sum over the bitmap (lane l: rows 2l, 2l + 1)
@@ -1225,8 +1237,8 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)srcbase, (int)(row >> 1));
                         const unsigned long long mw = (unsigned long long)mhi << 32 | mlo;
                         const uint32_t id = base + (uint32_t)__popcll(mw & ((2ull << lane) - 1));
-                        r0v[kk] = id ? s.rec[id - 1][0] : 0u;          // (no reference in front of this byte: run 0)
-                        r1v[kk] = id ? s.rec[id - 1][1] : 1u;
+                        r0v[kk] = s.rec[id][0];                        // (no reference in front of this byte: entry 0, run 0)
+                        r1v[kk] = s.rec[id][1];
                     }
                     uint32_t siv[EB2], farv[EB2];
 #pragma unroll
@@ -1235,7 +1247,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         const uint32_t j = ((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane;
                         const uint32_t startb = r0v[kk] & 0xffff, len = r0v[kk] >> 16, d = r1v[kk];
                         uint32_t kk2 = j - startb;
-                        const bool inside = kk2 < len && j < tlen;
+                        const bool inside = kk2 < len;             // (the tokens taken cover bytes 0 .. tlen - 1 and nothing else)
                         // A run longer than its distance repeats its first `distance` bytes: a byte beyond the first
                         // period copies the period in front of the run (same value, chain one level deep instead of
                         // run / distance levels).
@@ -1250,7 +1262,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         const uint32_t si = siv[kk];
                         sv[k] = R2_DONE;
                         if (si != 0x7fffffffu) {
-                            if ((int32_t)si < 0 && pos < (uint64_t)(0u - si)) bad = true;
+                            if (early && (int32_t)si < 0 && (uint32_t)pos < 0u - si) bad = true;
                             const uint32_t v = (int32_t)si < 0 ? R2_DONE | farv[kk] : si;
                             sv[k] = v;
                             s.state[j] = (uint16_t)v;
@@ -1405,26 +1417,30 @@ __global__ void pinf2_account_kernel(const uint32_t *ctr, uint32_t *totals, uint
 #ifndef SPNG_EMU
 hipError_t launch_pinf2_find(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t retry, hipStream_t stream)
 {
-    pinf2_find_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs, seg0, retry);
+    if (retry) pinf2_find_kernel<1><<<nsegs, 64, 0, stream>>>(d_streams, d_segs, seg0);
+    else pinf2_find_kernel<0><<<nsegs, 64, 0, stream>>>(d_streams, d_segs, seg0);
     return hipGetLastError();
 }
 hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t *d_pt, uint8_t *d_pool, uint32_t *d_next,
                                uint32_t pages, uint32_t retry, hipStream_t stream)
 {
     DPool pool{d_pool, d_next, pages, 0};
-    pinf2_decode_kernel<<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_pt, pool, seg0, retry);
+    if (retry) pinf2_decode_kernel<1><<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_pt, pool, seg0);
+    else pinf2_decode_kernel<0><<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_pt, pool, seg0);
     return hipGetLastError();
 }
 hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t retry, hipStream_t stream)
 {
-    pinf2_scan_kernel<<<nstreams, 64, 0, stream>>>(d_streams, d_segs, retry);
+    if (retry) pinf2_scan_kernel<1><<<nstreams, 64, 0, stream>>>(d_streams, d_segs);
+    else pinf2_scan_kernel<0><<<nstreams, 64, 0, stream>>>(d_streams, d_segs);
     return hipGetLastError();
 }
 hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
                                 spng_result *d_results, int32_t *d_done, uint32_t retry, hipStream_t stream)
 {
     DPool pool{d_pool, nullptr, pages, 0};
-    pinf2_resolve_kernel<<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, retry);
+    if (retry) pinf2_resolve_kernel<1><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done);
+    else pinf2_resolve_kernel<0><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done);
     return hipGetLastError();
 }
 hipError_t launch_pinf2_account(const uint32_t *d_ctr, uint32_t *d_totals, uint32_t pages, hipStream_t stream)

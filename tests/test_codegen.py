@@ -75,7 +75,7 @@ def _kernels(name):
 
 
 def _one(table, fragment):
-    hits = [v for k, v in table.items() if fragment in k]
+    hits = [v for k, v in table.items() if fragment in k and "ILj1E" not in k]      # (not the <RETRY = 1> instantiation)
     assert len(hits) == 1, (fragment, list(table))
     return hits[0]
 

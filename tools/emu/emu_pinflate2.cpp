@@ -64,13 +64,13 @@ int main(int argc, char **argv)
     memset(&res, 0xff, sizeof res);
     int32_t done = 0;
 
-    emu::launch((unsigned)k, 64, [&] { pinf2_find_kernel(&st, segs.data(), 0, 0); });
+    emu::launch((unsigned)k, 64, [&] { pinf2_find_kernel<0>(&st, segs.data(), 0); });
     if (verbose) for (uint64_t q = 0; q < k; ++q) fprintf(stderr, "seg %llu: start %lld\n", (unsigned long long)q, (long long)segs[q].start_bit);
-    emu::launch((unsigned)k, 64, [&] { pinf2_decode_kernel(&st, segs.data(), pt.data(), pool, 0, 0); });
+    emu::launch((unsigned)k, 64, [&] { pinf2_decode_kernel<0>(&st, segs.data(), pt.data(), pool, 0); });
     if (verbose) for (uint64_t q = 0; q < k; ++q)
         fprintf(stderr, "seg %llu: end %lld status %d nhw %llu next %u\n", (unsigned long long)q, (long long)segs[q].end_bit, segs[q].status,
                 (unsigned long long)segs[q].ntok, segs[q].next);
-    emu::launch(1, 64, [&] { pinf2_scan_kernel(&st, segs.data(), 0); });
+    emu::launch(1, 64, [&] { pinf2_scan_kernel<0>(&st, segs.data()); });
     if (verbose) fprintf(stderr, "stream: ok %d nhw %llu end_bit %llu pages used %u\n", st.ok, (unsigned long long)st.ntok, (unsigned long long)st.end_bit, next);
     {   // the token stream, expanded the plain way: tells a decode bug from a resolve bug
         std::vector<uint8_t> out(st.out_pos ? std::vector<uint8_t>(want.begin(), want.begin() + st.out_pos) : std::vector<uint8_t>());
@@ -99,7 +99,7 @@ int main(int argc, char **argv)
         if (verbose || i != out.size() || (st.ok == 1 && out.size() != want.size()))
             fprintf(stderr, "token stream expands to %zu bytes, agrees with the expected bytes up to %zu of %zu\n", out.size(), i, want.size());
     }
-    emu::launch(1, RT2, [&] { pinf2_resolve_kernel(&st, segs.data(), pt.data(), pool, &res, &done, 0); });
+    emu::launch(1, RT2, [&] { pinf2_resolve_kernel<0>(&st, segs.data(), pt.data(), pool, &res, &done); });
 
     if (resumed) {
         // report what the pipeline did
