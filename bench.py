@@ -126,7 +126,7 @@ def cpu_baseline(streams, images, rows, cores: int):
 
 def pmc_traffic(kind: str, images: int, unique: int):
     """HBM bytes per launch of each kernel from the committed rocprofv3 PMC passes of this very workload
-    (profiles/r02_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+    (profiles/ + PMC_FILE: FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
     MI355X_MICROARCH.md prescribes); None when the file does not describe this configuration."""
     try:
         pmc = json.loads((ROOT / "profiles" / PMC_FILE).read_text())
@@ -200,6 +200,17 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
     first = rank * args.images if weak else lo
     do_gather = with_gather and world > 1 and not args.no_gather
     groups = max(1, min(args.groups, -(-args.images // world))) if do_gather else 1
+    # what this rank is about to hold: its shard's scanline scratch + rasters, the compressed inputs, on rank 0 the gathered
+    # rasters of the whole job, and the pipeline's token pool (sized by the library to at most half of what is then free:
+    # planned here with its cautious 3.2 token bytes per compressed byte of one group).  Checked before anything is allocated.
+    U_, S_ = spng.inflated_size(W, H, DEPTH, CHANNELS, False), spng.storage_size(W, H, DEPTH, CHANNELS)
+    plan = {"shard": n * (((U_ + 4096 + 255) & ~255) + S_), "inputs": sum(C),
+            "gathered": args.images * S_ if (do_gather and rank == 0) else 0}
+    plan["tokens_min"] = int(3.2 * max(C)) + (1 << 20)                   # (one stream's worth: the pool's lower bound)
+    free_b, total_b = torch.cuda.mem_get_info(s.tdev)
+    need = plan["shard"] + plan["gathered"] + plan["tokens_min"]
+    assert need <= free_b, (f"rank {rank}: planned allocations {need / 2**30:.1f} GiB ({plan}) exceed the {free_b / 2**30:.1f} GiB "
+                            f"free of {total_b / 2**30:.1f} GiB")
     job = DecodeJob(spng, s, torch, d_streams, n, first, unique, groups)
     S = job.S
     gathered = None
@@ -454,7 +465,9 @@ def main():
     ap.add_argument("--swiftpng-unique", type=int, default=8)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: --images in total, sharded (strong, BASELINE configs[2]); or --images per GPU (weak)")
-    ap.add_argument("--groups", type=int, default=4, help="N > 1: decode/gather pipeline depth per step")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="N > 1: calls a rank cuts its shard into, each one's rasters leaving for rank 0 while the next decodes "
+                         "(1: a call pays every stream's serial resolve once, profiles/r03_probe_groups.log)")
     ap.add_argument("--level", type=int, default=9, help="encode mode: DEFLATE level (BASELINE configs[3]: 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
@@ -567,6 +580,11 @@ def main():
                 ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), 1, 0, args.no_cpu_baseline
                 return run_encode(ea, torch, dist, spng, s, rank, world)
             leg("encode", enc)
+
+            def enc_photo():
+                from bench_encode import run_encode_photographic
+                return run_encode_photographic(torch, spng, s, args.level)
+            leg("encode_photographic", enc_photo)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

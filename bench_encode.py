@@ -149,3 +149,42 @@ def run_encode(args, torch, dist, spng, s, rank, world):
         except Exception as exc:                                   # noqa: BLE001
             out["cpu_baseline"]["all_cores_error"] = repr(exc)[:200]
     return out
+
+
+def run_encode_photographic(torch, spng, s, level=9, images=256, size=1024):
+    """SURVEY 8d item 3's second encode input: images with structure (swift_png_amd.synth: gradients, edges, texture -- what a
+    photograph gives a PNG encoder) instead of noise.  Compressible input is where the level >= 8 search has work to do
+    (DESIGN 4.5), so the rasters are 1024 x 1024: `images` streams of 4 MiB, all resident at once."""
+    from swift_png_amd import synth
+    w = h = size
+    unique = min(8, images)
+    U = spng.inflated_size(w, h, DEPTH, CHANNELS, False)
+    S = spng.storage_size(w, h, DEPTH, CHANNELS)
+    cap = s.lib.spng_deflate_bound(U)
+    rasters = [s.to_device(synth.image(100 + k, w, h).tobytes()) for k in range(unique)]
+    d_rows = torch.empty(images * U, dtype=torch.uint8, device=s.tdev)
+    d_out = torch.empty(images * cap, dtype=torch.uint8, device=s.tdev)
+    descs = (spng.ImageDesc * images)()
+    for j in range(images):
+        r = rasters[j % unique]
+        descs[j] = spng.ImageDesc(d_out.data_ptr() + j * cap, cap, d_rows.data_ptr() + j * U, U, r.data_ptr(), w, h, DEPTH, CHANNELS, 0, 0, 0)
+    dres = s.empty(images * ctypes.sizeof(spng.Result))
+    torch.cuda.synchronize()
+    s.profile(True)
+    t0 = time.perf_counter()
+    st = s.lib.spng_encode_batch(s.ctx, descs, level, images, ctypes.c_void_p(dres.data_ptr()), None)
+    assert st == 0, st
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = {k: s.profile_get(getattr(spng, "K_" + k.upper()))[0] for k in ("filter", "deflate")}
+    s.profile(False)
+    res = list((spng.Result * images).from_buffer_copy(bytes(dres.cpu().numpy())))
+    assert all(r.status == 0 for r in res), [r.status for r in res if r.status][:8]
+    total_c = sum(r.written for r in res)
+    for j in range(unique):
+        z = bytes(d_out[j * cap:j * cap + res[j].written].cpu().numpy())
+        assert zlib.decompress(z) == bytes(d_rows[j * U:(j + 1) * U].cpu().numpy()), f"stream {j} does not inflate to its scanlines"
+    return {"workload": f"{images} x {w}x{h} RGBA8 synthetic photographs (swift_png_amd.synth) -> filter-select + DEFLATE level {level}",
+            "ms": round(dt * 1e3, 1), "mpixels_per_s": round(images * w * h / 1e6 / dt, 2),
+            "per_stream_mb_per_s": round(U / 1e6 / (prof["deflate"] * 1e-3), 3), "compressed_ratio": round(images * U / total_c, 3),
+            "kernels_ms": {k: round(v, 2) for k, v in prof.items()}, "inflates_to_its_scanlines": True}
