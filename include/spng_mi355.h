@@ -133,7 +133,9 @@ enum { SPNG_CFG_INFLATE_MODE = 0,   /* SPNG_INFLATE_AUTO: parallel pipeline, ser
        SPNG_CFG_INFLATE_OVERLAP = 4,       /* parallel inflate: SPNG_OVERLAP_ALWAYS = every batch of >= 2 streams in two halves
                                               on two streams, the decode of one beside the resolve of the other
                                               (an experiment: slower than one pass on MI355X, so never by default) */
-       SPNG_CFG_COUNT = 5 };
+       SPNG_CFG_RESOLVE_PARTS = 5,         /* parallel inflate, batches of <= 384 streams: workgroups that resolve ONE stream side by
+                                              side (0: as many as fill the chip, at most 64; 1: one, as in large batches; n: n) */
+       SPNG_CFG_COUNT = 6 };
 enum { SPNG_INFLATE_AUTO = 0, SPNG_INFLATE_SERIAL = 1 };
 enum { SPNG_OVERLAP_AUTO = 0, SPNG_OVERLAP_ALWAYS = 1, SPNG_OVERLAP_NEVER = 2 };
 int32_t spng_configure(spng_ctx *ctx, int key, int64_t value);

@@ -38,7 +38,7 @@ TARGET_RGBA, TARGET_VA = 0, 1
 PREMULTIPLY, PREMULTIPLY_AS_U8 = 1, 2
 K_LEX = 12
 K_PINF_FIND, K_PINF_DECODE, K_PINF_RESOLVE = 8, 9, 11
-CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES, CFG_UNFILTER_PIECE_ROWS, CFG_INFLATE_OVERLAP = 0, 1, 2, 3, 4
+CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES, CFG_UNFILTER_PIECE_ROWS, CFG_INFLATE_OVERLAP, CFG_RESOLVE_PARTS = 0, 1, 2, 3, 4, 5
 OVERLAP_AUTO, OVERLAP_ALWAYS, OVERLAP_NEVER = 0, 1, 2
 INFLATE_AUTO, INFLATE_SERIAL = 0, 1
 

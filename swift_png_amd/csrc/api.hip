@@ -77,6 +77,8 @@ struct spng_ctx {
     void *d_graph = nullptr; size_t graph_cap = 0;   // deflate levels >= 8: match graphs
     void *d_log = nullptr;  size_t log_cap = 0;
     void *d_tok = nullptr;  size_t tok_cap = 0;      // bytes
+    void *d_sym = nullptr;  size_t sym_cap = 0;      // several workgroups per stream: 16-bit symbols, windows (bytes)
+    void *d_win = nullptr;  size_t win_cap = 0;
     // token pool of the pipeline (pinflate2.hip): halfwords a compressed byte turned into in the last batch (learned,
     // so that the next batch of the same kind takes one pass), and the pinned word the page counter is read back into
     double   pool_ratio = 0;
@@ -86,7 +88,7 @@ struct spng_ctx {
     // second stream of the pipeline: the decode of one half of a batch runs beside the resolve of the other
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
-    int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0, 0, 0};
+    int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0, 0, 0, 0};
     // profiling
     bool profiling = false;
     struct Span { int kernel; hipEvent_t a, b; };
@@ -250,6 +252,8 @@ void spng_destroy(spng_ctx *c)
     if (c->d_graph) (void)hipFree(c->d_graph);
     if (c->d_log) (void)hipFree(c->d_log);
     if (c->d_tok) (void)hipFree(c->d_tok);
+    if (c->d_sym) (void)hipFree(c->d_sym);
+    if (c->d_win) (void)hipFree(c->d_win);
     if (c->h_pool_used) (void)hipHostFree(c->h_pool_used);
     if (c->pool_ev) (void)hipEventDestroy(c->pool_ev);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
@@ -458,6 +462,8 @@ struct InflatePlan {
     struct Group { uint32_t s0, s1, g0, g1, page0, pages; };   // streams, segments, its pages of the pool
     std::vector<Group> groups;
     bool overlap = false;            // two groups, each with its own half of the pool, on two streams (see launch_inflate_plan)
+    uint32_t pmax = 0;               // several workgroups per stream: part slots per stream (0: one workgroup per stream)
+    size_t parts_at = 0;
     size_t next_at = 0;
     bool gzip = false;               // some stream is SPNG_FORMAT_GZIP: header kernel in front, CRC-32 check behind
     std::vector<uint64_t> state;     // {bit, written} per stream: spng_inflate_resume_batch's, else the library's own zeros
@@ -465,7 +471,7 @@ struct InflatePlan {
     size_t jobs_at = 0, streams_at = 0, segs_at = 0, done_at = 0, gz_at = 0, gzparts_at = 0, state_at = 0, sumparts_at = 0;
     size_t bytes() const
     {
-        return jobs.size() * (sizeof(InflateJob) + sizeof(PStream) + 4 + (gzip ? 8 + 4 * (size_t)gzip_pieces() : 0) +
+        return jobs.size() * (sizeof(InflateJob) + sizeof(PStream) + 4 + (size_t)pmax * sizeof(PPart) + 256 + (gzip ? 8 + 4 * (size_t)gzip_pieces() : 0) +
                               (state.empty() ? 0 : 16 + 8 * (size_t)gzip_pieces())) +
                segs.size() * sizeof(PSeg) + 8192 + 512;
     }
@@ -624,6 +630,40 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
             p.overlap = true;
         }
     }
+    // Few streams: a workgroup per stream would leave most of the chip idle while each resolves its stream at ~0.9 GB/s
+    // (one 4K image: 77 ms of an 89 ms decode).  Then a stream's chain is cut into parts that resolve side by side
+    // (pinflate2.hip, "Several workgroups per stream"): 16-bit symbols in c->d_sym, the windows in c->d_win.
+    p.pmax = 0;
+    if (p.internal && p.jobs.size() <= 384 && c->cfg[SPNG_CFG_RESOLVE_PARTS] != 1) {
+        uint32_t pm = (uint32_t)(768 / p.jobs.size());
+        if (c->cfg[SPNG_CFG_RESOLVE_PARTS] > 1) pm = (uint32_t)c->cfg[SPNG_CFG_RESOLVE_PARTS];
+        if (pm > 64) pm = 64;
+        uint64_t syms = 0;
+        for (size_t i = 0; i < p.jobs.size(); ++i) {
+            p.streams[i].sym_off = syms;
+            syms += (p.jobs[i].dst_cap + 15) & ~(uint64_t)7;
+        }
+        const uint64_t win = (uint64_t)p.jobs.size() * pm * 32768;
+        if (pm >= 2) {
+            bool room = true;
+            if (syms * 2 > c->sym_cap) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (c->d_sym) { HIP_TRY(hipFree(c->d_sym)); c->d_sym = nullptr; c->sym_cap = 0; }
+                if (hipMalloc(&c->d_sym, syms * 2) != hipSuccess) { (void)hipGetLastError(); room = false; }
+                else c->sym_cap = syms * 2;
+            }
+            if (room && win > c->win_cap) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (c->d_win) { HIP_TRY(hipFree(c->d_win)); c->d_win = nullptr; c->win_cap = 0; }
+                if (hipMalloc(&c->d_win, win) != hipSuccess) { (void)hipGetLastError(); room = false; }
+                else c->win_cap = win;
+            }
+            if (room) {
+                p.pmax = pm;
+                for (auto &st : p.streams) st.parts_max = pm;
+            }
+        }
+    }
     c->pool_pages_planned = p.pool_pages;
     c->pool_src_bytes = total;
     if (!c->h_pool_used) {
@@ -654,6 +694,10 @@ static void stage_inflate(InflatePlan &p, Arena &a)
     if (p.parallel) {
         p.next_at = a.take(64);
         memset(a.host<uint32_t>(p.next_at), 0, 64);
+        if (p.pmax) {
+            p.parts_at = a.take(n * p.pmax * sizeof(PPart));
+            memset(a.host<PPart>(p.parts_at), 0, n * p.pmax * sizeof(PPart));
+        }
     }
     if (p.parallel || p.gzip) {
         p.done_at = a.take(n * 4);
@@ -703,8 +747,15 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
             if (second) HIP_TRY(hipStreamWaitEvent(q, c->ev_mid, 0));
             { Timed t(c, SPNG_K_PINF_DECODE, q); HIP_TRY(launch_pinf2_decode(ds, dg, g.g0, g.g1 - g.g0, (uint32_t *)c->d_log, pool, ctr, g.pages, retry, q)); }
             if (p.overlap && gi == 0) HIP_TRY(hipEventRecord(c->ev_mid, q));
-            HIP_TRY(launch_pinf2_scan(ds + g.s0, g.s1 - g.s0, dg, retry, q));
-            { Timed t(c, SPNG_K_PINF_RESOLVE, q); HIP_TRY(launch_pinf2_resolve(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, pool, g.pages, dr, dd + g.s0, retry, q)); }
+            PPart *dparts = p.pmax ? a.dev<PPart>(p.parts_at) + (size_t)g.s0 * p.pmax : nullptr;
+            const uint32_t pm = retry ? 0u : p.pmax;                 // (the retry pass: one workgroup per stream)
+            HIP_TRY(launch_pinf2_scan(ds + g.s0, g.s1 - g.s0, dg, dparts, retry, q));
+            {
+                Timed t(c, SPNG_K_PINF_RESOLVE, q);
+                HIP_TRY(launch_pinf2_resolve(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, pool, g.pages, dr, dd + g.s0, dparts, pm, retry, q));
+                if (pm) HIP_TRY(launch_pinf2_parts(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, pool, g.pages, dr, dd + g.s0, dparts, pm,
+                                                   (uint16_t *)c->d_sym, (uint8_t *)c->d_win + (size_t)g.s0 * pm * 32768, q));
+            }
             HIP_TRY(launch_pinf2_account(ctr, dnext + 8, g.pages, q));
         }
         if (!c->pool_pending) {

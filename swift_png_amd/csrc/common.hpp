@@ -114,6 +114,10 @@ struct PStream {
     // resumable streams (spng_inflate_resume_batch): where to start, and where to note how far the chain got
     uint64_t       start_bit, out_pos;
     uint64_t      *state;
+    // several workgroups per stream: parts_max slots in the part table (0: one workgroup), how many the chain was cut into
+    uint32_t       parts_max, parts;
+    uint64_t       out_total;              // scan: bytes of the whole chain
+    uint64_t       sym_off;                // its 16-bit symbols in the symbol scratch (in symbols)
 };
 enum { PSEG_FAIL = 0, PSEG_CONT = 1, PSEG_FINAL = 2, PSEG_PARTIAL = 3, PSEG_NOPAGE = 4 };
 // One segment: the blocks that start in [index * seg_bytes, (index + 1) * seg_bytes).
@@ -128,6 +132,16 @@ struct PSeg {
     int32_t  status;                       // count: PSEG_*
     uint32_t used;                         // scan: part of the chain
     uint32_t next, pad;                    // count: index of the segment that starts where this one stopped
+    uint64_t nbytes;                       // decode: bytes its tokens stand for
+    uint64_t out_base;                     // scan: its first byte, counted from the stream's first byte of this call
+};
+// A part of a stream's segment chain that one workgroup resolves (pinflate2.hip, "Several workgroups per stream").
+struct PPart {
+    uint32_t seg, seg_end;                 // first chain segment (index in the stream), the next part's (~0: to the chain's end)
+    uint64_t out_pos;                      // first byte, counted from the stream's first byte of this call
+    uint64_t out_len;                      // bytes
+    unsigned long long sumS, sumI;         // Adler-32 partial sums over its bytes (not reduced)
+    uint32_t present, failed;
 };
 
 struct DeflateJob {
@@ -158,9 +172,12 @@ hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result 
 hipError_t launch_pinf2_find(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t retry, hipStream_t stream);
 hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t seg0, uint32_t nsegs, uint32_t *d_pt, uint8_t *d_pool, uint32_t *d_next,
                                uint32_t pages, uint32_t retry, hipStream_t stream);
-hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t retry, hipStream_t stream);
+hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, PPart *d_parts, uint32_t retry, hipStream_t stream);
 hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
-                                spng_result *d_results, int32_t *d_done, uint32_t retry, hipStream_t stream);
+                                spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax, uint32_t retry, hipStream_t stream);
+hipError_t launch_pinf2_parts(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
+                              spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax, uint16_t *d_sym, uint8_t *d_win,
+                              hipStream_t stream);
 hipError_t launch_pinf2_account(const uint32_t *d_ctr, uint32_t *d_totals, uint32_t pages, hipStream_t stream);
 hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 // gzip.hip

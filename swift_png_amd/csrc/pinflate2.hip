@@ -713,7 +713,7 @@ __device__ __forceinline__ void advance_tokens(Cursor &c, uint32_t count, g8 *pb
 template <bool PAIRS>
 __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_t n, uint64_t cb,
                                                  uint64_t entry, uint32_t sdw, const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &cur,
-                                                 uint64_t &next, int lane DP_ARG)
+                                                 uint64_t &next, uint64_t &nbytes, int lane DP_ARG)
 {
     DP(0);
     const uint32_t sb = sdw * 32, chb = sb * 64;
@@ -850,7 +850,7 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     {
         g8 *pa = cur.pa;
         const uint32_t r0 = (uint32_t)(cur.nhw & (PAGE_HW - 1)) + off;
-        uint32_t done = 0, qq = e & 0xffff;
+        uint32_t done = 0, qq = e & 0xffff, nout = 0;
         while (done < mine) {
             DPN(18, 1);
             uint32_t h0 = 0, h1 = 0;
@@ -861,8 +861,10 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
             *token_at(pa, pb, r0 + done) = (uint16_t)h0;
             if (two) *token_at(pa, pb, r0 + done + 1) = (uint16_t)h1;
             done += two ? 2u : 1u;
+            nout += !two ? 1u : k == D2_REF ? (h0 & 0xff) + 3 : 2u;      // the bytes the token stands for
             qq += nb;
         }
+        nbytes += wave_sum(nout);
     }
     advance_tokens(cur, tot, pb);
     DP(5);
@@ -920,7 +922,7 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
     // of the input so far, or not acceptable: the serial kernel, started there, tells which -- and keeps the
     // blocks before it.
     const bool resumable = uni64((uint64_t)st.state) != 0;
-    uint64_t hw_block = 0;
+    uint64_t hw_block = 0, nbytes = 0, bytes_block = 0;
 #ifdef SPNG_D_PROF
     uint64_t dp[32];
     for (int i = 0; i < 32; ++i) dp[i] = 0;
@@ -934,7 +936,7 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
             continue;
         }
         Hdr2 h;
-        hw_block = cur.nhw;
+        hw_block = cur.nhw; bytes_block = nbytes;
         DP(7);
         const bool hok_ = UB(parse_header2(s, src, n, pos, h, lane DP_PASS));
         DP(8);
@@ -955,6 +957,7 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
                     const uint32_t r0 = (uint32_t)(cur.nhw & (PAGE_HW - 1));
                     for (uint32_t i = (uint32_t)lane; i < m; i += 64) *token_at(cur.pa, pb, r0 + i) = (uint16_t)src[from + k + i];
                     advance_tokens(cur, m, pb);
+                    nbytes += m;
                 }
             }
             if (!ok) break;
@@ -972,8 +975,8 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
             for (;;) {
                 uint64_t next;
                 // (two instances of the loops: without pairs in the table a step skips their bookkeeping)
-                state = h.pairs ? UNI(decode_chunk<true>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS))
-                                : UNI(decode_chunk<false>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, lane DP_PASS));
+                state = h.pairs ? UNI(decode_chunk<true>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, nbytes, lane DP_PASS))
+                                : UNI(decode_chunk<false>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, nbytes, lane DP_PASS));
                 entry = uni64(next);
                 if (state) break;
                 cb += (uint64_t)sdw * 32 * 64;
@@ -985,10 +988,10 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
         if (h.bfinal) { status = PSEG_FINAL; break; }
     }
     uint64_t nhw = cur.nhw;
-    if (status == PSEG_FAIL && resumable) { status = PSEG_PARTIAL; nhw = hw_block; }   // (pos is still the block's first bit)
+    if (status == PSEG_FAIL && resumable) { status = PSEG_PARTIAL; nhw = hw_block; nbytes = bytes_block; }   // (pos is still the block's first bit)
     // (no padding: resolve reads whole 16-byte units, inside the last page, and masks what lies behind nhw)
     if (status == PSEG_FAIL && cur.dry) status = PSEG_NOPAGE;
-    if (lane == 0) { sg.end_bit = pos; sg.ntok = nhw; sg.status = status; sg.next = nk; }
+    if (lane == 0) { sg.end_bit = pos; sg.ntok = nhw; sg.nbytes = nbytes; sg.status = status; sg.next = nk; }
 #ifdef SPNG_D_PROF
     if (blockIdx.x == 1 && lane == 0)
         printf("decode: %lu blocks %lu chunks %lu halfwords %lu windows; lane-0 steps r0 %lu r1 %lu replay %lu; cycles: total %lu stage %lu setup %lu round0 %lu "
@@ -1001,8 +1004,14 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
 // One wave per stream walks the chain: segment 0, then the segment decode says it stopped at, ... up to the
 // first one that saw the final block.  A found start that no chain member stops at (a bit pattern inside
 // stored data or in the middle of a block that happens to parse as a header) is simply not on the chain.
+//
+// Several workgroups per stream (st.parts_max > 0: a batch of few streams, each of which would otherwise be resolved by one
+// workgroup at ~0.9 GB/s): the chain is cut, at segment boundaries, into parts of about equal output; a part other than
+// the first does not know the 32 KiB in front of it and resolves to 16-bit SYMBOLS -- a byte, or a marker "byte o of the
+// window in front of this part" -- which a second, memory-bound pass turns into bytes once the windows are known
+// (pinf2_resolve_kernel<_, true>, pinf2_window_kernel, pinf2_fixup_kernel, pinf2_verdict_kernel).
 template <uint32_t RETRY>
-__global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ streams, PSeg *__restrict__ segs)
+__global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ streams, PSeg *__restrict__ segs, PPart *__restrict__ parts)
 {
     constexpr uint32_t retry = RETRY;
     const int lane = threadIdx.x;
@@ -1013,7 +1022,7 @@ __global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ st
     }
     const uint32_t first = UNI(st.seg_first), count = UNI(st.seg_count);
     bool ok = false, partial = false, dry = false;
-    uint64_t tok = 0, end_bit = 0;
+    uint64_t tok = 0, end_bit = 0, out = 0;
     uint32_t k = 0;
     for (uint32_t hops = 0; hops < count; ++hops) {
         PSeg *sg = segs + first + k;
@@ -1021,8 +1030,9 @@ __global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ st
         const int32_t status = (int32_t)UNI(sg->status);
         if (status == PSEG_NOPAGE && start != NONE2) dry = true;
         if (start == NONE2 || status == PSEG_FAIL || status == PSEG_NOPAGE) break;
-        if (lane == 0) { sg->tok_base = tok; sg->used = 1; }
+        if (lane == 0) { sg->tok_base = tok; sg->out_base = out; sg->used = 1; }
         tok += uni64(sg->ntok);
+        out += uni64(sg->nbytes);
         if (status == PSEG_FINAL) { ok = true; end_bit = end; break; }
         if (status == PSEG_PARTIAL) { ok = true; partial = true; end_bit = end; break; }
         const uint32_t nx = UNI(sg->next);
@@ -1030,8 +1040,36 @@ __global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ st
         if (uni64(segs[first + nx].start_bit) != end) break;
         k = nx;
     }
+    // the parts: a new one begins with the first chain segment whose first byte is at or behind the next multiple of 1 / P of
+    // the output (and behind the first 32 KiB, so that every marker names a byte that exists); a stream from its first byte only (no resumed one), and one
+    // that fits its buffer.  (The table arrives zeroed.)
+    const uint32_t pmax = UNI(st.parts_max);
+    uint32_t np = 0;
+    if (pmax > 1 && ok && uni64(st.start_bit) == 0 && uni64(st.out_pos) == 0 && out <= uni64(st.dst_cap) && out > 0) {
+        PPart *pp = parts + (uint64_t)blockIdx.x * pmax;
+        uint64_t begun = 0;                                      // first byte of the part being filled
+        uint32_t kk = 0, tnext = 1;                              // next boundary: the first segment at or behind tnext / pmax
+        np = 1;
+        if (lane == 0) { pp[0].seg = 0; pp[0].out_pos = 0; pp[0].present = 1; }
+        for (uint32_t hops = 0; hops < count; ++hops) {
+            const PSeg *sg = segs + first + kk;
+            const uint64_t ob = uni64(sg->out_base);
+            if (kk != 0 && tnext < pmax && ob >= 32768u && ob > begun && ob * pmax >= (uint64_t)tnext * out) {
+                if (lane == 0) {
+                    pp[np].seg = kk; pp[np].out_pos = ob; pp[np].present = 1;
+                    pp[np - 1].seg_end = kk; pp[np - 1].out_len = ob - begun;
+                }
+                begun = ob; np += 1;
+                tnext = (uint32_t)(ob * pmax / out) + 1;
+            }
+            if ((int32_t)UNI(sg->status) == PSEG_FINAL || (int32_t)UNI(sg->status) == PSEG_PARTIAL) break;
+            kk = UNI(sg->next);
+        }
+        if (lane == 0) { pp[np - 1].seg_end = ~0u; pp[np - 1].out_len = out - begun; }
+    }
     // pass: 1 = the chain broke where the token pool was empty: once more, with the pool to itself and its like (retry)
-    if (lane == 0) { st.ok = ok ? (partial ? 2 : 1) : 0; st.ntok = tok; st.end_bit = end_bit; st.pass = (!retry && dry) ? 1 : 0; st.tok_base = 0; }
+    if (lane == 0) { st.ok = ok ? (partial ? 2 : 1) : 0; st.ntok = tok; st.end_bit = end_bit; st.pass = (!retry && dry) ? 1 : 0; st.tok_base = 0;
+                     st.out_total = out; st.parts = np; }
 }
 
 // ---- resolve: tokens -> bytes -------------------------------------------------------------------------------
@@ -1050,8 +1088,13 @@ static constexpr uint32_t WINDOW2 = 32768;           // the DEFLATE window
 static constexpr uint32_t R2_DONE = 0x8000;          // state: R2_DONE | byte, or the tile index of an earlier byte
 static constexpr uint32_t PTC = 256;                 // page-table entries cached in LDS
 
-struct RLds2 {
-    uint8_t  ring[WINDOW2];            // the last 32 KiB of output, at position mod 32 KiB
+// MARK (a part that does not know the window in front of it): the ring and the states hold SYMBOLS -- 0x4000 | byte, or
+// 0x8000 | o = byte o of the 32 KiB in front of the part -- and a state below 0x2000 is the tile index of an earlier byte.
+template <bool MARK> struct RingOf { typedef uint8_t T; };
+template <> struct RingOf<true> { typedef uint16_t T; };
+template <bool MARK>
+struct RLds2T {
+    typename RingOf<MARK>::T ring[WINDOW2];   // the last 32 KiB of output, at position mod 32 KiB
     uint16_t state[TILE2];
     uint32_t rec[MAXM2 + 2][2];        // back-references of the tile: first byte | run << 16; distance ([0]: none, run 0; [last]: keeps what follows 16-byte aligned)
     uint32_t bitmap[TILE2 / 32];       // their first bytes
@@ -1061,10 +1104,12 @@ struct RLds2 {
     uint32_t again[3];                 // pointer jumping: somebody still has an unknown byte (flag of round r: r mod 3)
     uint32_t cut[2];                   // where the tile ends when the window holds more than a tile: bytes, halfword
 };
+typedef RLds2T<false> RLds2;
 
 // exclusive prefix sum over the workgroup; every thread gets the grand total too.  One barrier: s.part is not touched
 // again before the next barrier of the caller.
-__device__ __forceinline__ uint32_t block_excl_scan2(RLds2 &s, uint32_t v, uint32_t &total, int tid)
+template <class L>
+__device__ __forceinline__ uint32_t block_excl_scan2(L &s, uint32_t v, uint32_t &total, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t wt;
@@ -1082,26 +1127,85 @@ __device__ __forceinline__ uint32_t block_excl_scan2(RLds2 &s, uint32_t v, uint3
     return off + before;
 }
 
-template <uint32_t RETRY>
+// What a stream whose chain was resolved to its end has to say (one thread).  S = sum b_i, I = sum i * b_i (mod 65521)
+// over the bytes this call produced, pos = bytes in the output.
+__device__ __forceinline__ void stream_verdict(const PStream &st, uint32_t S, uint32_t I, uint64_t pos, spng_result *__restrict__ results,
+                                               int32_t *__restrict__ done)
+{
+    const g8 *src = (const g8 *)st.src;
+    const uint64_t n = st.src_len;
+    uint64_t *state = st.state;
+    // what was in front of this call (spng_inflate_resume_batch): the sum above then lacks those bytes
+    const bool whole = st.start_bit == 0 && st.out_pos == 0;
+    if (st.ok == 2) {
+        // the chain stopped in front of a block the input does not hold completely (or that is not acceptable): the
+        // serial kernel goes on from there
+        state[0] = st.end_bit; state[1] = pos;
+    } else if (!whole) {
+        // resumed and complete: the trailer must be there; the sum over ALL bytes is compared afterwards (gzip.hip)
+        const uint64_t endb = (st.end_bit + 7) / 8, consumed = endb + (st.format == SPNG_FORMAT_ZLIB ? 4 : 0);
+        spng_result &res = results[st.image];
+        if (consumed <= n) {
+            res.status = SPNG_DONE; res.reserved = 1;
+            res.written = pos; res.consumed = consumed;
+            res.aux[0] = res.aux[1] = 0;
+            *done = 1;
+        }   // (else: the serial kernel, from where this call started, reports "need more input")
+    } else {
+        const uint64_t endb = (st.end_bit + 7) / 8;
+        spng_result &res = results[st.image];
+        if (st.format == SPNG_FORMAT_IOS) {
+            res.status = SPNG_DONE; res.reserved = 1;
+            res.written = pos; res.consumed = endb;
+            res.aux[0] = res.aux[1] = 0;
+            *done = 1;
+        } else if (endb + 4 <= n) {
+            // .checksum (InflatorBuffers.swift:112-130; Stream.swift:402-429): Adler-32 from S and I:
+            // a = 1 + S, b = N + N * S - I  (i counted from 0)
+            const uint32_t declared = (uint32_t)src[endb] << 24 | (uint32_t)src[endb + 1] << 16 |
+                                      (uint32_t)src[endb + 2] << 8 | (uint32_t)src[endb + 3];
+            const uint32_t N = (uint32_t)(pos % 65521);
+            const uint32_t computed = (uint32_t)((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
+            // every block was taken: a checksum that differs is the stream's own (invalidStreamChecksum(declared:computed:))
+            res.status = declared == computed ? SPNG_DONE : SPNG_E_STREAM_CHECKSUM; res.reserved = 1;
+            res.written = pos; res.consumed = endb + 4;
+            res.aux[0] = declared == computed ? 0 : declared; res.aux[1] = declared == computed ? 0 : computed;
+            *done = 1;
+        }   // (else the trailer is cut off: the serial kernel says so)
+    }
+}
+
+// parts / pmax: the part table (scan) when streams may be cut into parts (pmax slots each; 0: they are not).  MARK = false
+// resolves a whole stream, or its first part (grid = streams); MARK = true the parts behind the first (grid = streams x
+// (pmax - 1)) into symbols at sym[st.sym_off + position].
+template <uint32_t RETRY, bool MARK>
 __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const PStream *__restrict__ streams, const PSeg *__restrict__ segs,
                                                                const uint32_t *__restrict__ pt_slab, DPool pool,
-                                                               spng_result *__restrict__ results, int32_t *__restrict__ done)
+                                                               spng_result *__restrict__ results, int32_t *__restrict__ done,
+                                                               PPart *__restrict__ parts, uint32_t pmax, uint16_t *__restrict__ sym)
 {
     constexpr uint32_t retry = RETRY;
-    __shared__ __attribute__((aligned(16))) RLds2 s;
+    constexpr uint32_t DONE = MARK ? 0x4000u : R2_DONE;       // a state that is a byte ...
+    constexpr uint32_t KNOWN = MARK ? 0xc000u : R2_DONE;      // ... or, MARK, a marker: nothing left to look up
+    __shared__ __attribute__((aligned(16))) RLds2T<MARK> s;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)UNI((uint32_t)tid >> 6);
-    const PStream &st = streams[blockIdx.x];
-    if (!UNI(st.ok) || (retry && done[blockIdx.x])) return;
+    const uint32_t sidx = MARK ? blockIdx.x / (pmax - 1) : blockIdx.x;
+    const uint32_t pidx = MARK ? 1 + blockIdx.x % (pmax - 1) : 0;
+    const PStream &st = streams[sidx];
+    if (!UNI(st.ok) || (retry && done[sidx])) return;
+    const uint32_t nparts = pmax ? UNI(st.parts) : 0;           // > 1: the stream is resolved in parts
+    if (MARK && pidx >= nparts) return;
+    PPart *part = nparts > 1 ? parts + (uint64_t)sidx * pmax + pidx : nullptr;
+    const uint32_t seg_end = part ? UNI(part->seg_end) : ~0u;
+    const uint64_t part_pos = part ? uni64(part->out_pos) : 0;  // (MARK: markers count from here)
     g8 *dst = (g8 *)uni64((uint64_t)st.dst);
     const uint64_t cap = uni64(st.dst_cap);
-    const g8 *src = (const g8 *)uni64((uint64_t)st.src);
-    const uint64_t n = uni64(st.src_len);
-    uint64_t pos = uni64(st.out_pos);                  // (resumable streams: the bytes earlier calls produced are in dst)
+    uint64_t pos = uni64(st.out_pos) + part_pos;       // (resumable streams: the bytes earlier calls produced are in dst)
     uint32_t accS = 0, accI = 0;                     // Adler-32 partial sums (inflate.hip: struct Out)
     uint32_t pmod = (uint32_t)(pos % 65521);          // pos mod 65521, kept along
     bool bad = false, over = false;
-    uint64_t *state = (uint64_t *)uni64((uint64_t)st.state);
-    if (pos) {
+    g16 *symo = MARK ? (g16 *)(sym + uni64(st.sym_off)) : nullptr;
+    if (!MARK && pos) {
         // the window so far
         for (uint64_t p = (pos > WINDOW2 ? pos - WINDOW2 : 0) + (uint32_t)tid; p < pos; p += RT2) s.ring[p & (WINDOW2 - 1)] = dst[p];
     }
@@ -1110,7 +1214,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
     if (tid == 0) { s.rec[0][0] = 0; s.rec[0][1] = 1; }
     __syncthreads();
     const uint32_t seg_first = UNI(st.seg_first), seg_count = UNI(st.seg_count);
-    uint32_t sk = 0;
+    uint32_t sk = part ? UNI(part->seg) : 0;
 #ifdef SPNG_D_PROF
     uint64_t rp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, rp_t = __builtin_readcyclecounter();
 #define RP2(k) do { const uint64_t now_ = __builtin_readcyclecounter(); rp[k] += now_ - rp_t; rp_t = now_; } while (0)
@@ -1120,7 +1224,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
 #define RPN2(k, v)
 #endif
     constexpr uint32_t NULL2 = TK_NULL | TK_NULL << 16;
-    for (uint32_t hops = 0; hops < seg_count && !over; ++hops) {
+    for (uint32_t hops = 0; hops < seg_count && !over && sk != seg_end; ++hops) {
         const PSeg &sg = segs[seg_first + sk];
         const uint64_t nhw = uni64(sg.ntok);
         const g32 *ptg = (const g32 *)(pt_slab + uni64(sg.log_off));
@@ -1183,7 +1287,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
 #pragma unroll
                 for (int j = 0; j < (int)HPT2; ++j) {
                     const uint32_t v = hh[j];
-                    if (!(v & 0x8000)) { s.state[curb] = (uint16_t)(R2_DONE | v); curb += 1; }
+                    if (!(v & 0x8000)) { s.state[curb] = (uint16_t)(DONE | v); curb += 1; }
                     else if ((v & 0xC000) == 0x8000) {
                         const uint32_t len = (v & 0xff) + 3;
                         const uint32_t h1 = j < (int)HPT2 - 1 ? hh[j < (int)HPT2 - 1 ? j + 1 : (int)HPT2 - 1] : hnext;
@@ -1213,7 +1317,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
             RP2(2);
             // ---- expand: the reference (if any) that covers each of my bytes
             const uint32_t rbase = (uint32_t)pos & (WINDOW2 - 1);
-            const bool early = pos < WINDOW2;                        // (only there can a distance reach in front of the output)
+            const bool early = pos - part_pos < WINDOW2;             // (only there can a distance reach in front of the output / the part)
             uint32_t sv[BPT2];
             {
                 // back-references that start in front of each row: prefix sum over the bitmap (lane l: rows 2l, 2l + 1)
@@ -1260,10 +1364,17 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         const int k = part * (int)EB2 + kk;
                         const uint32_t j = ((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane;
                         const uint32_t si = siv[kk];
-                        sv[k] = R2_DONE;
+                        sv[k] = DONE;
                         if (si != 0x7fffffffu) {
-                            if (early && (int32_t)si < 0 && (uint32_t)pos < 0u - si) bad = true;
-                            const uint32_t v = (int32_t)si < 0 ? R2_DONE | farv[kk] : si;
+                            uint32_t v;
+                            if (MARK) {
+                                // in front of the tile: the symbol in the ring, or -- in front of the part -- a marker
+                                const uint32_t rel = (uint32_t)(pos - part_pos) + si;             // (from the part's first byte)
+                                v = (int32_t)si >= 0 ? si : (!early || (int32_t)rel >= 0) ? farv[kk] : 0x8000u | (rel + WINDOW2);
+                            } else {
+                                if (early && (int32_t)si < 0 && (uint32_t)pos < 0u - si) bad = true;
+                                v = (int32_t)si < 0 ? DONE | farv[kk] : si;
+                            }
                             sv[k] = v;
                             s.state[j] = (uint16_t)v;
                         }
@@ -1278,12 +1389,12 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                 bool more = false;
                 uint32_t gv[BPT2];
 #pragma unroll
-                for (int k = 0; k < (int)BPT2; ++k) { gv[k] = R2_DONE; if (!(sv[k] & R2_DONE)) gv[k] = s.state[sv[k]]; }
+                for (int k = 0; k < (int)BPT2; ++k) { gv[k] = DONE; if (!(sv[k] & KNOWN)) gv[k] = s.state[sv[k]]; }
 #pragma unroll
                 for (int k = 0; k < (int)BPT2; ++k) {
-                    if (!(sv[k] & R2_DONE)) {
+                    if (!(sv[k] & KNOWN)) {
                         const uint32_t j = ((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane;
-                        sv[k] = gv[k]; s.state[j] = (uint16_t)gv[k]; more = more || !(gv[k] & R2_DONE);
+                        sv[k] = gv[k]; s.state[j] = (uint16_t)gv[k]; more = more || !(gv[k] & KNOWN);
                     }
                 }
                 // one barrier per round.  Three flags in rotation: the one cleared here was last read before
@@ -1305,11 +1416,19 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
 #pragma unroll
                 for (int k = 0; k < (int)BPT2; ++k) {
                     const uint32_t j = ((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane;
-                    if (j < tlen) s.ring[(rbase + j) & (WINDOW2 - 1)] = (uint8_t)bv[k];
+                    if (j < tlen) s.ring[(rbase + j) & (WINDOW2 - 1)] = (typename RingOf<MARK>::T)bv[k];
                 }
             }
             __syncthreads();
-            {
+            if constexpr (MARK) {
+                // symbols, eight to a 16-byte unit of the position; what lies in front of the part is its neighbour's to write
+                const uint64_t u0 = pos >> 3, u1 = (pos + tlen) >> 3;
+                for (uint64_t u = u0 + (uint32_t)tid; u < u1; u += RT2) {
+                    const uint16_t *r = s.ring + ((u << 3) & (WINDOW2 - 1));
+                    if ((u << 3) >= part_pos) ((gPV4 *)(symo + (u << 3)))->v = *(const v4u *)r;
+                    else for (int c = 0; c < 8; ++c) if ((u << 3) + c >= part_pos) symo[(u << 3) + c] = r[c];
+                }
+            } else {
                 const uint64_t u0 = pos >> 4, u1 = (pos + tlen) >> 4;
                 for (uint64_t u = u0 + (uint32_t)tid; u < u1; u += RT2) {
                     const v4u v = *(const v4u *)(s.ring + ((u << 4) & (WINDOW2 - 1)));
@@ -1343,7 +1462,10 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
 #endif
     // the bytes behind the last whole unit
     __syncthreads();
-    {
+    if constexpr (MARK) {
+        const uint64_t u1 = pos >> 3 << 3, at = u1 + (uint32_t)tid;
+        if (!over && at < pos && at >= part_pos) symo[at] = s.ring[at & (WINDOW2 - 1)];
+    } else {
         const uint64_t u1 = pos >> 4 << 4;
         if (!over && u1 + (uint32_t)tid < pos) {
             const uint32_t b = s.ring[(u1 + (uint32_t)tid) & (WINDOW2 - 1)];
@@ -1354,8 +1476,12 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
         }
     }
     // ---- verdict
-    if (__syncthreads_or(bad || over)) return;                  // leave it to the serial kernel
-    {
+    if (__syncthreads_or(bad || over)) {                        // leave it to the serial kernel
+        if (part && tid == 0) part->failed = 1;
+        return;
+    }
+    if constexpr (MARK) return;                                 // (pinf2_fixup_kernel sums the bytes, pinf2_verdict_kernel judges)
+    else {
         // S = sum b_i, I = sum i * b_i (mod 65521) over the workgroup
         const uint32_t S1 = wave_sum(accS) % 65521, I1 = wave_sum(accI % 65521) % 65521;
         __syncthreads();
@@ -1364,45 +1490,116 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
         uint32_t S = 0, I = 0;
         for (int w = 0; w < (int)NW2; ++w) { S += s.part[w]; I += s.part[NW2 + w]; }
         S %= 65521; I %= 65521;
-        // what was in front of this call (spng_inflate_resume_batch): the sum above then lacks those bytes
-        const bool whole = uni64(st.start_bit) == 0 && uni64(st.out_pos) == 0;
-        if (tid == 0 && st.ok == 2) {
-            // the chain stopped in front of a block the input does not hold completely (or that is not acceptable): the
-            // serial kernel goes on from there
-            state[0] = st.end_bit; state[1] = pos;
-        } else if (tid == 0 && !whole) {
-            // resumed and complete: the trailer must be there; the sum over ALL bytes is compared afterwards (gzip.hip)
-            const uint64_t endb = (st.end_bit + 7) / 8, consumed = endb + (st.format == SPNG_FORMAT_ZLIB ? 4 : 0);
-            spng_result &res = results[st.image];
-            if (consumed <= n) {
-                res.status = SPNG_DONE; res.reserved = 1;
-                res.written = pos; res.consumed = consumed;
-                res.aux[0] = res.aux[1] = 0;
-                done[blockIdx.x] = 1;
-            }   // (else: the serial kernel, from where this call started, reports "need more input")
-        } else if (tid == 0) {
-            const uint64_t endb = (st.end_bit + 7) / 8;
-            spng_result &res = results[st.image];
-            if (st.format == SPNG_FORMAT_IOS) {
-                res.status = SPNG_DONE; res.reserved = 1;
-                res.written = pos; res.consumed = endb;
-                res.aux[0] = res.aux[1] = 0;
-                done[blockIdx.x] = 1;
-            } else if (endb + 4 <= n) {
-                // .checksum (InflatorBuffers.swift:112-130; Stream.swift:402-429): Adler-32 from S and I:
-                // a = 1 + S, b = N + N * S - I  (i counted from 0)
-                const uint32_t declared = (uint32_t)src[endb] << 24 | (uint32_t)src[endb + 1] << 16 |
-                                          (uint32_t)src[endb + 2] << 8 | (uint32_t)src[endb + 3];
-                const uint32_t N = (uint32_t)(pos % 65521);
-                const uint32_t computed = (uint32_t)((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
-                // every block was taken: a checksum that differs is the stream's own (invalidStreamChecksum(declared:computed:))
-                res.status = declared == computed ? SPNG_DONE : SPNG_E_STREAM_CHECKSUM; res.reserved = 1;
-                res.written = pos; res.consumed = endb + 4;
-                res.aux[0] = declared == computed ? 0 : declared; res.aux[1] = declared == computed ? 0 : computed;
-                done[blockIdx.x] = 1;
-            }   // (else the trailer is cut off: the serial kernel says so)
+        if (part) {                                             // the first of several parts: its sums, no verdict yet
+            if (tid == 0) { part->sumS = S; part->sumI = I; }
+            return;
+        }
+        if (tid == 0) stream_verdict(st, S, I, pos, results, done + sidx);
+    }
+}
+
+// ---- several workgroups per stream: windows, symbols -> bytes, verdict ------------------------------------------
+// The 32 KiB in front of every part behind the first, part after part (one workgroup per stream): the bytes of the first
+// part, or the symbols of the part before with ITS window put in for the markers -- 32 KiB per step.  win[(stream * pmax + p)
+// * 32768 + o] = byte o of the window of part p.
+__global__ __launch_bounds__(512) void pinf2_window_kernel(const PStream *__restrict__ streams, const PPart *__restrict__ parts, uint32_t pmax,
+                                                           const uint16_t *__restrict__ sym, uint8_t *__restrict__ win)
+{
+    const PStream &st = streams[blockIdx.x];
+    const uint32_t np = UNI(st.parts);
+    if (!UNI(st.ok) || np < 2) return;
+    const PPart *pp = parts + (uint64_t)blockIdx.x * pmax;
+    const g8 *dst = (const g8 *)uni64((uint64_t)st.dst);
+    const g16 *symo = (const g16 *)(sym + uni64(st.sym_off));
+    g8 *w = (g8 *)win + (uint64_t)blockIdx.x * pmax * WINDOW2;
+    for (uint32_t p = 1; p < np; ++p) {
+        const uint64_t from = uni64(pp[p].out_pos) - WINDOW2, before = uni64(pp[p - 1].out_pos);     // (out_pos >= 32768)
+        for (uint32_t o = threadIdx.x; o < WINDOW2; o += 512) {
+            const uint64_t a = from + o;
+            uint32_t b;
+            if (p == 1) b = dst[a];
+            else if (a >= before) {
+                const uint32_t v = symo[a];
+                b = v & 0x8000 ? w[(uint64_t)(p - 1) * WINDOW2 + (v & 0x7fff)] : v & 0xff;
+            } else b = w[(uint64_t)(p - 1) * WINDOW2 + (uint32_t)(a - (before - WINDOW2))];
+            w[(uint64_t)p * WINDOW2 + o] = (uint8_t)b;
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+// Symbols -> bytes for the parts behind the first, and their Adler-32 sums (grid = (FIX_WG, streams * (pmax - 1)), 256
+// threads, eight bytes per thread and step).
+static constexpr uint32_t FIX_WG = 32;
+__global__ __launch_bounds__(256) void pinf2_fixup_kernel(const PStream *__restrict__ streams, PPart *__restrict__ parts, uint32_t pmax,
+                                                          const uint16_t *__restrict__ sym, const uint8_t *__restrict__ win)
+{
+    const uint32_t sidx = blockIdx.y / (pmax - 1), pidx = 1 + blockIdx.y % (pmax - 1);
+    const PStream &st = streams[sidx];
+    if (!UNI(st.ok) || pidx >= UNI(st.parts)) return;
+    PPart &part = parts[(uint64_t)sidx * pmax + pidx];
+    if (UNI(part.failed)) return;
+    const uint64_t p0 = uni64(part.out_pos), p1 = p0 + uni64(part.out_len);
+    g8 *dst = (g8 *)uni64((uint64_t)st.dst);
+    const g16 *symo = (const g16 *)(sym + uni64(st.sym_off));
+    const g8 *w = (const g8 *)win + ((uint64_t)sidx * pmax + pidx) * WINDOW2;
+    unsigned long long S = 0, I = 0;
+    const uint64_t u0 = p0 >> 3, u1 = (p1 + 7) >> 3;
+    for (uint64_t u = u0 + (uint64_t)blockIdx.x * 256 + threadIdx.x; u < u1; u += (uint64_t)FIX_WG * 256) {
+        const uint64_t at = u << 3;
+        const bool inner = at >= p0 && at + 8 <= p1;
+        uint32_t b[8];
+        if (inner) {
+            const v4u v = ((const gPV4 *)(symo + at))->v;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b[c] = (v[c >> 1] >> (16 * (c & 1))) & 0xffff;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) b[c] = (at + c >= p0 && at + c < p1) ? (uint32_t)symo[at + c] : 0x4000u;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) b[c] = b[c] & 0x8000 ? (uint32_t)w[b[c] & 0x7fff] : b[c] & 0xff;
+        if (inner) {
+            v2u o;
+            o[0] = b[0] | b[1] << 8 | b[2] << 16 | b[3] << 24; o[1] = b[4] | b[5] << 8 | b[6] << 16 | b[7] << 24;
+            ((gPV2 *)(dst + at))->v = o;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) if (at + c >= p0 && at + c < p1) dst[at + c] = (uint8_t)b[c];
+        }
+        const uint32_t g = (uint32_t)(at % 65521);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bool mine = inner || (at + c >= p0 && at + c < p1);
+            const uint32_t v = mine ? b[c] : 0u;
+            S += v; I += (unsigned long long)((g + (uint32_t)c) % 65521u) * v;
         }
     }
+    // (64-bit sums without reduction: a part is far below 2^40 bytes)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        S += (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)S, m, 64) | (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(S >> 32), m, 64) << 32;
+        I += (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)I, m, 64) | (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(I >> 32), m, 64) << 32;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&part.sumS, S); atomicAdd(&part.sumI, I); }
+}
+
+// The verdict of a stream that was resolved in parts (one thread per stream).
+__global__ void pinf2_verdict_kernel(const PStream *__restrict__ streams, const PPart *__restrict__ parts, uint32_t pmax,
+                                     spng_result *__restrict__ results, int32_t *__restrict__ done, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const PStream &st = streams[i];
+    if (!st.ok || st.parts < 2 || done[i]) return;
+    const PPart *pp = parts + (uint64_t)i * pmax;
+    unsigned long long S = 0, I = 0;
+    for (uint32_t p = 0; p < st.parts; ++p) {
+        if (pp[p].failed) return;                               // (the serial kernel takes the stream)
+        S = (S + pp[p].sumS % 65521) % 65521; I = (I + pp[p].sumI % 65521) % 65521;
+    }
+    stream_verdict(st, (uint32_t)S, (uint32_t)I, st.out_total, results, done + i);
 }
 
 // pages a pass took: its page counter into the batch's totals = {pages, some pass ran dry}
@@ -1429,18 +1626,30 @@ hipError_t launch_pinf2_decode(PStream *d_streams, PSeg *d_segs, uint32_t seg0, 
     else pinf2_decode_kernel<0><<<nsegs, 64, 0, stream>>>(d_streams, d_segs, d_pt, pool, seg0);
     return hipGetLastError();
 }
-hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t retry, hipStream_t stream)
+hipError_t launch_pinf2_scan(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, PPart *d_parts, uint32_t retry, hipStream_t stream)
 {
-    if (retry) pinf2_scan_kernel<1><<<nstreams, 64, 0, stream>>>(d_streams, d_segs);
-    else pinf2_scan_kernel<0><<<nstreams, 64, 0, stream>>>(d_streams, d_segs);
+    if (retry) pinf2_scan_kernel<1><<<nstreams, 64, 0, stream>>>(d_streams, d_segs, d_parts);
+    else pinf2_scan_kernel<0><<<nstreams, 64, 0, stream>>>(d_streams, d_segs, d_parts);
     return hipGetLastError();
 }
 hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
-                                spng_result *d_results, int32_t *d_done, uint32_t retry, hipStream_t stream)
+                                spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax, uint32_t retry, hipStream_t stream)
 {
     DPool pool{d_pool, nullptr, pages, 0};
-    if (retry) pinf2_resolve_kernel<1><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done);
-    else pinf2_resolve_kernel<0><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done);
+    if (retry) pinf2_resolve_kernel<1, false><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, nullptr);
+    else pinf2_resolve_kernel<0, false><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, nullptr);
+    return hipGetLastError();
+}
+// the parts behind the first of every stream, the windows, symbols -> bytes, the verdicts (pmax >= 2)
+hipError_t launch_pinf2_parts(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
+                              spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax, uint16_t *d_sym, uint8_t *d_win,
+                              hipStream_t stream)
+{
+    DPool pool{d_pool, nullptr, pages, 0};
+    pinf2_resolve_kernel<0, true><<<nstreams * (pmax - 1), RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, d_sym);
+    pinf2_window_kernel<<<nstreams, 512, 0, stream>>>(d_streams, d_parts, pmax, d_sym, d_win);
+    pinf2_fixup_kernel<<<dim3(FIX_WG, nstreams * (pmax - 1)), 256, 0, stream>>>(d_streams, d_parts, pmax, d_sym, d_win);
+    pinf2_verdict_kernel<<<(nstreams + 63) / 64, 64, 0, stream>>>(d_streams, d_parts, pmax, d_results, d_done, nstreams);
     return hipGetLastError();
 }
 hipError_t launch_pinf2_account(const uint32_t *d_ctr, uint32_t *d_totals, uint32_t pages, hipStream_t stream)

@@ -144,3 +144,51 @@ def test_emulated_pipeline_stops_in_front_of_a_corrupt_block(emu, tmp_path):
     (tmp_path / "raw").write_bytes(rows)
     r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", "1048576"], capture_output=True, text=True, timeout=600)
     assert r.returncode in (3, 4, 5), (r.returncode, r.stdout[-300:])
+
+
+def part_cases():
+    """streams of several blocks and >= 150 KB of output: the chain can be cut into parts"""
+    rng = np.random.default_rng(11)
+    rows = scanlines(7, 56 * 4096)
+    yield "zlib6", deflate(rows, 6), rows, 4096
+    t16 = rng.integers(0, 16, 150000, dtype=np.uint8).tobytes()
+    yield "text16", deflate(t16, 6, 15, zlib.Z_HUFFMAN_ONLY), t16, 4096
+    # runs that reach back across part boundaries: zeros and a 4-byte period, a block every 40 KB, tiny compressed blocks
+    def flushed(data, step):
+        co = zlib.compressobj(6)
+        out = b""
+        for i in range(0, len(data), step):
+            out += co.compress(data[i:i + step]) + co.flush(zlib.Z_FULL_FLUSH if (i // step) % 2 else zlib.Z_SYNC_FLUSH)
+        return out + co.flush()
+    z0 = bytes(200000)
+    yield "zeros", flushed(z0, 20000), z0, 256
+    p4 = bytes([1, 2, 3, 255]) * 40000
+    yield "period4", flushed(p4, 20000), p4, 256
+    mixed = bytes(60000) + rows[:80000] + bytes([9, 8, 7]) * 20000 + rows[80000:120000]
+    yield "mixed", flushed(mixed, 15000), mixed, 512
+
+
+PART_CASES = list(part_cases())
+
+
+@pytest.mark.parametrize("parts", [4])
+@pytest.mark.parametrize("name", [c[0] for c in PART_CASES])
+def test_emulated_pipeline_resolves_a_stream_in_parts(emu, tmp_path, name, parts):
+    """several workgroups per stream (api.hip: batches of few streams): the chain cut into parts, those behind the first resolved
+    to symbols with markers for what lies in front of them, the windows handed from part to part, symbols -> bytes, one verdict
+    (Adler-32 over all parts) -- the same bytes and the same result as one workgroup gives"""
+    _, z, raw, segment = next(c for c in PART_CASES if c[0] == name)
+    assert zlib.decompress(z) == raw
+    (tmp_path / "z").write_bytes(z)
+    (tmp_path / "raw").write_bytes(raw)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", str(segment)], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, EMU_PARTS=str(parts)))
+    assert r.returncode == 0, (name, r.stdout[-300:], r.stderr[-300:])
+    made = int(r.stdout.split("parts:")[1].split()[0])
+    assert 2 <= made <= parts, r.stdout
+    # a wrong Adler-32 is the pipeline's own verdict in parts too
+    bad = bytearray(z); bad[-1] ^= 0x20
+    (tmp_path / "z").write_bytes(bytes(bad))
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", str(segment)], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, EMU_PARTS=str(parts)))
+    assert r.returncode == 5 and "error" in r.stdout, (r.returncode, r.stdout[-300:])

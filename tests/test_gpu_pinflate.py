@@ -148,6 +148,45 @@ def test_two_halves_on_two_streams(gpu, pool):
         s.configure(spng.CFG_TOKEN_BYTES, 0)
 
 
+@pytest.mark.parametrize("parts", [0, 1, 7, 64])
+def test_streams_resolved_by_several_workgroups(gpu, parts):
+    """SPNG_CFG_RESOLVE_PARTS (batches of <= 384 streams): a stream's chain cut into parts that resolve side by side -- symbols with
+    markers for what lies in front of a part, windows handed from part to part, symbols -> bytes, one verdict.  Whatever the
+    number of parts (0: automatic, 1: one workgroup as in large batches), every stream -- long zero runs and 4-byte periods
+    that reach across parts, stored data, flushes, a truncated one, a wrong Adler-32, empty input -- gives the oracle's status,
+    byte count, bytes and error payload."""
+    s = gpu.load()
+    rng = np.random.default_rng(7)
+    co = zlib.compressobj(6)
+    flat = bytes(3 << 20)
+    zeros = b"".join(co.compress(flat[i:i + 50000]) + co.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(flat), 50000)) + co.flush()
+    co = zlib.compressobj(6)
+    per = bytes([7, 0, 255, 3]) * (1 << 19)
+    period = b"".join(co.compress(per[i:i + 70000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(per), 70000)) + co.flush()
+    datas = [scanlines(60 + i, int(4096 * rng.integers(200, 900))) for i in range(5)]
+    zs = [zlib.compress(d, int(rng.integers(1, 10))) for d in datas] + [zeros, period, make("stored_mix", 2 << 20), make("flushes", 3 << 20), b""]
+    wants = datas + [flat, per, zlib.decompress(zs[7]), zlib.decompress(zs[8]), b""]
+    zs[1] = zs[1][:len(zs[1]) * 3 // 5]                                         # truncated inside a block
+    bad = bytearray(zs[3]); bad[-3] ^= 0x08; zs[3] = bytes(bad)                 # Adler-32
+    d_in = [s.to_device(z) for z in zs]
+    caps = [len(w) + 32 for w in wants]
+    s.configure(spng.CFG_RESOLVE_PARTS, parts)
+    try:
+        for _ in range(2):
+            outs, res = s.inflate_batch(d_in, caps)
+            for i, z in enumerate(zs):
+                st, out, used, aux = ph.orc_inflate(z, 0, cap=caps[i])
+                assert (res[i].status, res[i].written) == (st, len(out)), (i, res[i].status, st, res[i].written, len(out))
+                assert bytes(outs[i][:len(out)].cpu().numpy()) == out, i
+                if st == 0:
+                    assert res[i].consumed == used
+                elif st != spng.NEED_MORE_INPUT:
+                    assert tuple(res[i].aux) == tuple(aux), i
+            assert sum(r.reserved == 1 for r in res) >= 8                          # (the pipeline's own results)
+    finally:
+        s.configure(spng.CFG_RESOLVE_PARTS, 0)
+
+
 def test_damaged_streams_cost_one_block_not_the_batch(gpu):
     """VERDICT r2 "bound the fallback cost": a batch with one stream whose Adler-32 trailer is wrong and one that is cut off
     in the middle of a block.  Statuses, byte counts and payloads are the oracle's (LZ77.InflatorBuffers.swift:112-130); the

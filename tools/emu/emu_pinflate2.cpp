@@ -70,7 +70,16 @@ int main(int argc, char **argv)
     if (verbose) for (uint64_t q = 0; q < k; ++q)
         fprintf(stderr, "seg %llu: end %lld status %d nhw %llu next %u\n", (unsigned long long)q, (long long)segs[q].end_bit, segs[q].status,
                 (unsigned long long)segs[q].ntok, segs[q].next);
-    emu::launch(1, 64, [&] { pinf2_scan_kernel<0>(&st, segs.data()); });
+    // EMU_PARTS=n: the stream's chain in up to n parts, resolved by n workgroups (what api.hip does for batches of few streams)
+    const uint32_t pmax = getenv("EMU_PARTS") ? (uint32_t)atoi(getenv("EMU_PARTS")) : 0;
+    std::vector<PPart> parts(pmax ? pmax : 1);
+    memset(parts.data(), 0, parts.size() * sizeof(PPart));
+    std::vector<uint16_t> sym(pmax ? want.size() + 4096 + 64 : 8, 0xEEEE);
+    std::vector<uint8_t> win((size_t)(pmax ? pmax : 1) * 32768, 0xCD);
+    st.parts_max = pmax; st.sym_off = 0;
+    emu::launch(1, 64, [&] { pinf2_scan_kernel<0>(&st, segs.data(), parts.data()); });
+    if (verbose && pmax) for (uint32_t q = 0; q < st.parts; ++q)
+        fprintf(stderr, "part %u: seg %u .. %u out %llu + %llu\n", q, parts[q].seg, parts[q].seg_end, (unsigned long long)parts[q].out_pos, (unsigned long long)parts[q].out_len);
     if (verbose) fprintf(stderr, "stream: ok %d nhw %llu end_bit %llu pages used %u\n", st.ok, (unsigned long long)st.ntok, (unsigned long long)st.end_bit, next);
     {   // the token stream, expanded the plain way: tells a decode bug from a resolve bug
         std::vector<uint8_t> out(st.out_pos ? std::vector<uint8_t>(want.begin(), want.begin() + st.out_pos) : std::vector<uint8_t>());
@@ -99,7 +108,14 @@ int main(int argc, char **argv)
         if (verbose || i != out.size() || (st.ok == 1 && out.size() != want.size()))
             fprintf(stderr, "token stream expands to %zu bytes, agrees with the expected bytes up to %zu of %zu\n", out.size(), i, want.size());
     }
-    emu::launch(1, RT2, [&] { pinf2_resolve_kernel<0>(&st, segs.data(), pt.data(), pool, &res, &done); });
+    emu::launch(1, RT2, [&] { pinf2_resolve_kernel<0, false>(&st, segs.data(), pt.data(), pool, &res, &done, parts.data(), pmax, nullptr); });
+    if (pmax >= 2) {
+        emu::launch(pmax - 1, RT2, [&] { pinf2_resolve_kernel<0, true>(&st, segs.data(), pt.data(), pool, &res, &done, parts.data(), pmax, sym.data()); });
+        emu::launch(1, 512, [&] { pinf2_window_kernel(&st, parts.data(), pmax, sym.data(), win.data()); });
+        emu::launch(FIX_WG, 256, [&] { pinf2_fixup_kernel(&st, parts.data(), pmax, sym.data(), win.data()); }, pmax - 1);
+        emu::launch(1, 64, [&] { pinf2_verdict_kernel(&st, parts.data(), pmax, &res, &done, 1); });
+        printf("parts: %u\n", st.parts);
+    }
 
     if (resumed) {
         // report what the pipeline did

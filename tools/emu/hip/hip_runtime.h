@@ -115,15 +115,15 @@ inline void resolve_wave(std::vector<Fiber> &fb, size_t base, size_t n)
 }
 
 // Runs `body` for every thread of every block, blocks one after another.
-inline void launch(unsigned grid, unsigned block, const std::function<void()> &body)
+inline void launch(unsigned grid, unsigned block, const std::function<void()> &body, unsigned gridy = 1)
 {
     static std::vector<Fiber> fb;
-    for (unsigned b = 0; b < grid; ++b) {
+    for (unsigned b = 0; b < grid * gridy; ++b) {
         fb.clear(); fb.resize(block);
         for (unsigned t = 0; t < block; ++t) {
             Fiber &f = fb[t];
             f.stack.resize(256 << 10);
-            f.tid = {t, 0, 0}; f.bid = {b, 0, 0}; f.bdim = {block, 1, 1}; f.gdim = {grid, 1, 1};
+            f.tid = {t, 0, 0}; f.bid = {b % grid, b / grid, 0}; f.bdim = {block, 1, 1}; f.gdim = {grid, gridy, 1};
             f.body = &body; f.state = RUN;
             getcontext(&f.ctx);
             f.ctx.uc_stack.ss_sp = f.stack.data(); f.ctx.uc_stack.ss_size = f.stack.size(); f.ctx.uc_link = nullptr;
@@ -258,6 +258,7 @@ template <class T> inline T __hip_atomic_fetch_or(T *p, T v, int, int) { T o = *
 template <class T> inline T __hip_atomic_load(const T *p, int, int) { return *p; }
 template <class T> inline void __hip_atomic_store(T *p, T v, int, int) { *p = v; }
 inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+inline void __threadfence() {}
 inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
