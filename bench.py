@@ -345,6 +345,32 @@ def parallel_zlib(rows: bytes, level: int, threads: int) -> bytes:
     return b"\x78\x9c" + b"".join(parts) + zlib.adler32(rows).to_bytes(4, "big")
 
 
+def run_single_image(torch, spng, s, stream, image, steps=5):
+    """What the reference does per call: ONE 4096 x 4096 RGBA8 image decoded alone (spng_decode_batch of one), stream resident
+    in HBM.  The pipeline cuts the one stream into segments (decode) and parts (resolve): latency, not throughput."""
+    d_z = s.to_device(stream)
+    U = spng.inflated_size(W, H, DEPTH, CHANNELS, False)
+    S = spng.storage_size(W, H, DEPTH, CHANNELS)
+    d_rows, d_out = s.empty(U + 4096), s.empty(S)
+    desc = s.image_desc(d_z, d_rows, d_out, W, H, DEPTH, CHANNELS, False, 0, rows_cap=U + 4096)
+    for _ in range(2):
+        s.decode_batch([desc])
+    torch.cuda.synchronize()
+    names = ("pinf_find", "pinf_decode", "pinf_resolve", "inflate", "unfilter")
+    s.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = s.decode_batch([desc])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    prof = {k: round(s.profile_get(getattr(spng, "K_" + k.upper()))[0] / steps, 3) for k in names}
+    s.profile(False)
+    assert res[0].status == 0 and res[0].reserved == 1
+    assert torch.equal(d_out, s.to_device(image.reshape(-1))), "single image: raster differs"
+    return {"workload": "1 x 4096x4096 RGBA8 PNG decode (level 6, zlib encoder), one call per image",
+            "ms": round(dt * 1e3, 3), "mpixels_per_s": round(MPIX / dt, 1), "kernels_ms": prof, "bit_exact": True}
+
+
 def run_config5(torch, spng, s, steps):
     """BASELINE configs[4]: one 8192 x 8192 RGBA16 Adam7 image (536,886,272 inflated bytes, seven sub-images, one
     stream), level 6, decoded on one GPU: inflate pipeline + per-pass unfilter + scatter."""
@@ -571,6 +597,7 @@ def main():
             leg("copy_ceiling", lambda: copy_ceiling(torch, s))
             if isinstance(out["copy_ceiling"].get("gbps"), float) and "unfilter" in kernels:
                 kernels["unfilter"]["frac_of_copy_ceiling"] = round(kernels["unfilter"]["gbps"] / out["copy_ceiling"]["gbps"], 4)
+            leg("single_image", lambda: run_single_image(torch, spng, s, m["streams"][0], m["images"][0]))
             leg("config5", lambda: run_config5(torch, spng, s, 3))
             leg("file_to_pixels", lambda: run_file_to_pixels(torch, spng, s, m["streams"][:8], m["images"][:8], min(256, args.images), 2))
 

@@ -752,9 +752,25 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
             HIP_TRY(launch_pinf2_scan(ds + g.s0, g.s1 - g.s0, dg, dparts, retry, q));
             {
                 Timed t(c, SPNG_K_PINF_RESOLVE, q);
-                HIP_TRY(launch_pinf2_resolve(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, pool, g.pages, dr, dd + g.s0, dparts, pm, retry, q));
+                // (the parts behind the first on the second stream, beside the first parts: 93 KB + 61 KB of LDS share a CU)
+                hipStream_t q2 = q;
+                if (pm && !p.overlap) {
+                    if (!c->stream2) {
+                        HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                        for (hipEvent_t *e : {&c->ev_fork, &c->ev_mid, &c->ev_join}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+                    }
+                    q2 = c->stream2;
+                    HIP_TRY(hipEventRecord(c->ev_fork, q));
+                    HIP_TRY(hipStreamWaitEvent(q2, c->ev_fork, 0));
+                }
                 if (pm) HIP_TRY(launch_pinf2_parts(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, pool, g.pages, dr, dd + g.s0, dparts, pm,
-                                                   (uint16_t *)c->d_sym, (uint8_t *)c->d_win + (size_t)g.s0 * pm * 32768, q));
+                                                   (uint16_t *)c->d_sym, q2));
+                HIP_TRY(launch_pinf2_resolve(ds + g.s0, g.s1 - g.s0, dg, (uint32_t *)c->d_log, pool, g.pages, dr, dd + g.s0, dparts, pm, retry, q));
+                if (pm) {
+                    if (q2 != q) { HIP_TRY(hipEventRecord(c->ev_join, q2)); HIP_TRY(hipStreamWaitEvent(q, c->ev_join, 0)); }
+                    HIP_TRY(launch_pinf2_join(ds + g.s0, g.s1 - g.s0, dr, dd + g.s0, dparts, pm, (uint16_t *)c->d_sym,
+                                              (uint8_t *)c->d_win + (size_t)g.s0 * pm * 32768, q));
+                }
             }
             HIP_TRY(launch_pinf2_account(ctr, dnext + 8, g.pages, q));
         }

@@ -1640,13 +1640,18 @@ hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_s
     else pinf2_resolve_kernel<0, false><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, nullptr);
     return hipGetLastError();
 }
-// the parts behind the first of every stream, the windows, symbols -> bytes, the verdicts (pmax >= 2)
+// the parts behind the first of every stream (pmax >= 2) ...
 hipError_t launch_pinf2_parts(PStream *d_streams, uint32_t nstreams, PSeg *d_segs, uint32_t *d_pt, uint8_t *d_pool, uint32_t pages,
-                              spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax, uint16_t *d_sym, uint8_t *d_win,
-                              hipStream_t stream)
+                              spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax, uint16_t *d_sym, hipStream_t stream)
 {
     DPool pool{d_pool, nullptr, pages, 0};
     pinf2_resolve_kernel<0, true><<<nstreams * (pmax - 1), RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, d_sym);
+    return hipGetLastError();
+}
+// ... and, when they and the first parts are done: the windows, symbols -> bytes, the verdicts
+hipError_t launch_pinf2_join(PStream *d_streams, uint32_t nstreams, spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax,
+                             uint16_t *d_sym, uint8_t *d_win, hipStream_t stream)
+{
     pinf2_window_kernel<<<nstreams, 512, 0, stream>>>(d_streams, d_parts, pmax, d_sym, d_win);
     pinf2_fixup_kernel<<<dim3(FIX_WG, nstreams * (pmax - 1)), 256, 0, stream>>>(d_streams, d_parts, pmax, d_sym, d_win);
     pinf2_verdict_kernel<<<(nstreams + 63) / 64, 64, 0, stream>>>(d_streams, d_parts, pmax, d_results, d_done, nstreams);
