@@ -75,7 +75,8 @@ def _kernels(name):
 
 
 def _one(table, fragment):
-    hits = [v for k, v in table.items() if fragment in k and "ILj1E" not in k]      # (not the <RETRY = 1> instantiation)
+    # (not the <RETRY = 1> instantiations, nor resolve's <_, MARK = true> unless asked for by its mangled arguments)
+    hits = [v for k, v in table.items() if fragment in k and "ILj1E" not in k and ("Lb1E" not in k or "Lb1E" in fragment)]
     assert len(hits) == 1, (fragment, list(table))
     return hits[0]
 
@@ -89,6 +90,8 @@ def test_pipeline_kernel_resources():
     res = _one(table, "pinf2_resolve_kernel")
     assert res["group_segment_fixed_size"] <= 65536          # (static LDS) and two 512-thread workgroups per CU
     assert res["vgpr_count"] <= 128 and res["private_segment_fixed_size"] == 0 and res["max_flat_workgroup_size"] == 512
+    mark = [v for k, v in table.items() if "pinf2_resolve_kernel" in k and "ILj0ELb1E" in k]
+    assert len(mark) == 1 and mark[0]["group_segment_fixed_size"] <= 98304 and mark[0]["private_segment_fixed_size"] == 0   # (symbols: a 64 KiB ring)
     find = _one(table, "pinf2_find_kernel")
     assert find["private_segment_fixed_size"] == 0 and find["group_segment_fixed_size"] <= 16384
     # LDS and global memory are reached with their own instructions
