@@ -19,11 +19,12 @@
 //            marked (round 1: a link), the true chain is the set of lanes reachable from lane 0 (pointer
 //            doubling), and -- tables and compressed bytes still in LDS -- every lane on it decodes
 //            exactly the tokens that start in its subsequence once more, now into a compact token
-//            stream: 16-bit halfwords (a literal is one, a back-reference two), staged in LDS and written
-//            to HBM in whole aligned 16-byte units.  Round 2's count + emit (two kernels, a log slab, the
-//            tables of every block built twice, 4-byte tokens written in pieces) are this one kernel.
-//            Token space comes from a page pool (64 KiB pages, one atomic per page), so nothing has to
-//            be counted before it is written.
+//            stream: 16-bit halfwords (a literal is one, a back-reference two), every lane storing its
+//            own run of them straight into HBM at the place a prefix sum gives it (the lines fill up in
+//            L2).  Where the root table holds two literals' codes in one index a step decodes both.
+//            Round 2's count + emit (two kernels, a log slab, the tables of every block built twice,
+//            4-byte tokens written in pieces) are this one kernel.  Token space comes from a page pool
+//            (64 KiB pages, one atomic per page), so nothing has to be counted before it is written.
 //   resolve  one 512-thread workgroup per stream turns tokens into bytes, a tile (<= 8 KiB) at a time.
 //            Thread t owns bytes t, t + 512, ...: consecutive lanes, consecutive bytes, so every LDS
 //            access of a wave is a contiguous row or a gather with few distinct addresses.  Literals go
@@ -32,11 +33,15 @@
 //            row's bitmap word.  Sources before the tile come from the 32 KiB LDS ring; pointers inside
 //            the tile are halved by pointer jumping, rows that are complete cost nothing.  The tile
 //            leaves for HBM in whole 16-byte units of the output position, Adler-32 folded in.
+//            In batches of few streams a stream's chain is cut into parts that several workgroups
+//            resolve side by side ("Several workgroups per stream" at the scan kernel).
 //
-// Exactness.  The pipeline only ever reports SPNG_DONE, and only when every check of the reference
-// passed on the way (header rules, complete trees, references inside the output, capacity, Adler-32,
-// segment chain).  Anything else is left to inflate.hip, which decodes with the reference's exact
-// accept/reject behaviour and error payloads.  spng_result.reserved tells which path produced a result.
+// Exactness.  The pipeline reports SPNG_DONE -- or, when every block was taken and only the Adler-32
+// differs, the reference's checksum error -- and only when every check of the reference passed on the
+// way (header rules, complete trees, references inside the output, capacity, segment chain).  Anything
+// else is left to inflate.hip, started at the first block the pipeline did not take (every call carries
+// resume state), which decodes with the reference's exact accept/reject behaviour and error payloads.
+// spng_result.reserved tells which path produced a result.
 //
 // Streams that arrive in pieces (spng_inflate_resume_batch): the resume point is the first segment start; a
 // segment that meets a block it cannot take as it stands ends PARTIAL in front of it; resolve begins with

@@ -6,7 +6,7 @@ import swift_png_amd as spng
 from swift_png_amd import synth
 
 s = spng.load(0)
-N, W, H = 256, 4096, 4096
+N, W, H = int(os.environ.get("PROBE_N", "256")), 4096, 4096
 U = spng.inflated_size(W, H, 8, 4, False); S = W * H * 4
 src = torch.empty(N * U, dtype=torch.uint8, device=s.tdev)
 out = torch.empty(N * S, dtype=torch.uint8, device=s.tdev)
