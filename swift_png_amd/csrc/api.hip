@@ -669,6 +669,11 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
             }
         }
     }
+    if (!p.pmax && c->d_sym) {
+        // (a large batch after small ones: the symbol scratch -- two bytes per output byte -- goes back to the device)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->d_sym)); c->d_sym = nullptr; c->sym_cap = 0;
+    }
     c->pool_pages_planned = p.pool_pages;
     c->pool_src_bytes = total;
     if (!c->h_pool_used) {
