@@ -669,7 +669,7 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
             }
         }
     }
-    if (!p.pmax && c->d_sym) {
+    if (!p.pmax && c->d_sym && p.jobs.size() > 384) {
         // (a large batch after small ones: the symbol scratch -- two bytes per output byte -- goes back to the device)
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipFree(c->d_sym)); c->d_sym = nullptr; c->sym_cap = 0;
