@@ -6,6 +6,7 @@ checked before a GPU minute is spent, and kept checked.  Timing, bank conflicts 
 import os
 import shutil
 import subprocess
+from pathlib import Path
 import zlib
 
 import numpy as np
@@ -192,3 +193,15 @@ def test_emulated_pipeline_resolves_a_stream_in_parts(emu, tmp_path, name, parts
     r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", str(segment)], capture_output=True, text=True,
                        timeout=900, env=dict(os.environ, EMU_PARTS=str(parts)))
     assert r.returncode == 5 and "error" in r.stdout, (r.returncode, r.stdout[-300:])
+
+
+@pytest.mark.parametrize("seed", [3, 17, 29, 41, 58, 77])
+def test_emulated_pipeline_random_streams(emu, tmp_path, seed):
+    """tools/emu/fuzz_pinflate.py: random data x zlib parameters x flush pattern x segment length x resolve parts (hundreds of
+    seeds were run when the pipeline changed; a few stay in the suite)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_pinflate", str(Path(__file__).resolve().parent.parent / "tools" / "emu" / "fuzz_pinflate.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rc, what = fz.run(str(emu), seed, str(tmp_path))
+    assert rc in (0, 3, 4), what
