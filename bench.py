@@ -604,7 +604,7 @@ def main():
             def enc():
                 from bench_encode import run_encode
                 ea = argparse.Namespace(**vars(args))
-                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), 1, 0, args.no_cpu_baseline
+                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), 1, 1, args.no_cpu_baseline   # (the first call of a context allocates the match-graph slab: ~2 s)
                 return run_encode(ea, torch, dist, spng, s, rank, world)
             leg("encode", enc)
 
