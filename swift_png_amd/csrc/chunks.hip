@@ -246,14 +246,17 @@ hipError_t launch_lex(const spng_file_desc *d_files, uint32_t count, spng_lexed 
     // (enough waves to fill the chip; a wave strides over its file's chunks)
     const uint32_t want = (8192 + count - 1) / count;
     if (bx > want) bx = want < 1 ? 1 : want;
-    lex_chunk_kernel<<<dim3(bx, count), 64, 0, stream>>>(d_files, (LexChunk *)d_table, d_table_at, (LexWalk *)d_walks);
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u)             // (grid y stops at 65535)
+        lex_chunk_kernel<<<dim3(bx, count - y0 < 65535u ? count - y0 : 65535u), 64, 0, stream>>>(d_files + y0, (LexChunk *)d_table, d_table_at + y0,
+                                                                                                 (LexWalk *)d_walks + y0);
     lex_finish_kernel<<<(count + 63) / 64, 64, 0, stream>>>(d_out, (const LexChunk *)d_table, d_table_at, (const LexWalk *)d_walks, d_files, count);
     return hipGetLastError();
 }
 hipError_t launch_write_idat(const spng_chunking_desc *d_descs, uint32_t count, uint32_t blocks_x, spng_result *d_results, hipStream_t stream)
 {
     if (!count) return hipSuccess;
-    write_idat_kernel<<<dim3(blocks_x ? blocks_x : 1, count), 64, 0, stream>>>(d_descs, d_results);
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u)
+        write_idat_kernel<<<dim3(blocks_x ? blocks_x : 1, count - y0 < 65535u ? count - y0 : 65535u), 64, 0, stream>>>(d_descs + y0, d_results + y0);
     return hipGetLastError();
 }
 hipError_t launch_crc_partial(const uint8_t *d, uint64_t n, uint64_t piece, uint32_t *d_partial, uint32_t pieces, hipStream_t stream)

@@ -241,7 +241,8 @@ hipError_t launch_filter(const FilterJob *d_jobs, uint32_t count, uint32_t max_r
     uint32_t bx = (max_rows + 3) / 4;
     if (bx > 4096) bx = 4096;
     if (!bx) bx = 1;
-    filter_kernel<<<dim3(bx, count), 256, 0, stream>>>(d_jobs);
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u)             // (grid y stops at 65535)
+        filter_kernel<<<dim3(bx, count - y0 < 65535u ? count - y0 : 65535u), 256, 0, stream>>>(d_jobs + y0);
     return hipGetLastError();
 }
 

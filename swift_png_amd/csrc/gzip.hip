@@ -171,19 +171,28 @@ __global__ void gzip_deflate_post_kernel(const DeflateJob *__restrict__ jobs, sp
 // inflated bytes (MRC32.swift:26-50; .checksum, InflatorBuffers.swift:112-130) -- is checked here, once, when a
 // call reports SPNG_DONE: S = sum b_i and I = sum i * b_i (mod 65521) over 256 pieces, one wave each (the same
 // closed form as the inflate kernels: s1 = 1 + S, s2 = N + N S - I).
+// Who compared the Adler-32 of a finished stream?  The pipeline's verdict (reserved == 1) over a stream it held from its
+// first bit is final.  The serial kernel compares only when it is not `resumed` (inflate.hip: an internal job from {0, 0});
+// every other stream -- all of spng_inflate_resume_batch's, whatever their state -- is compared here.
+__device__ __forceinline__ bool checked_by_pipeline(const InflateJob &j, const spng_result &r)
+{
+    const bool from_start = j.state[0] == 0 && j.state[1] == 0;
+    return from_start && (r.reserved == 1 || j.internal != 0);
+}
 __global__ __launch_bounds__(64) void resume_adler_kernel(const InflateJob *__restrict__ jobs, const spng_result *__restrict__ results,
                                                           uint64_t *__restrict__ parts)
 {
     const int lane = threadIdx.x;
-    const uint32_t i = blockIdx.y;
+    const uint32_t i = blockIdx.x / GZ_PIECES, piece = blockIdx.x % GZ_PIECES;      // (streams on x: grid y stops at 65535)
     const InflateJob &j = jobs[i];
     if (!uni64((uint64_t)j.state) || (int32_t)UNI(j.format) != SPNG_FORMAT_ZLIB) return;
-    // (a state that still reads {0, 0}: whoever finished the stream saw all of it and compared the checksum itself)
-    if (uni64(j.state[0]) == 0 && uni64(j.state[1]) == 0) return;
     const spng_result &r = results[UNI(j.image)];
     if ((int32_t)UNI(r.status) != SPNG_DONE) return;
+    // (the pipeline finished a stream it saw from its first bit: it compared the checksum itself; the serial kernel leaves
+    // the comparison of every caller-resumable stream to this pass, also when it happened to see all of it in one call)
+    if (checked_by_pipeline(j, r)) return;
     const gbyte *p = (const gbyte *)uni64((uint64_t)j.dst);
-    const uint64_t n = uni64(r.written), len = piece_len(n), from = (uint64_t)blockIdx.x * len;
+    const uint64_t n = uni64(r.written), len = piece_len(n), from = (uint64_t)piece * len;
     const uint64_t m = from >= n ? 0 : (n - from < len ? n - from : len);
     uint32_t S = 0, I = 0, g = (uint32_t)((from + (uint64_t)lane) % 65521);      // position mod 65521, kept incrementally
     for (uint64_t k = lane; k < m; k += 64) {
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(64) void resume_adler_kernel(const InflateJob *__re
         g += 64; g = g >= 65521 ? g - 65521 : g;
     }
     S = wave_sum32(S % 65521) % 65521; I = wave_sum32(I) % 65521;
-    if (lane == 0) parts[(uint64_t)i * GZ_PIECES + blockIdx.x] = (uint64_t)S << 32 | I;
+    if (lane == 0) parts[(uint64_t)i * GZ_PIECES + piece] = (uint64_t)S << 32 | I;
 }
 __global__ void resume_post_kernel(const InflateJob *__restrict__ jobs, spng_result *__restrict__ results,
                                    const uint64_t *__restrict__ parts, uint32_t count)
@@ -202,9 +211,9 @@ __global__ void resume_post_kernel(const InflateJob *__restrict__ jobs, spng_res
     if (i >= count) return;
     const InflateJob &j = jobs[i];
     if (!j.state || j.format != SPNG_FORMAT_ZLIB) return;
-    if (j.state[0] == 0 && j.state[1] == 0) return;
     spng_result &r = results[j.image];
     if (r.status != SPNG_DONE) return;
+    if (checked_by_pipeline(j, r)) return;
     uint64_t S = 0, I = 0;
     for (uint32_t k = 0; k < GZ_PIECES; ++k) { const uint64_t v = parts[(uint64_t)i * GZ_PIECES + k]; S += v >> 32; I += (uint32_t)v; }
     S %= 65521; I %= 65521;
@@ -216,7 +225,7 @@ __global__ void resume_post_kernel(const InflateJob *__restrict__ jobs, spng_res
 }
 hipError_t launch_resume_post(const InflateJob *d_jobs, spng_result *d_results, uint64_t *d_parts, uint32_t count, hipStream_t stream)
 {
-    resume_adler_kernel<<<dim3(GZ_PIECES, count), 64, 0, stream>>>(d_jobs, d_results, d_parts);
+    resume_adler_kernel<<<count * GZ_PIECES, 64, 0, stream>>>(d_jobs, d_results, d_parts);
     resume_post_kernel<<<(count + 63) / 64, 64, 0, stream>>>(d_jobs, d_results, d_parts, count);
     return hipGetLastError();
 }
@@ -230,14 +239,17 @@ hipError_t launch_gzip_pre(InflateJob *d_jobs, PStream *d_streams, spng_result *
 hipError_t launch_gzip_inflate_post(const InflateJob *d_jobs, spng_result *d_results, const uint64_t *d_gz, uint32_t *d_parts,
                                     uint32_t count, hipStream_t stream)
 {
-    gzip_inflate_crc_kernel<<<dim3(GZ_PIECES, count), 64, 0, stream>>>(d_jobs, d_results, d_gz, d_parts);
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u)             // (grid y stops at 65535)
+        gzip_inflate_crc_kernel<<<dim3(GZ_PIECES, count - y0 < 65535u ? count - y0 : 65535u), 64, 0, stream>>>(d_jobs + y0, d_results, d_gz + y0,
+                                                                                                            d_parts + (uint64_t)y0 * GZ_PIECES);
     gzip_inflate_post_kernel<<<(count + 63) / 64, 64, 0, stream>>>(d_jobs, d_results, d_gz, d_parts, count);
     return hipGetLastError();
 }
 hipError_t launch_gzip_deflate_post(const DeflateJob *d_jobs, spng_result *d_results, uint32_t *d_parts, uint32_t count,
                                     hipStream_t stream)
 {
-    gzip_deflate_crc_kernel<<<dim3(GZ_PIECES, count), 64, 0, stream>>>(d_jobs, d_parts);
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u)
+        gzip_deflate_crc_kernel<<<dim3(GZ_PIECES, count - y0 < 65535u ? count - y0 : 65535u), 64, 0, stream>>>(d_jobs + y0, d_parts + (uint64_t)y0 * GZ_PIECES);
     gzip_deflate_post_kernel<<<(count + 63) / 64, 64, 0, stream>>>(d_jobs, d_results, d_parts, count);
     return hipGetLastError();
 }

@@ -993,9 +993,11 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
         if (h.bfinal) { status = PSEG_FINAL; break; }
     }
     uint64_t nhw = cur.nhw;
-    if (status == PSEG_FAIL && resumable) { status = PSEG_PARTIAL; nhw = hw_block; nbytes = bytes_block; }   // (pos is still the block's first bit)
+    // The pool ran dry (a batch unlike the one it was sized by): the stream takes the retry pass, with the pool to itself and
+    // its like; dry again there, it stops in front of this block like any other block that cannot be taken.
+    if (status == PSEG_FAIL && cur.dry && !retry) status = PSEG_NOPAGE;
+    else if (status == PSEG_FAIL && resumable) { status = PSEG_PARTIAL; nhw = hw_block; nbytes = bytes_block; }   // (pos is still the block's first bit)
     // (no padding: resolve reads whole 16-byte units, inside the last page, and masks what lies behind nhw)
-    if (status == PSEG_FAIL && cur.dry) status = PSEG_NOPAGE;
     if (lane == 0) { sg.end_bit = pos; sg.ntok = nhw; sg.nbytes = nbytes; sg.status = status; sg.next = nk; }
 #ifdef SPNG_D_PROF
     if (blockIdx.x == 1 && lane == 0)

@@ -42,10 +42,21 @@ struct __attribute__((packed)) U128u { u32x4 v; };       // 16 bytes, alignment 
 #define SPNG_UNF_P8 32                                   // tile width in units for bpp > 4
 #endif
 
+// Skew between consecutive rows of a band.  The arithmetic only needs lane r to be *behind* lane r-1; by how much is a
+// choice.  One unit (bpp bytes) is the least and is what the byte-wise form uses.  The packed forms (bpp 4 and 8) trail by
+// one 16-byte chunk instead: then every row window starts on a multiple of 16 bytes of its row, so the 16-byte loads and
+// stores of rows that are themselves aligned (PNG.Image.storage always is) never straddle, and the value from the row above
+// is the previous iteration's output register moved one lane down.  Price: 63 chunks of ramp per band instead of 63 units.
+#ifndef SPNG_UNF_CHUNK_SKEW
+#define SPNG_UNF_CHUNK_SKEW 1
+#endif
+
 template <int BPP> struct Cfg {
     static constexpr int P    = (BPP <= 4) ? SPNG_UNF_P4 : SPNG_UNF_P8;   // units per tile window
-    static constexpr int K    = (63 + P - 1) / P;        // producer tiles a consumer tile reaches into
+    static constexpr bool CS  = SPNG_UNF_CHUNK_SKEW && (BPP == 4 || BPP == 8);
+    static constexpr int SKB  = CS ? 16 : BPP;           // bytes a row trails the row above by
     static constexpr int TB   = P * BPP;                 // bytes per row per tile (multiple of 16)
+    static constexpr int K    = (63 * SKB + TB - 1) / TB; // producer tiles a consumer tile reaches into
     static constexpr int ROWB = TB + 16;                 // LDS row stride: conflict-free b128 columns
     static constexpr int CPR  = TB / 16;                 // 16-byte chunks per row
     static_assert(TB % 16 == 0, "tile row must be a whole number of 16-byte chunks");
@@ -174,9 +185,11 @@ __device__ __forceinline__ uint32_t paeth_pk(uint32_t a, uint32_t b, uint32_t c)
 
 // DW dwords per unit: 1 (RGBA8, VA16, ...: bpp 4) or 2 (RGBA16: bpp 8).  The row above is one unit ahead, so what
 // this lane needs from it -- the unit it finished in the previous step -- still sits in its registers, dword by dword.
-template <int P, int DW, bool FIRST, bool PAETH>
+// CS (chunk skew): the row above is one 16-byte chunk ahead, so its unit above mine is dword k of what it wrote in the
+// previous iteration (`pw`, carried from tile to tile); ux0 then counts chunks, not units.
+template <int P, int DW, bool FIRST, bool PAETH, bool CS>
 __device__ __forceinline__ void reconstruct_pk(uint8_t *tile, int rowb, int lane, uint32_t ft, int64_t ux0,
-                                               uint32_t *o, uint32_t *bprev)
+                                               uint32_t *o, uint32_t *bprev, uint32_t *pw)
 {
     constexpr uint32_t M = 0x00ff00ffu;
     const uint32_t m_sub = ft == 1 ? M : 0u, m_up = ft == 2 ? M : 0u, m_avg = ft == 3 ? M : 0u,
@@ -195,7 +208,7 @@ __device__ __forceinline__ void reconstruct_pk(uint8_t *tile, int rowb, int lane
         for (int k = 0; k < 4; ++k) {
             constexpr int dmask = DW - 1;
             const int d = k & dmask;                           // which dword of its unit (DW divides 4)
-            const uint32_t b = from_lane_above(o[d], tq[k]);
+            const uint32_t b = from_lane_above(CS ? pw[k] : o[d], tq[k]);
             const uint32_t b_lo = b & M, b_hi = (b >> 8) & M;
             uint32_t p_lo = (a_lo[d] & m_sub) | (b_lo & m_up) | (((a_lo[d] + b_lo) >> 1) & m_avg);
             uint32_t p_hi = (a_hi[d] & m_sub) | (b_hi & m_up) | (((a_hi[d] + b_hi) >> 1) & m_avg);
@@ -206,11 +219,12 @@ __device__ __forceinline__ void reconstruct_pk(uint8_t *tile, int rowb, int lane
             uint32_t x_lo = ((r[k] & M) + p_lo) & M, x_hi = (((r[k] >> 8) & M) + p_hi) & M;
             if (FIRST) {
                 // units left of the row start produce zeros, so that unit 0 sees a = c = 0
-                const uint32_t live = (ux0 + (t4 * 4 + k) / DW >= 0) ? M : 0u;
+                const uint32_t live = (CS ? ux0 + t4 >= 0 : ux0 + (t4 * 4 + k) / DW >= 0) ? M : 0u;
                 x_lo &= live; x_hi &= live;
             }
             o[d] = x_lo | x_hi << 8;
             r[k] = o[d];
+            if (CS) pw[k] = o[d];
             c_lo[d] = b_lo; c_hi[d] = b_hi; a_lo[d] = x_lo; a_hi[d] = x_hi;
             bprev[d] = b;
         }
@@ -219,8 +233,13 @@ __device__ __forceinline__ void reconstruct_pk(uint8_t *tile, int rowb, int lane
     }
 }
 
+#ifdef SPNG_UNF_WPE                // tuning builds: cap the registers so that this many waves fit a SIMD
+#define SPNG_UNF_ATTR __attribute__((amdgpu_waves_per_eu(SPNG_UNF_WPE, SPNG_UNF_WPE)))
+#else
+#define SPNG_UNF_ATTR
+#endif
 template <int BPP>
-__global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob *__restrict__ jobs,
+__global__ __launch_bounds__(SPNG_UNF_NW * 64) SPNG_UNF_ATTR void unfilter_kernel(const UnfJob *__restrict__ jobs,
                                                                      const spng_result *__restrict__ results,
                                                                      uint32_t sb_rows)
 {
@@ -269,8 +288,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         rows = last - first;
     }
     const int64_t pitch = job.pitch;
-    const uint32_t W = job.pitch / BPP;
-    const uint32_t ntiles = (W + 63 + C::P - 1) / C::P;
+    const uint32_t ntiles = (uint32_t)((pitch + 63 * C::SKB + C::TB - 1) / C::TB);
     const uint32_t nbands = (rows + 63) / 64;
     uint8_t *tile = tiles[wave];
 
@@ -284,7 +302,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
             u32x4 v = {0, 0, 0, 0};
             if (rw < rows)
                 v = load_window(job.in + (uint64_t)rw * job.in_stride + 1,
-                                ((int64_t)T * C::P - r) * BPP + 16 * cj, pitch);
+                                (int64_t)T * C::TB - (int64_t)r * C::SKB + 16 * cj, pitch);
             R[m] = v;
         }
         Rtop = u32x4{0, 0, 0, 0};
@@ -300,8 +318,8 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         }
         if (lane < C::CPR) *(u32x4 *)(tile + 16 * lane) = Rtop;
     };
-    // band j tile T needs the last row of band j-1 on units [T*P, T*P+P): lane 63 of band j-1 is 63
-    // units behind, so they come from its tiles T .. T+K.  `done` of the producing wave counts the
+    // band j tile T needs the last row of band j-1 on bytes [T*TB, T*TB+TB): lane 63 of band j-1 is 63 * SKB
+    // bytes behind, so they come from its tiles T .. T+K.  `done` of the producing wave counts the
     // tiles (over all of its bands) whose stores have been drained.
     auto ready = [&](uint32_t band, uint32_t T) -> bool {
         if (!band) return true;
@@ -324,7 +342,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         const uint32_t row = band * 64 + lane;
         const uint32_t ft = row < rows ? job.in[(uint64_t)row * job.in_stride] : 0u;
         const bool any_pae = __any(ft == 4);            // no Paeth row in this band: skip its arithmetic
-        uint32_t o[BPP], bprev[BPP];
+        uint32_t o[BPP], bprev[BPP], pw[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < BPP; ++k) { o[k] = 0; bprev[k] = 0; }
 
@@ -359,13 +377,15 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS tile written before it is read
 
-            const int64_t ux0 = (int64_t)T * C::P - lane;
+            // first unit (chunk skew: first chunk) of this lane's window, counted from the row start
+            const int64_t ux0 = C::CS ? (int64_t)T * C::CPR - lane : (int64_t)T * C::P - lane;
 #ifndef SPNG_UNF_NOCOMPUTE        // tuning builds only: measure the memory pipeline alone
             if constexpr (BPP == 4 || BPP == 8) {
                 // (o / bprev hold the unit as packed dwords here, byte-wise in the generic form)
-                if (T == 0)       reconstruct_pk<C::P, BPP / 4, true, true>(tile, C::ROWB, lane, ft, ux0, o, bprev);
-                else if (any_pae) reconstruct_pk<C::P, BPP / 4, false, true>(tile, C::ROWB, lane, ft, ux0, o, bprev);
-                else              reconstruct_pk<C::P, BPP / 4, false, false>(tile, C::ROWB, lane, ft, ux0, o, bprev);
+                // (tiles in which some lane is still left of its row start)
+                if (T * (C::CS ? C::CPR : C::P) < 63u) reconstruct_pk<C::P, BPP / 4, true, true, C::CS>(tile, C::ROWB, lane, ft, ux0, o, bprev, pw);
+                else if (any_pae) reconstruct_pk<C::P, BPP / 4, false, true, C::CS>(tile, C::ROWB, lane, ft, ux0, o, bprev, pw);
+                else              reconstruct_pk<C::P, BPP / 4, false, false, C::CS>(tile, C::ROWB, lane, ft, ux0, o, bprev, pw);
             } else {
                 reconstruct_generic<BPP, C::P>(tile, C::ROWB, lane, ft, ux0, o, bprev);
             }
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
                 const uint32_t rw = band * 64 + r;
                 if (rw < rows)
                     store_window(job.out + (uint64_t)rw * job.out_stride,
-                                 ((int64_t)T * C::P - r) * BPP + 16 * cj, pitch,
+                                 (int64_t)T * C::TB - (int64_t)r * C::SKB + 16 * cj, pitch,
                                  *(const u32x4 *)(tile + (1 + r) * C::ROWB + 16 * cj));
             }
             ++count;
@@ -468,7 +488,8 @@ hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32
                           const spng_result *d_results, uint32_t blocks_x, hipStream_t stream)
 {
     if (!count) return hipSuccess;
-    scatter_kernel<<<dim3(blocks_x, count), 256, 0, stream>>>(d_jobs, d_results, d_job_image);
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u)             // (grid y stops at 65535; a batch of interlaced images has 7 jobs each)
+        scatter_kernel<<<dim3(blocks_x, count - y0 < 65535u ? count - y0 : 65535u), 256, 0, stream>>>(d_jobs + y0, d_results, d_job_image + y0);
     return hipGetLastError();
 }
 

@@ -120,9 +120,11 @@ __global__ __launch_bounds__(256) void unpack_kernel(const UnpackJob *__restrict
 hipError_t launch_unpack(const UnpackJob *d_jobs, uint32_t count, uint32_t blocks_x, int target, hipStream_t stream)
 {
     if (!count) return hipSuccess;
-    const dim3 grid(blocks_x ? blocks_x : 1, count);
-    if (target == 8) unpack_kernel<uint8_t><<<grid, 256, 0, stream>>>(d_jobs);
-    else unpack_kernel<uint16_t><<<grid, 256, 0, stream>>>(d_jobs);
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u) {           // (grid y stops at 65535)
+        const dim3 grid(blocks_x ? blocks_x : 1, count - y0 < 65535u ? count - y0 : 65535u);
+        if (target == 8) unpack_kernel<uint8_t><<<grid, 256, 0, stream>>>(d_jobs + y0);
+        else unpack_kernel<uint16_t><<<grid, 256, 0, stream>>>(d_jobs + y0);
+    }
     return hipGetLastError();
 }
 

@@ -205,3 +205,18 @@ def test_emulated_pipeline_random_streams(emu, tmp_path, seed):
     spec.loader.exec_module(fz)
     rc, what = fz.run(str(emu), seed, str(tmp_path))
     assert rc in (0, 3, 4), what
+
+
+def test_emulated_pipeline_retry_pass_after_a_dry_pool(emu, tmp_path):
+    """the token pool runs dry under a segment: the stream is marked for the retry pass (PSEG_NOPAGE -> st.pass = 1), which --
+    given pages -- decodes and resolves it; the result is the pipeline's (NOPAGE had become unreachable and the
+    retry launches did nothing)"""
+    rows = scanlines(21, 600 * 512)
+    z = deflate(rows, 6)
+    (tmp_path / "z").write_bytes(z)
+    (tmp_path / "raw").write_bytes(rows)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", "8192", "2"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, EMU_RETRY_PAGES="64", EMU_PTCAP="64"))
+    assert "first pass: ok 0 pass 1" in r.stdout, (r.stdout[-400:], r.stderr[-300:])
+    assert "retry pass: ok 1 done 1" in r.stdout, (r.stdout[-400:], r.stderr[-300:])
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-300:])

@@ -591,6 +591,57 @@ def test_deflate_full_search_sparse_matches(gpu):
         assert zlib.decompress(got) == data
 
 
+def _mixed_content(n, seed, kinds=(0, 1, 2, 3)):
+    """noise, runs longer than 100 (the skip rule of DeflatorBuffers.Stream.swift:376-380), text, a 6-letter alphabet"""
+    rng = np.random.default_rng(seed)
+    parts, total = [], 0
+    text = b"lorem ipsum dolor sit amet, consectetur adipiscing elit, sed do eiusmod tempor " * 64
+    while total < n:
+        k = int(rng.choice(kinds))
+        if k == 0:
+            p = rng.integers(0, 256, int(rng.integers(20000, 200000)), dtype=np.uint8).tobytes()
+        elif k == 1:
+            p = b"".join(bytes([int(rng.integers(0, 8))]) * int(rng.integers(101, 900)) for _ in range(200))
+        elif k == 2:
+            o = int(rng.integers(0, 4000))
+            p = text[o:o + int(rng.integers(3000, 60000))]
+        else:
+            p = rng.integers(0, 6, int(rng.integers(10000, 80000)), dtype=np.uint8).tobytes()
+        parts.append(p)
+        total += len(p)
+    return b"".join(parts)[:n]
+
+
+def test_deflate_full_search_at_the_vertex_cap(gpu):
+    """BASELINE configs[3] at its real stream length.  The block limit of levels >= 8 doubles per block -- 2047, 4095, ...
+    vertices -- up to 2^21 - 1 (LZ77.DeflatorMatches.swift:229; capacity DeflatorBuffers.swift:33): the cap is reached 2.1 MB
+    into a stream and first APPLIES (a block that would have doubled again) past 4.2 MB.  Whole streams against the oracle:
+    9 MiB of mixed content at level 9 (three capped blocks), 6.5 MiB (two) at level 13, whose search never gives up."""
+    s = gpu.load()
+    nine = _mixed_content(9 << 20, 5)
+    got = s.deflate(nine, 9)
+    want = ph.orc_deflate(nine, 9)
+    assert len(got) == len(want) and got == want
+    assert zlib.decompress(got) == nine
+    thirteen = _mixed_content(13 << 19, 6, kinds=(0, 0, 0, 2, 3))
+    got = s.deflate(thirteen, 13)
+    assert got == ph.orc_deflate(thirteen, 13)
+    assert zlib.decompress(got) == thirteen
+
+
+def test_encode_random_4k_raster_whole_stream(gpu):
+    """One full-size unit of BASELINE configs[3]: a 4096 x 4096 RGBA8 raster of uniform random bytes, filter-select +
+    level 9, the WHOLE 64 MiB stream (32 blocks at the vertex cap) equal to the oracle's."""
+    s = gpu.load()
+    rng = np.random.default_rng(2024)
+    raster = rng.integers(0, 256, 4096 * 4096 * 4, dtype=np.uint8)
+    rows = s.filter(raster.tobytes(), 4096, 4096, 8, 4, False)
+    assert rows == ph.orc_filter(raster, 4096, 4096, 8, 4, False)
+    got = s.deflate(rows, 9)
+    want = ph.orc_deflate(rows, 9)
+    assert len(got) == len(want) and hashlib.sha256(got).digest() == hashlib.sha256(want).digest()
+
+
 @pytest.mark.parametrize("exponent", [8, 11, 15])
 def test_deflate_window_exponent(gpu, exponent):
     """LZ77.Deflator(format:level:exponent:hint:) with a small window (LZ77Tests/Compression.swift:12 uses 8):

@@ -148,6 +148,30 @@ def test_two_halves_on_two_streams(gpu, pool):
         s.configure(spng.CFG_TOKEN_BYTES, 0)
 
 
+def test_retry_pass_takes_the_streams_a_dry_pool_left(gpu):
+    """A token pool far too small for the batch (SPNG_CFG_TOKEN_BYTES): the streams whose segments found it empty take the
+    retry pass -- the pool to themselves -- and come out of the PIPELINE (reserved == 1), not of the serial kernel.
+    ADVICE r3: PSEG_NOPAGE had become unreachable, so the retry launches never did anything."""
+    s = gpu.load()
+    datas = [scanlines(70 + i, 4096 * 160) for i in range(12)]
+    zs = [zlib.compress(d, 6) for d in datas]
+    d_in = [s.to_device(z) for z in zs]
+    caps = [len(d) + 16 for d in datas]
+    # two groups' worth of estimate, but sized by the default 3.2 bytes per byte while these streams need less: force dryness
+    # with a pool that holds a few streams' tokens only
+    s.configure(spng.CFG_TOKEN_BYTES, 3 << 20)
+    s.configure(spng.CFG_SEGMENT_BYTES, 16384)
+    try:
+        outs, res = s.inflate_batch(d_in, caps)
+        for i, d in enumerate(datas):
+            assert res[i].status == 0 and res[i].written == len(d), (i, res[i].status)
+            assert bytes(outs[i][:len(d)].cpu().numpy()) == d, i
+        assert all(r.reserved == 1 for r in res), [r.reserved for r in res]
+    finally:
+        s.configure(spng.CFG_TOKEN_BYTES, 0)
+        s.configure(spng.CFG_SEGMENT_BYTES, 0)
+
+
 @pytest.mark.parametrize("parts", [0, 1, 7, 64])
 def test_streams_resolved_by_several_workgroups(gpu, parts):
     """SPNG_CFG_RESOLVE_PARTS (batches of <= 384 streams): a stream's chain cut into parts that resolve side by side -- symbols with

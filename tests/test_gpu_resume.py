@@ -204,3 +204,28 @@ def test_gzip_member_arrives_in_pieces(gpu):
         for i in range(0, len(bad), 50000):
             inf.push(bytes(bad[i:i + 50000]))
     assert e.value.status == 32
+
+
+@pytest.mark.parametrize("mode", [spng.INFLATE_AUTO, spng.INFLATE_SERIAL])
+def test_resume_single_push_checks_the_adler32(gpu, mode):
+    """A whole zlib stream handed to spng_inflate_resume_batch in ONE call with state {0, 0}: whoever finishes it -- the
+    pipeline, or the serial kernel alone (SPNG_INFLATE_SERIAL; the token pool could not be allocated) -- the trailer is
+    compared (invalidStreamChecksum(declared:computed:), LZ77.InflatorBuffers.swift:112-130).  ADVICE r3: the serial kernel
+    defers the comparison of every caller-resumable stream, and the deferred pass used to skip states that read {0, 0}."""
+    s = gpu.load()
+    data = scanlines(3, 4096 * 50)
+    good = zlib.compress(data, 6)
+    bad = bytearray(good); bad[-2] ^= 0x10; bad = bytes(bad)
+    s.configure(spng.CFG_INFLATE_MODE, mode)
+    try:
+        for z in (good, bad):
+            p = Pusher(s, cap=len(data) + 64)
+            res = p.push(z)
+            st, out, consumed, aux = ph.orc_inflate(z, 0, cap=len(data) + 64)
+            assert res.status == st, (mode, res.status, st)
+            assert res.written == len(out) and p.out(res.written) == out
+            if st == spng.E_STREAM_CHECKSUM:
+                assert (res.aux[0], res.aux[1]) == tuple(aux)
+            assert res.reserved == (0 if mode == spng.INFLATE_SERIAL else 1)
+    finally:
+        s.configure(spng.CFG_INFLATE_MODE, spng.INFLATE_AUTO)

@@ -109,6 +109,20 @@ int main(int argc, char **argv)
             fprintf(stderr, "token stream expands to %zu bytes, agrees with the expected bytes up to %zu of %zu\n", out.size(), i, want.size());
     }
     emu::launch(1, RT2, [&] { pinf2_resolve_kernel<0, false>(&st, segs.data(), pt.data(), pool, &res, &done, parts.data(), pmax, nullptr); });
+    // EMU_RETRY_PAGES=n: a stream whose segments found the pool empty takes the retry pass (api.hip: the pool to itself and
+    // its like -- here a second pool of n pages)
+    if (getenv("EMU_RETRY_PAGES")) {
+        printf("first pass: ok %d pass %u\n", st.ok, st.pass);
+        const uint32_t pages2 = (uint32_t)atoi(getenv("EMU_RETRY_PAGES"));
+        std::vector<uint8_t> poolmem2((size_t)pages2 << PAGE_SHIFT, 0xAB);
+        uint32_t next2 = 0;
+        DPool pool2{poolmem2.data(), &next2, pages2, 0};
+        emu::launch((unsigned)k, 64, [&] { pinf2_find_kernel<1>(&st, segs.data(), 0); });
+        emu::launch((unsigned)k, 64, [&] { pinf2_decode_kernel<1>(&st, segs.data(), pt.data(), pool2, 0); });
+        emu::launch(1, 64, [&] { pinf2_scan_kernel<1>(&st, segs.data(), parts.data()); });
+        emu::launch(1, RT2, [&] { pinf2_resolve_kernel<1, false>(&st, segs.data(), pt.data(), pool2, &res, &done, parts.data(), 0, nullptr); });
+        printf("retry pass: ok %d done %d pages %u\n", st.ok, done, next2);
+    }
     if (pmax >= 2) {
         emu::launch(pmax - 1, RT2, [&] { pinf2_resolve_kernel<0, true>(&st, segs.data(), pt.data(), pool, &res, &done, parts.data(), pmax, sym.data()); });
         emu::launch(1, 512, [&] { pinf2_window_kernel(&st, parts.data(), pmax, sym.data(), win.data()); });
