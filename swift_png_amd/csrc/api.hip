@@ -368,10 +368,6 @@ static int32_t plan_unfilter(const spng_image_desc *descs, uint32_t count, Unfil
             UnfJob j;
             j.in = (const uint8_t *)d.d_rows + off;
             j.in_stride = p[z].pitch + 1;
-#ifdef SPNG_PROBE_ALIGNED_ROWS     // tuning builds only: the probe lays rows out SPNG_PROBE_ALIGNED_ROWS bytes apart, filter byte at offset 15
-            j.in = (const uint8_t *)d.d_rows + 15;
-            j.in_stride = SPNG_PROBE_ALIGNED_ROWS;
-#endif
             if (direct) { j.out = (uint8_t *)d.d_storage; j.out_stride = p[z].pitch; }
             else        { j.out = (uint8_t *)d.d_rows + off + 1; j.out_stride = p[z].pitch + 1; }
             j.stream_off = off;

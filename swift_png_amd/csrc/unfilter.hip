@@ -4,6 +4,9 @@
 // (Sources/PNG/PNG.swift:124-147) and, through the job geometry, the row/pass walker of
 // PNG.Decoder.push (:59-140).  Byte arithmetic is u8 wrap-around exactly as in the reference.
 //
+// Two kernels: `unfilter_pk_kernel` (bpp 4 and 8: RGBA8, VA16, RGBA16 -- the formats of every BASELINE config; second half
+// of this file) and `unfilter_kernel`, the byte-wise form for bpp 1, 2, 3 and 6, described first:
+//
 // Parallelisation.  Pixel (x, y) of a sub-image depends on (x-1, y), (x, y-1) and (x-1, y-1), so
 // the dependency DAG is a 2-D wavefront.  One wave (64 lanes) owns a band of 64 consecutive rows:
 // lane r reconstructs row r and runs one pixel ("unit" = bpp bytes) behind lane r-1, so at step t
@@ -42,21 +45,10 @@ struct __attribute__((packed)) U128u { u32x4 v; };       // 16 bytes, alignment 
 #define SPNG_UNF_P8 32                                   // tile width in units for bpp > 4
 #endif
 
-// Skew between consecutive rows of a band.  The arithmetic only needs lane r to be *behind* lane r-1; by how much is a
-// choice.  One unit (bpp bytes) is the least and is what the byte-wise form uses.  The packed forms (bpp 4 and 8) trail by
-// one 16-byte chunk instead: then every row window starts on a multiple of 16 bytes of its row, so the 16-byte loads and
-// stores of rows that are themselves aligned (PNG.Image.storage always is) never straddle, and the value from the row above
-// is the previous iteration's output register moved one lane down.  Price: 63 chunks of ramp per band instead of 63 units.
-#ifndef SPNG_UNF_CHUNK_SKEW
-#define SPNG_UNF_CHUNK_SKEW 1
-#endif
-
 template <int BPP> struct Cfg {
     static constexpr int P    = (BPP <= 4) ? SPNG_UNF_P4 : SPNG_UNF_P8;   // units per tile window
-    static constexpr bool CS  = SPNG_UNF_CHUNK_SKEW && (BPP == 4 || BPP == 8);
-    static constexpr int SKB  = CS ? 16 : BPP;           // bytes a row trails the row above by
+    static constexpr int K    = (63 + P - 1) / P;        // producer tiles a consumer tile reaches into
     static constexpr int TB   = P * BPP;                 // bytes per row per tile (multiple of 16)
-    static constexpr int K    = (63 * SKB + TB - 1) / TB; // producer tiles a consumer tile reaches into
     static constexpr int ROWB = TB + 16;                 // LDS row stride: conflict-free b128 columns
     static constexpr int CPR  = TB / 16;                 // 16-byte chunks per row
     static_assert(TB % 16 == 0, "tile row must be a whole number of 16-byte chunks");
@@ -177,69 +169,14 @@ __device__ __forceinline__ uint32_t paeth_pk(uint32_t a, uint32_t b, uint32_t c)
                 pc = __builtin_elementwise_max(ds, -ds);
     const s16x2 fifteen = {15, 15};
     // sign masks per 16-bit lane; `opaque` keeps them bit masks (v_bfi) instead of per-half compares
-    const uint32_t nota = opaque(__builtin_bit_cast(uint32_t, ((pb - pa) | (pc - pa)) >> fifteen));
+    const uint32_t nota = opaque(__builtin_bit_cast(uint32_t, (__builtin_elementwise_min(pb, pc) - pa) >> fifteen));   // pa > min(pb, pc)
     const uint32_t usec = opaque(__builtin_bit_cast(uint32_t, (pc - pb) >> fifteen));
     const uint32_t bc = (c & usec) | (b & ~usec);
     return (bc & nota) | (a & ~nota);
 }
 
-// DW dwords per unit: 1 (RGBA8, VA16, ...: bpp 4) or 2 (RGBA16: bpp 8).  The row above is one unit ahead, so what
-// this lane needs from it -- the unit it finished in the previous step -- still sits in its registers, dword by dword.
-// CS (chunk skew): the row above is one 16-byte chunk ahead, so its unit above mine is dword k of what it wrote in the
-// previous iteration (`pw`, carried from tile to tile); ux0 then counts chunks, not units.
-template <int P, int DW, bool FIRST, bool PAETH, bool CS>
-__device__ __forceinline__ void reconstruct_pk(uint8_t *tile, int rowb, int lane, uint32_t ft, int64_t ux0,
-                                               uint32_t *o, uint32_t *bprev, uint32_t *pw)
-{
-    constexpr uint32_t M = 0x00ff00ffu;
-    const uint32_t m_sub = ft == 1 ? M : 0u, m_up = ft == 2 ? M : 0u, m_avg = ft == 3 ? M : 0u,
-                   m_pae = ft == 4 ? M : 0u;
-    u32x4 *mine = (u32x4 *)(tile + (1 + lane) * rowb);
-    const u32x4 *top = (const u32x4 *)tile;
-    uint32_t a_lo[DW], a_hi[DW], c_lo[DW], c_hi[DW];
-#pragma unroll
-    for (int d = 0; d < DW; ++d) { a_lo[d] = o[d] & M; a_hi[d] = (o[d] >> 8) & M; c_lo[d] = bprev[d] & M; c_hi[d] = (bprev[d] >> 8) & M; }
-#pragma unroll 2
-    for (int t4 = 0; t4 < P * DW / 4; ++t4) {
-        const u32x4 raw = mine[t4], tp = top[t4];
-        uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
-        const uint32_t tq[4] = {tp.x, tp.y, tp.z, tp.w};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            constexpr int dmask = DW - 1;
-            const int d = k & dmask;                           // which dword of its unit (DW divides 4)
-            const uint32_t b = from_lane_above(CS ? pw[k] : o[d], tq[k]);
-            const uint32_t b_lo = b & M, b_hi = (b >> 8) & M;
-            uint32_t p_lo = (a_lo[d] & m_sub) | (b_lo & m_up) | (((a_lo[d] + b_lo) >> 1) & m_avg);
-            uint32_t p_hi = (a_hi[d] & m_sub) | (b_hi & m_up) | (((a_hi[d] + b_hi) >> 1) & m_avg);
-            if (PAETH) {
-                p_lo |= paeth_pk(a_lo[d], b_lo, c_lo[d]) & m_pae;
-                p_hi |= paeth_pk(a_hi[d], b_hi, c_hi[d]) & m_pae;
-            }
-            uint32_t x_lo = ((r[k] & M) + p_lo) & M, x_hi = (((r[k] >> 8) & M) + p_hi) & M;
-            if (FIRST) {
-                // units left of the row start produce zeros, so that unit 0 sees a = c = 0
-                const uint32_t live = (CS ? ux0 + t4 >= 0 : ux0 + (t4 * 4 + k) / DW >= 0) ? M : 0u;
-                x_lo &= live; x_hi &= live;
-            }
-            o[d] = x_lo | x_hi << 8;
-            r[k] = o[d];
-            if (CS) pw[k] = o[d];
-            c_lo[d] = b_lo; c_hi[d] = b_hi; a_lo[d] = x_lo; a_hi[d] = x_hi;
-            bprev[d] = b;
-        }
-        u32x4 w; w.x = r[0]; w.y = r[1]; w.z = r[2]; w.w = r[3];
-        mine[t4] = w;
-    }
-}
-
-#ifdef SPNG_UNF_WPE                // tuning builds: cap the registers so that this many waves fit a SIMD
-#define SPNG_UNF_ATTR __attribute__((amdgpu_waves_per_eu(SPNG_UNF_WPE, SPNG_UNF_WPE)))
-#else
-#define SPNG_UNF_ATTR
-#endif
 template <int BPP>
-__global__ __launch_bounds__(SPNG_UNF_NW * 64) SPNG_UNF_ATTR void unfilter_kernel(const UnfJob *__restrict__ jobs,
+__global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob *__restrict__ jobs,
                                                                      const spng_result *__restrict__ results,
                                                                      uint32_t sb_rows)
 {
@@ -288,7 +225,8 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) SPNG_UNF_ATTR void unfilter_kerne
         rows = last - first;
     }
     const int64_t pitch = job.pitch;
-    const uint32_t ntiles = (uint32_t)((pitch + 63 * C::SKB + C::TB - 1) / C::TB);
+    const uint32_t W = job.pitch / BPP;
+    const uint32_t ntiles = (W + 63 + C::P - 1) / C::P;
     const uint32_t nbands = (rows + 63) / 64;
     uint8_t *tile = tiles[wave];
 
@@ -302,7 +240,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) SPNG_UNF_ATTR void unfilter_kerne
             u32x4 v = {0, 0, 0, 0};
             if (rw < rows)
                 v = load_window(job.in + (uint64_t)rw * job.in_stride + 1,
-                                (int64_t)T * C::TB - (int64_t)r * C::SKB + 16 * cj, pitch);
+                                ((int64_t)T * C::P - r) * BPP + 16 * cj, pitch);
             R[m] = v;
         }
         Rtop = u32x4{0, 0, 0, 0};
@@ -318,8 +256,8 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) SPNG_UNF_ATTR void unfilter_kerne
         }
         if (lane < C::CPR) *(u32x4 *)(tile + 16 * lane) = Rtop;
     };
-    // band j tile T needs the last row of band j-1 on bytes [T*TB, T*TB+TB): lane 63 of band j-1 is 63 * SKB
-    // bytes behind, so they come from its tiles T .. T+K.  `done` of the producing wave counts the
+    // band j tile T needs the last row of band j-1 on units [T*P, T*P+P): lane 63 of band j-1 is 63
+    // units behind, so they come from its tiles T .. T+K.  `done` of the producing wave counts the
     // tiles (over all of its bands) whose stores have been drained.
     auto ready = [&](uint32_t band, uint32_t T) -> bool {
         if (!band) return true;
@@ -341,8 +279,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) SPNG_UNF_ATTR void unfilter_kerne
     for (uint32_t band = wave; band < nbands; band += NW) {
         const uint32_t row = band * 64 + lane;
         const uint32_t ft = row < rows ? job.in[(uint64_t)row * job.in_stride] : 0u;
-        const bool any_pae = __any(ft == 4);            // no Paeth row in this band: skip its arithmetic
-        uint32_t o[BPP], bprev[BPP], pw[4] = {0, 0, 0, 0};
+        uint32_t o[BPP], bprev[BPP];
 #pragma unroll
         for (int k = 0; k < BPP; ++k) { o[k] = 0; bprev[k] = 0; }
 
@@ -377,18 +314,9 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) SPNG_UNF_ATTR void unfilter_kerne
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS tile written before it is read
 
-            // first unit (chunk skew: first chunk) of this lane's window, counted from the row start
-            const int64_t ux0 = C::CS ? (int64_t)T * C::CPR - lane : (int64_t)T * C::P - lane;
+            const int64_t ux0 = (int64_t)T * C::P - lane;
 #ifndef SPNG_UNF_NOCOMPUTE        // tuning builds only: measure the memory pipeline alone
-            if constexpr (BPP == 4 || BPP == 8) {
-                // (o / bprev hold the unit as packed dwords here, byte-wise in the generic form)
-                // (tiles in which some lane is still left of its row start)
-                if (T * (C::CS ? C::CPR : C::P) < 63u) reconstruct_pk<C::P, BPP / 4, true, true, C::CS>(tile, C::ROWB, lane, ft, ux0, o, bprev, pw);
-                else if (any_pae) reconstruct_pk<C::P, BPP / 4, false, true, C::CS>(tile, C::ROWB, lane, ft, ux0, o, bprev, pw);
-                else              reconstruct_pk<C::P, BPP / 4, false, false, C::CS>(tile, C::ROWB, lane, ft, ux0, o, bprev, pw);
-            } else {
-                reconstruct_generic<BPP, C::P>(tile, C::ROWB, lane, ft, ux0, o, bprev);
-            }
+            reconstruct_generic<BPP, C::P>(tile, C::ROWB, lane, ft, ux0, o, bprev);
 #endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
@@ -405,7 +333,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) SPNG_UNF_ATTR void unfilter_kerne
                 const uint32_t rw = band * 64 + r;
                 if (rw < rows)
                     store_window(job.out + (uint64_t)rw * job.out_stride,
-                                 (int64_t)T * C::TB - (int64_t)r * C::SKB + 16 * cj, pitch,
+                                 ((int64_t)T * C::P - r) * BPP + 16 * cj, pitch,
                                  *(const u32x4 *)(tile + (1 + r) * C::ROWB + 16 * cj));
             }
             ++count;
@@ -422,19 +350,306 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) SPNG_UNF_ATTR void unfilter_kerne
     if (lane == 0) __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// =====================================================================================================================
+// bpp 4 and 8 (RGBA8, VA16, RGBA16 ...): the line-aligned form (round 4)
+// =====================================================================================================================
+// What the kernel above pays for is not arithmetic and not its loads: `tools/probe_copy.hip` (profiles/r04_probe_copy.log)
+// moves the same bytes with the same skewed 64-row tiles at 3.3 TB/s -- and at 5.0 TB/s as soon as the STORES cover whole,
+// aligned 128-byte lines, whatever the loads look like (skewed or not, rows pitch + 1 apart or padded).  A row window that
+// trails the row above by bpp bytes never ends on a line boundary, so every line of PNG.Image.storage was written in two
+// pieces a tile apart, and the L2 -- 4 MiB per XCD, 8 MiB of tiles in flight -- had usually let go of the first piece by then.
+//
+// So here the skew lives in LDS only.  Global memory is read and written in row-aligned tiles of TB = 128 bytes (16 bytes per
+// lane, 8 lanes per row, 8 rows per instruction; storage rows are whole lines, scanline rows start wherever pitch + 1 puts them,
+// which loads do not mind).  A row keeps a ring of two tiles in LDS; lane r of a ramp reconstructs unit s - r at step s, reading
+// and writing its own row's ring one unit at a time (the upper neighbour still arrives from lane r - 1 by DPP).  A ramp must fit
+// a tile -- its last lane finishes tile T - 1 during phase T, which is when that tile is stored -- so a ramp is RR = 128 / bpp
+// rows: a wave carries two (bpp 4) or four (bpp 8) independent scanline chains side by side, each with its own top row, its own
+// piece of the image (pieces: see above) and RR-row bands pipelined over the waves of the workgroup as before.
+template <int BPP> struct Pk {
+    static constexpr int DW = BPP / 4;                   // dwords per unit
+    static constexpr int RR = 128 / BPP;                 // rows per ramp = units per tile
+    static constexpr int NCH = 64 / RR;                  // chains per wave
+    static constexpr int TB = 128, RING = 256;
+};
+#ifndef SPNG_UNF_PK_NW
+#define SPNG_UNF_PK_NW 4                                 // waves per workgroup (16.9 KB of LDS each; 2 and 3 measured 16 % slower, 1 the same)
+#endif
+struct __attribute__((aligned(16))) PkWave {
+    uint8_t rows[64][256];                               // [LDS row = lane][ring of two 128-byte tiles: tile T at (T & 1) * 128]
+    uint8_t top[4][2][128];                              // [chain][T & 1]: the row above the chain's band
+};
+
+// one phase = RR steps of every lane: 32 dwords of its row, eight at a time (the reads of the next eight are issued before
+// the arithmetic of these, so that no step waits for LDS).  Per dword ~50 VALU operations: the two 16-bit halves only where
+// nine bits are needed (Paeth); Average is v_lerp_u8, the filter select and the byte-wise add run on whole dwords
+// (x + p per byte = ((x & 7f..) + (p & 7f..)) ^ ((x ^ p) & 80..)), the halves come from v_perm_b32.
+// WRAP: the lane's 128-byte window may cross the end of the ring (even phases: tile T - 1 sits in the upper slot).
+template <int BPP, bool FIRST, bool PAETH, bool WRAP>
+__device__ __forceinline__ void phase_pk(uint8_t *rowp, const uint8_t *topp, uint32_t a0, int u0, bool head, uint32_t ft,
+                                         uint32_t *o, uint32_t *bprev)
+{
+    constexpr int DW = Pk<BPP>::DW;
+    constexpr uint32_t M = 0x00ff00ffu, SEL_LO = 0x0c020c00u, SEL_HI = 0x0c030c01u;
+    const uint32_t m_sub = ft == 1 ? ~0u : 0u, m_up = ft == 2 ? ~0u : 0u, m_avg = ft == 3 ? ~0u : 0u, m_pae = ft == 4 ? ~0u : 0u;
+    uint32_t a_lo[DW], a_hi[DW], c_lo[DW], c_hi[DW];
+#pragma unroll
+    for (int d = 0; d < DW; ++d) { a_lo[d] = o[d] & M; a_hi[d] = (o[d] >> 8) & M; c_lo[d] = bprev[d] & M; c_hi[d] = (bprev[d] >> 8) & M; }
+    auto at = [&](int dw) -> uint8_t * { return WRAP ? rowp + ((a0 + 4u * (uint32_t)dw) & 255u) : rowp + a0 + 4 * dw; };
+    uint32_t xa[8], xb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xa[i] = *(const uint32_t *)at(i);
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+        if (blk < 3) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xb[i] = *(const uint32_t *)at(8 * (blk + 1) + i);
+        }
+        const u32x4 t0 = ((const u32x4 *)topp)[2 * blk], t1 = ((const u32x4 *)topp)[2 * blk + 1];
+        const uint32_t tq[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            constexpr int dmask = DW - 1;
+            const int d = i & dmask;                           // which dword of its unit
+            uint32_t b = from_lane_above(o[d], 0u);
+            b = head ? tq[i] : b;                              // (first lane of a ramp: the row above the band)
+            uint32_t p = (o[d] & m_sub) | (b & m_up) | (__builtin_amdgcn_lerp(o[d], b, 0u) & m_avg);
+            const uint32_t b_lo = __builtin_amdgcn_perm(0u, b, SEL_LO), b_hi = __builtin_amdgcn_perm(0u, b, SEL_HI);
+            if (PAETH) p |= (paeth_pk(a_lo[d], b_lo, c_lo[d]) | paeth_pk(a_hi[d], b_hi, c_hi[d]) << 8) & m_pae;
+            const uint32_t x = xa[i];
+            uint32_t v = ((x & 0x7f7f7f7fu) + (p & 0x7f7f7f7fu)) ^ ((x ^ p) & 0x80808080u);
+            if (FIRST) v = (u0 + (8 * blk + i) / DW >= 0) ? v : 0u;   // units left of the row start produce zeros: unit 0 sees a = c = 0
+            o[d] = v;
+            r[i] = v;
+            c_lo[d] = b_lo; c_hi[d] = b_hi;
+            a_lo[d] = __builtin_amdgcn_perm(0u, v, SEL_LO); a_hi[d] = __builtin_amdgcn_perm(0u, v, SEL_HI);
+            bprev[d] = b;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(uint32_t *)at(8 * blk + i) = r[i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xa[i] = xb[i];
+    }
+}
+
+template <int BPP>
+__global__ __launch_bounds__(SPNG_UNF_PK_NW * 64) void unfilter_pk_kernel(const UnfJob *__restrict__ jobs, const spng_result *__restrict__ results,
+                                                                           uint32_t sb_rows, uint32_t npieces)
+{
+    using C = Pk<BPP>;
+    constexpr int NW = SPNG_UNF_PK_NW, RR = C::RR, NCH = C::NCH;
+    __shared__ PkWave lds[NW];
+    __shared__ uint32_t done[NW];                        // phases completed (stores drained) by each wave
+
+    UnfJob job = jobs[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = (int)UNI(threadIdx.x >> 6);
+    if (results && skip_status(results[job.image].status)) return;
+    if (threadIdx.x < NW) done[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t rows = job.rows;
+    if (job.rows_len) {
+        // a short stream silently yields an incomplete image (PNG.Decoder.swift:88-94)
+        const uint64_t len = *job.rows_len;
+        const uint64_t avail = len > job.stream_off ? (len - job.stream_off) / job.in_stride : 0;
+        rows = avail < rows ? (uint32_t)avail : rows;
+    }
+    // the pieces of this workgroup's chains (see unfilter_kernel: a piece starts on a row filtered with None or Sub)
+    auto cut = [&](uint64_t x) -> uint32_t {
+        if (x == 0) return 0;
+        for (uint64_t r0 = x; r0 < rows; r0 += 64) {
+            const uint64_t r = r0 + lane;
+            const uint32_t ft = r < rows ? job.in[r * job.in_stride] : 0u;
+            const unsigned long long m = __ballot(r < rows && ft <= 1);
+            if (m) return (uint32_t)(r0 + __ffsll((long long)m) - 1);
+        }
+        return rows;
+    };
+    uint32_t first[NCH], nrows[NCH];
+    bool htop[NCH];
+    uint32_t maxb = 0;
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+        const uint32_t q = blockIdx.y * NCH + h;
+        uint32_t f = 0, l = 0;
+        if (q < npieces) {
+            f = npieces > 1 ? UNI(cut((uint64_t)q * sb_rows)) : 0u;
+            l = q + 1 == npieces ? rows : UNI(cut((uint64_t)(q + 1) * sb_rows));
+        }
+        first[h] = f; nrows[h] = l > f ? l - f : 0u;
+        htop[h] = f == 0 && job.has_prev != 0;          // (rows that arrived with a later push: the row above is in front of `out`)
+        const uint32_t nb = (nrows[h] + RR - 1) / RR;
+        maxb = nb > maxb ? nb : maxb;
+    }
+    if (!maxb) return;
+    const int64_t pitch = job.pitch;
+    const uint32_t nta = (uint32_t)((pitch + C::TB - 1) / C::TB), nph = nta + 1;   // row tiles; phases per band
+    PkWave &w = lds[wave];
+
+    // lane as a loader: chunk cj of LDS rows r0, r0 + 8, ... (8 rows per instruction);  lane as a worker: LDS row = lane
+    const int r0 = lane >> 3, cj = lane & 7;
+    const int hh = lane / RR, rp = lane % RR;            // my chain, my place in its ramp
+    uint32_t my_first = 0, my_rows = 0;
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) if (hh == h) { my_first = first[h]; my_rows = nrows[h]; }
+    const bool head = rp == 0;
+
+    u32x4 R[8], Rtop;
+    auto issue = [&](uint32_t band, uint32_t T) {
+        const int64_t off = (int64_t)T * C::TB + 16 * cj;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            constexpr int per = RR / 8;                          // load instructions per chain
+            const int h = m / per;
+            const uint32_t rw = band * RR + (uint32_t)((m % per) * 8 + r0);      // row inside the chain's piece
+            u32x4 v = {0, 0, 0, 0};
+            if (rw < nrows[h]) v = load_window(job.in + (uint64_t)(first[h] + rw) * job.in_stride + 1, off, pitch);
+            R[m] = v;
+        }
+        Rtop = u32x4{0, 0, 0, 0};
+        if (lane < NCH * 8) {
+            uint32_t f = 0, n = 0; bool ht = false;
+#pragma unroll
+            for (int h = 0; h < NCH; ++h) if (r0 == h) { f = first[h]; n = nrows[h]; ht = htop[h]; }
+            if ((band || ht) && band * RR < n)
+                Rtop = load_window_l2(job.out + ((int64_t)f + (int64_t)band * RR - 1) * (int64_t)job.out_stride, off, pitch);
+        }
+    };
+    auto commit = [&](uint32_t T) {
+        const uint32_t slot = (T & 1) * 128;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) *(u32x4 *)(&w.rows[r0 + 8 * m][slot + 16 * cj]) = R[m];
+        if (lane < NCH * 8) *(u32x4 *)(&w.top[r0][T & 1][16 * cj]) = Rtop;
+    };
+    // Band j tile T needs the last row of band j - 1 on bytes [T * TB, T * TB + TB): that tile is stored at the end of the
+    // producer's phase T + 1.  `done` of the producing wave counts the phases (over all of its bands) whose stores have drained.
+    auto ready = [&](uint32_t band, uint32_t T) -> bool {
+        if (!band) return true;
+        const uint32_t pw = (band - 1) % NW, pk = (band - 1) / NW;
+        const uint32_t need = pk * nph + (T + 1 < nph ? T + 1 : nph - 1) + 1;
+        return __hip_atomic_load(&done[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
+    };
+    auto wait_ready = [&](uint32_t band, uint32_t T) {
+        uint32_t spins = 0;
+        while (!ready(band, T)) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 26)) __builtin_trap();  // a protocol bug must fault, not hang the GPU
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+
+    uint32_t count = 0;                                  // phases this wave has completed
+    bool staged = false;                                 // R holds the tile about to be committed
+    for (uint32_t band = wave; band < maxb; band += NW) {
+        const uint32_t row = band * RR + (uint32_t)rp;
+        const bool mine = row < my_rows;
+        const uint32_t ft = mine ? job.in[(uint64_t)(my_first + row) * job.in_stride] : 0u;
+        const bool any_pae = __any(ft == 4);            // no Paeth row in this band: skip its arithmetic
+        uint32_t o[C::DW], bprev[C::DW];
+#pragma unroll
+        for (int k = 0; k < C::DW; ++k) { o[k] = 0; bprev[k] = 0; }
+
+        for (uint32_t T = 0; T < nph; ++T) {
+            if (T < nta) {
+                if (!staged) { wait_ready(band, T); issue(band, T); }
+                commit(T);
+            }
+            staged = false;
+            // prefetch the next tile of this wave while this phase is worked on.  If its producer (another wave) is not far
+            // enough ahead yet, fall back behind it *now*: publish what is pending and wait, so that from here on the prefetch
+            // always overlaps the arithmetic.
+            uint32_t nb = band, nT = T + 1;
+            if (nT >= nta) { nb = band + NW; nT = 0; }
+            if (nb < maxb && (T + 1 < nta || T + 1 == nph)) {
+                bool ok = ready(nb, nT);
+                // Blocking here is deadlock-free only if nothing the awaited tile depends on is a phase this wave has not
+                // published yet: (nb, nT) reaches back to phase nT + 1 + 2 (NW - 1) of this wave's band nb - NW.  Same band:
+                // that band is complete.  Next band (we are in the last phase of the current one): only when the chain stops
+                // short of this phase.
+                const bool may_block = NW > 1 && nb && (nb == band || (uint32_t)(2 * NW) + 1 < nph);
+                if (!ok && may_block) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0 && count)
+                        __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    wait_ready(nb, nT);
+                    ok = true;
+                }
+                if (ok) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    issue(nb, nT);
+                    staged = true;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS tile written before it is read
+
+            const int u0 = (int)(T * RR) - rp;           // my first unit of this phase
+            const uint32_t a0 = (uint32_t)(u0 * BPP) & 255u;
+#ifndef SPNG_UNF_NOCOMPUTE        // tuning builds only: measure the memory pipeline alone
+            // (odd phases: the window [128 - bpp rp, 256 - bpp rp) of the ring never wraps)
+            if (T == 0)            phase_pk<BPP, true, true, true>(w.rows[lane], w.top[hh][0], a0, u0, head, ft, o, bprev);
+            else if (T & 1) {
+                if (any_pae)       phase_pk<BPP, false, true, false>(w.rows[lane], w.top[hh][1], a0, u0, head, ft, o, bprev);
+                else               phase_pk<BPP, false, false, false>(w.rows[lane], w.top[hh][1], a0, u0, head, ft, o, bprev);
+            } else {
+                if (any_pae)       phase_pk<BPP, false, true, true>(w.rows[lane], w.top[hh][0], a0, u0, head, ft, o, bprev);
+                else               phase_pk<BPP, false, false, true>(w.rows[lane], w.top[hh][0], a0, u0, head, ft, o, bprev);
+            }
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+
+            // The stores of the previous phase (and the prefetch loads) have had the whole reconstruction to complete:
+            // drain, then publish the previous phase.  Publishing one phase late keeps the store latency off the critical path.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && count)
+                __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // tile T - 1 is complete in every row: whole lines to the output
+            if (T) {
+                const uint32_t slot = ((T - 1) & 1) * 128;
+                const int64_t off = (int64_t)(T - 1) * C::TB + 16 * cj;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    constexpr int per = RR / 8;
+                    const int h = m / per;
+                    const uint32_t rw = band * RR + (uint32_t)((m % per) * 8 + r0);
+                    if (rw < nrows[h])
+                        store_window(job.out + (uint64_t)(first[h] + rw) * job.out_stride, off, pitch,
+                                     *(const u32x4 *)(&w.rows[r0 + 8 * m][slot + 16 * cj]));
+                }
+            }
+            ++count;
+            // a tile that could not be prefetched depends on this phase (or a later one): publish now
+            if (!staged) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    // last phase of this wave
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&done[wave], count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, spng_result *d_results,
                            uint32_t pieces, uint32_t piece_rows, hipStream_t stream)
 {
     if (!count) return hipSuccess;
     constexpr int T = SPNG_UNF_NW * 64;
     const dim3 grid(count, pieces ? pieces : 1);
+    if (bpp == 4 || bpp == 8) {
+        // the line-aligned form: a workgroup's waves carry NCH chains each, i.e. NCH pieces per workgroup
+        const uint32_t np = pieces ? pieces : 1, nch = bpp == 4 ? Pk<4>::NCH : Pk<8>::NCH;
+        const dim3 g2(count, (np + nch - 1) / nch);
+        if (bpp == 4) unfilter_pk_kernel<4><<<g2, SPNG_UNF_PK_NW * 64, 0, stream>>>(d_jobs, d_results, piece_rows, np);
+        else unfilter_pk_kernel<8><<<g2, SPNG_UNF_PK_NW * 64, 0, stream>>>(d_jobs, d_results, piece_rows, np);
+        return hipGetLastError();
+    }
     switch (bpp) {
     case 1: unfilter_kernel<1><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     case 2: unfilter_kernel<2><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     case 3: unfilter_kernel<3><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
-    case 4: unfilter_kernel<4><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     case 6: unfilter_kernel<6><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
-    case 8: unfilter_kernel<8><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -105,6 +105,12 @@ def test_unfilter_kernel_resources():
     for v in k4:
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0
         assert v["group_segment_fixed_size"] <= 81920        # >= 2 workgroups per CU (LDS tiles set the occupancy)
+    # the line-aligned form (bpp 4 / 8): a ring of two 128-byte tiles per row, two 4-wave workgroups per CU
+    pk = [v for k, v in table.items() if "unfilter_pk_kernel" in k]
+    assert len(pk) == 2
+    for v in pk:
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0
+        assert v["group_segment_fixed_size"] <= 81920 and v["vgpr_count"] <= 256 and v["max_flat_workgroup_size"] == 256
 
 
 def test_deflate_kernel_resources():
