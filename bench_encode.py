@@ -84,7 +84,7 @@ def run_encode(args, torch, dist, spng, s, rank, world):
         step()
     fence()
     dt = time.perf_counter() - t0
-    prof = {k: s.profile_get(getattr(spng, "K_" + k.upper()))[0] / args.steps for k in ("filter", "deflate")}
+    prof = {k: s.profile_get(getattr(spng, "K_" + k.upper()))[0] / args.steps for k in ("filter", "deflate", "dfl_search", "dfl_parse")}
     s.profile(False)
     res = list((spng.Result * n).from_buffer_copy(bytes(dres.cpu().numpy())))
     assert all(r.status == 0 for r in res), [r.status for r in res if r.status][:8]
@@ -112,6 +112,10 @@ def run_encode(args, torch, dist, spng, s, rank, world):
                     "frac_of_hbm_peak": round((n * U + total_c) / (prof["deflate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)},
     }
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    # the two kernels of the level >= 8 rounds (both inside "deflate"): the chip-wide match search reads U, the one-wave-per-stream
+    # parse reads U again and writes C
+    kernels["deflate"]["search_ms"] = round(prof["dfl_search"], 3)
+    kernels["deflate"]["parse_ms"] = round(prof["dfl_parse"], 3)
     out = {
         "metric": "encoded_mpixels_per_s", "value": round(args.images * (world if weak else 1) * MPIX / (dt / args.steps), 2),
         "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),

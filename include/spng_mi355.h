@@ -135,8 +135,15 @@ enum { SPNG_CFG_INFLATE_MODE = 0,   /* SPNG_INFLATE_AUTO: parallel pipeline, ser
                                               (an experiment: slower than one pass on MI355X, so never by default) */
        SPNG_CFG_RESOLVE_PARTS = 5,         /* parallel inflate, batches of <= 384 streams: workgroups that resolve ONE stream side by
                                               side (0: as many as fill the chip, at most 64; 1: one, as in large batches; n: n) */
-       SPNG_CFG_COUNT = 6 };
+       SPNG_CFG_DEFLATE_MODE = 6,          /* levels >= 8: SPNG_DEFLATE_AUTO = search and parse in kernels of their own, rounds of 2^21 vertices
+                                              (streams its candidate pool cannot serve: the one-kernel search afterwards);
+                                              SPNG_DEFLATE_ONE_KERNEL = one wave per stream does everything (round 2's kernel) */
+       SPNG_CFG_DEFLATE_BYTES = 7,         /* levels >= 8: size limit of the context's scratch slab (per-stream vertex arrays, candidate
+                                              pool, link rings) in bytes; 0 = half of the free device memory.  Streams that do not
+                                              fit side by side go in groups */
+       SPNG_CFG_COUNT = 8 };
 enum { SPNG_INFLATE_AUTO = 0, SPNG_INFLATE_SERIAL = 1 };
+enum { SPNG_DEFLATE_AUTO = 0, SPNG_DEFLATE_ONE_KERNEL = 1 };
 enum { SPNG_OVERLAP_AUTO = 0, SPNG_OVERLAP_ALWAYS = 1, SPNG_OVERLAP_NEVER = 2 };
 int32_t spng_configure(spng_ctx *ctx, int key, int64_t value);
 
@@ -148,6 +155,7 @@ enum { SPNG_K_INFLATE = 0,          /* the serial inflate kernel (streams the pa
        SPNG_K_UNPACK = 7,
        SPNG_K_LEX = 12,             /* chunk lexing + CRC-32 / IDAT chunk emission */
        SPNG_K_PINF_FIND = 8, SPNG_K_PINF_DECODE = 9, SPNG_K_PINF_RESOLVE = 11,   /* its stages */
+       SPNG_K_DFL_SEARCH = 13, SPNG_K_DFL_PARSE = 14,   /* levels >= 8: the two kernels of a round (inside SPNG_K_DEFLATE) */
        SPNG_K_COUNT = 16 };
 int32_t spng_profile(spng_ctx *ctx, int enable);                /* enable/disable + reset counters  */
 int32_t spng_profile_get(spng_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);

@@ -72,7 +72,8 @@ struct spng_ctx {
     int slab_next = 0;
     void *h_ws = nullptr;                 // the slab of the call in progress
     Slab *cur = nullptr;
-    void *d_ring = nullptr; size_t ring_cap = 0;     // deflate link rings
+    void *d_ring = nullptr; size_t ring_cap = 0;     // deflate link rings (greedy / lazy kernel)
+    void *d_ring2 = nullptr; size_t ring2_cap = 0;   // (one-kernel full search)
     // parallel inflate (pinflate2.hip): chunk-record slab, token buffer, knobs (spng_configure)
     void *d_graph = nullptr; size_t graph_cap = 0;   // deflate levels >= 8: match graphs
     void *d_log = nullptr;  size_t log_cap = 0;
@@ -88,7 +89,7 @@ struct spng_ctx {
     // second stream of the pipeline: the decode of one half of a batch runs beside the resolve of the other
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
-    int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0, 0, 0, 0};
+    int64_t cfg[SPNG_CFG_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
     // profiling
     bool profiling = false;
     struct Span { int kernel; hipEvent_t a, b; };
@@ -249,6 +250,7 @@ void spng_destroy(spng_ctx *c)
     if (c->d_ws) (void)hipFree(c->d_ws);
     for (auto &sl : c->slabs) { if (sl.h) (void)hipHostFree(sl.h); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     if (c->d_ring) (void)hipFree(c->d_ring);
+    if (c->d_ring2) (void)hipFree(c->d_ring2);
     if (c->d_graph) (void)hipFree(c->d_graph);
     if (c->d_log) (void)hipFree(c->d_log);
     if (c->d_tok) (void)hipFree(c->d_tok);
@@ -1403,79 +1405,79 @@ int32_t spng_unpack(spng_ctx *c, const void *storage, uint32_t w, uint32_t h, in
 
 uint64_t spng_deflate_bound(uint64_t n) { return n + n / 4 + 4096; }   // (covers the 18 bytes of a gzip wrapper too)
 
-// shared by spng_deflate_batch / spng_encode_batch.  Per-stream link rings live in a context-owned slab; so
-// does the match graph of the levels >= 8 (129 bytes per vertex, up to 2^21 vertices per stream): those
-// streams are launched in groups that fit the slab, one group after the other on the stream.
-static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_result *dr, Arena &a, size_t jslot,
-                              size_t gzparts = (size_t)-1)
+// The one-kernel full search (deflate_full_kernel) for the streams in `sorted[first, last)`: per-stream graph scratch (129 bytes per
+// vertex, up to 2^21 vertices) from the context's slab, in groups that fit it.  The path of streams the two-kernel search could
+// not finish (its pool ran dry under them), and of SPNG_CFG_DEFLATE_MODE = SPNG_DEFLATE_ONE_KERNEL.
+static int32_t deflate_full_legacy(spng_ctx *c, std::vector<DeflateJob> &sorted, size_t first, size_t last, spng_result *dr, Arena &a, size_t jslot)
 {
-    const size_t ring_bytes = (size_t)jobs.size() * 65536 * 4;
-    if (ring_bytes > c->ring_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        if (c->d_ring) HIP_TRY(hipFree(c->d_ring));
-        c->d_ring = nullptr; c->ring_cap = 0;
-        HIP_TRY(hipMalloc(&c->d_ring, ring_bytes));
-        c->ring_cap = ring_bytes;
+    if (first >= last) return SPNG_DONE;
+    {
+        // link rings of these streams (the slab may still be read by the greedy / lazy kernel of this call: wait before it moves)
+        const size_t ring_bytes = (last - first) * 65536 * 4;
+        if (ring_bytes > c->ring2_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_ring2) HIP_TRY(hipFree(c->d_ring2));
+            c->d_ring2 = nullptr; c->ring2_cap = 0;
+            HIP_TRY(hipMalloc(&c->d_ring2, ring_bytes));
+            c->ring2_cap = ring_bytes;
+        }
     }
-    // greedy / lazy streams first, then the full-search ones: two contiguous job tables
-    std::vector<DeflateJob> sorted;
-    sorted.reserve(jobs.size());
-    for (auto &j : jobs) if (j.level < 8) sorted.push_back(j);
-    const size_t nfast = sorted.size();
     uint64_t need = 0, largest = 0;
-    for (auto &j : jobs) if (j.level >= 8) {
-        sorted.push_back(j);
-        DeflateJob &f = sorted.back();
+    for (size_t i = first; i < last; ++i) {
+        DeflateJob &f = sorted[i];
         f.graph_vertices = (uint32_t)deflate_graph_vertices(f.src_len);
         const uint64_t bytes = deflate_graph_bytes(f.graph_vertices);
         need += bytes; largest = bytes > largest ? bytes : largest;
     }
-    if (need) {
+    {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        uint64_t budget = (uint64_t)(free_b + c->graph_cap) * 3 / 4;
+        uint64_t budget = c->cfg[SPNG_CFG_DEFLATE_BYTES] ? (uint64_t)c->cfg[SPNG_CFG_DEFLATE_BYTES] : (uint64_t)(free_b + c->graph_cap) / 2;
         if (budget < largest) budget = largest;
-        const uint64_t want = need < budget ? need : budget;
-        if (want > c->graph_cap) {
+        uint64_t want = need < budget ? need : budget;
+        while (want > c->graph_cap) {
             HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->d_graph) HIP_TRY(hipFree(c->d_graph));
             c->d_graph = nullptr; c->graph_cap = 0;
-            HIP_TRY(hipMalloc(&c->d_graph, want));
-            c->graph_cap = want;
+            if (hipMalloc(&c->d_graph, want) == hipSuccess) { c->graph_cap = want; break; }
+            (void)hipGetLastError();
+            // no room for that many streams side by side: smaller groups
+            if (want <= largest) return fail_hip(hipErrorOutOfMemory, "deflate: no room for the match graph of one stream");
+            want = want / 2 > largest ? want / 2 : largest;
         }
     }
     // Which full-search streams get helper waves: the ones whose input repeats itself (deflate_density_kernel).  The sparse
     // ones go first, so every launch group is of one kind.
-    const size_t nfull = sorted.size() - nfast;
+    const size_t nfull = last - first;
     std::vector<uint32_t> dense(nfull, 0);
-    if (nfull) {
+    {
         memcpy(a.host<DeflateJob>(jslot), sorted.data(), sorted.size() * sizeof(DeflateJob));
         if (int32_t st = c->upload(jslot, jslot + sorted.size() * sizeof(DeflateJob))) return st;
         const size_t dslot = a.take(nfull * 4);
-        HIP_TRY(launch_deflate_density(a.dev<DeflateJob>(jslot) + nfast, (uint32_t)nfull, a.dev<uint32_t>(dslot), c->stream));
+        HIP_TRY(launch_deflate_density(a.dev<DeflateJob>(jslot) + first, (uint32_t)nfull, a.dev<uint32_t>(dslot), c->stream));
         HIP_TRY(hipMemcpyAsync(dense.data(), a.dev<uint32_t>(dslot), nfull * 4, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         std::vector<DeflateJob> part;
         part.reserve(nfull);
         for (int kind = 0; kind < 2; ++kind)
-            for (size_t i = 0; i < nfull; ++i) if ((int)dense[i] == kind) part.push_back(sorted[nfast + i]);
+            for (size_t i = 0; i < nfull; ++i) if ((int)dense[i] == kind) part.push_back(sorted[first + i]);
         size_t ndense = 0;
         for (uint32_t d : dense) ndense += d;
-        std::copy(part.begin(), part.end(), sorted.begin() + nfast);
+        std::copy(part.begin(), part.end(), sorted.begin() + first);
         for (size_t i = 0; i < nfull; ++i) dense[i] = i >= nfull - ndense;
     }
-    for (size_t i = 0; i < sorted.size(); ++i) sorted[i].ring = (uint32_t *)c->d_ring + i * 65536;
     // groups of full-search streams of one kind that fit the slab together
     struct Group { size_t first, last; bool helpers; };
     std::vector<Group> groups;
-    for (size_t i = nfast; i < sorted.size();) {
+    for (size_t i = first; i < last;) {
         uint64_t used = 0;
         size_t k = i;
-        const bool kind = dense[i - nfast] != 0;
-        while (k < sorted.size() && (dense[k - nfast] != 0) == kind) {
+        const bool kind = dense[i - first] != 0;
+        while (k < last && (dense[k - first] != 0) == kind) {
             const uint64_t bytes = deflate_graph_bytes(sorted[k].graph_vertices);
             if (used + bytes > c->graph_cap && k > i) break;
             sorted[k].graph = (uint32_t *)((char *)c->d_graph + used);
+            sorted[k].ring = (uint32_t *)c->d_ring2 + (k - first) * 65536;
             used += bytes; ++k;
         }
         groups.push_back({i, k, kind});
@@ -1483,11 +1485,174 @@ static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_r
     }
     memcpy(a.host<DeflateJob>(jslot), sorted.data(), sorted.size() * sizeof(DeflateJob));
     if (int32_t st = c->upload(jslot, jslot + sorted.size() * sizeof(DeflateJob))) return st;
+    for (auto &gr : groups)
+        HIP_TRY(launch_deflate_full(a.dev<DeflateJob>(jslot) + gr.first, (uint32_t)(gr.last - gr.first), gr.helpers, dr, c->stream));
+    return SPNG_DONE;
+}
+
+// The two-kernel full search (deflate.hip, "round 4") for sorted[first, last): per stream 11 bytes of scratch per vertex of a
+// round (<= 2^21 vertices), a pool of candidate words shared by all streams, rings for the search workgroups -- all from the
+// context's slab, which is capped at SPNG_CFG_DEFLATE_BYTES (default: half of the free memory); streams whose scratch does not fit
+// side by side go in groups.  Streams the pool could not serve come back unfinished and take the one-kernel search.
+static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted, size_t first, size_t last, spng_result *dr, Arena &a, size_t jslot)
+{
+    if (first >= last) return SPNG_DONE;
+    const size_t nfull = last - first;
+    auto scratch_of = [](uint64_t n) -> uint64_t {
+        const uint64_t V = deflate2_vertices(n), B = V / 64 + 2;
+        return ((2 * V + 255) & ~255ull) + ((8 * B + 255) & ~255ull) + ((4 * B + 255) & ~255ull) + ((8 * B + 255) & ~255ull) +
+               2 * ((4 * (V + 2) + 255) & ~255ull) + ((V + 2 + 255) & ~255ull);
+    };
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = c->cfg[SPNG_CFG_DEFLATE_BYTES] ? (uint64_t)c->cfg[SPNG_CFG_DEFLATE_BYTES] : (uint64_t)(free_b + c->graph_cap + c->ring_cap) / 2;
+    uint64_t largest = 0, all = 0, worst_pool = 0;
+    for (size_t i = first; i < last; ++i) {
+        const uint64_t sc = scratch_of(sorted[i].src_len);
+        largest = sc > largest ? sc : largest; all += sc;
+        // (a position leaves at most min(attempts, 30) words: 14 at level 8, 20 at level 9, 30 from level 10 on)
+        const uint64_t per = sorted[i].level <= 8 ? 14 : sorted[i].level == 9 ? 20 : 30;
+        worst_pool += (sorted[i].src_len < (1u << 21) ? sorted[i].src_len : (1u << 21)) * per * 4;
+    }
+    const uint64_t min_pool = 64ull << 20;
+    if (budget < largest + min_pool + (64ull << 20)) budget = largest + min_pool + (64ull << 20);
+    // groups of streams whose scratch takes at most 2 / 3 of the budget; the rest is rings and pool
+    std::vector<std::pair<size_t, size_t>> groups;
+    for (size_t i = first; i < last;) {
+        uint64_t used = 0; size_t k = i;
+        while (k < last && (k == i || used + scratch_of(sorted[k].src_len) <= budget * 2 / 3)) used += scratch_of(sorted[k++].src_len);
+        groups.push_back({i, k});
+        i = k;
+    }
+    uint64_t slab = 0;
+    struct Lay { uint64_t scratch, rings, pool; uint32_t cps, chunk; };
+    std::vector<Lay> lay;
+    for (auto &gr : groups) {
+        const uint32_t cnt = (uint32_t)(gr.second - gr.first);
+        Lay l;
+        l.scratch = 0;
+        for (size_t i = gr.first; i < gr.second; ++i) l.scratch += scratch_of(sorted[i].src_len);
+        uint32_t cps = (1536 + cnt - 1) / cnt;
+        cps = cps < 1 ? 1 : cps > 64 ? 64 : cps;
+        l.cps = cps; l.chunk = (((1u << 21) / cps + 63) / 64) * 64;
+        l.rings = (uint64_t)cnt * cps * 65536 * 4;
+        uint64_t room = budget > l.scratch + l.rings ? budget - l.scratch - l.rings : 0;
+        l.pool = worst_pool < room ? worst_pool : room;
+        if (l.pool < min_pool) l.pool = min_pool;
+        l.pool &= ~255ull;
+        const uint64_t tot = l.scratch + l.rings + l.pool + 4096;
+        slab = tot > slab ? tot : slab;
+        lay.push_back(l);
+    }
+    if (slab > c->graph_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_graph) HIP_TRY(hipFree(c->d_graph));
+        c->d_graph = nullptr; c->graph_cap = 0;
+        if (hipMalloc(&c->d_graph, slab) != hipSuccess) {
+            (void)hipGetLastError();
+            return deflate_full_legacy(c, sorted, first, last, dr, a, jslot);   // (it sizes its groups by what it can get)
+        }
+        c->graph_cap = slab;
+    }
+    // the stream table and the device-side states: in the arena, uploaded once
+    const size_t sslot = a.take(nfull * sizeof(D2Stream)), tslot = a.take(nfull * sizeof(D2State)), fslot = a.take((nfull + 1) * 4);
+    D2Stream *hs = a.host<D2Stream>(sslot);
+    D2State *ht = a.host<D2State>(tslot);
+    memset(ht, 0, nfull * sizeof(D2State));
+    uint32_t max_rounds = 0;
+    for (size_t g = 0; g < groups.size(); ++g) {
+        char *base = (char *)c->d_graph;
+        uint64_t at = 0;
+        auto take = [&](uint64_t bytes) { char *p = base + at; at += (bytes + 255) & ~255ull; return p; };
+        for (size_t i = groups[g].first; i < groups[g].second; ++i) {
+            const DeflateJob &j = sorted[i];
+            D2Stream &s = hs[i - first];
+            const uint64_t V = deflate2_vertices(j.src_len), B = V / 64 + 2;
+            s.src = j.src; s.dst = j.dst; s.src_len = j.src_len; s.dst_cap = j.dst_cap; s.format = j.format; s.level = j.level;
+            s.image = j.image; s.exponent = j.exponent;
+            s.state = a.dev<D2State>(tslot) + (i - first);
+            s.vinfo = (uint16_t *)take(2 * V); s.bbase = (uint64_t *)take(8 * B); s.bwords = (uint32_t *)take(4 * B); s.emask = (uint64_t *)take(8 * B);
+            s.up = (uint32_t *)take(4 * (V + 2)); s.step = (uint32_t *)take(4 * (V + 2)); s.pathb = (uint8_t *)take(V + 2);
+            D2State &t = ht[i - first];
+            t.rb = 0; t.limit = 2048; t.generic = 1;
+            t.re = j.src_len < 3 ? j.src_len : 0;
+            if (j.src_len >= 3) {
+                // (= d2_round_end(0, 2048, n): the blocks below the cap fit one round)
+                uint64_t end = 0; uint32_t lim = 2048;
+                for (;;) {
+                    const uint64_t room = j.src_len - end, size = (uint64_t)(lim - 1) < room ? (uint64_t)(lim - 1) : room;
+                    if (end > 0 && end + size > (1u << 21)) break;
+                    end += size;
+                    if (end == j.src_len) break;
+                    lim = 2 * lim < (1u << 21) ? 2 * lim : 1u << 21;
+                }
+                t.re = end;
+            }
+            const uint32_t r = deflate2_rounds(j.src_len);
+            max_rounds = r > max_rounds ? r : max_rounds;
+        }
+    }
+    if (int32_t st = c->upload(sslot, tslot + nfull * sizeof(D2State))) return st;
+    uint32_t *d_failed = a.dev<uint32_t>(fslot);
+    for (size_t g = 0; g < groups.size(); ++g) {
+        const uint32_t cnt = (uint32_t)(groups[g].second - groups[g].first);
+        const Lay &l = lay[g];
+        char *rings = (char *)c->d_graph + ((l.scratch + 255) & ~255ull);
+        char *pool = rings + l.rings;
+        unsigned long long *pool_next = (unsigned long long *)(pool + l.pool);
+        uint32_t rounds = 0;
+        for (size_t i = groups[g].first; i < groups[g].second; ++i) { const uint32_t r = deflate2_rounds(sorted[i].src_len); rounds = r > rounds ? r : rounds; }
+        for (uint32_t r = 0; r < rounds; ++r) {
+            { Timed t(c, SPNG_K_DFL_SEARCH); HIP_TRY(launch_deflate2_search(a.dev<D2Stream>(sslot) + (groups[g].first - first), cnt, l.cps, l.chunk, (uint32_t *)pool,
+                                                                            pool_next, l.pool / 4, (uint32_t *)rings, c->stream)); }
+            { Timed t(c, SPNG_K_DFL_PARSE); HIP_TRY(launch_deflate2_parse(a.dev<D2Stream>(sslot) + (groups[g].first - first), cnt, (uint32_t *)pool, dr, c->stream)); }
+        }
+    }
+    // who is not finished?  (the pool ran dry under them: a batch of very compressible streams on little memory)
+    HIP_TRY(launch_deflate2_failed(a.dev<D2Stream>(sslot), (uint32_t)nfull, d_failed, c->stream));
+    std::vector<uint32_t> failed(nfull + 1, 0);
+    HIP_TRY(hipMemcpyAsync(failed.data(), d_failed, (nfull + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (failed[0]) {
+        std::vector<DeflateJob> again;
+        for (size_t i = 0; i < nfull; ++i) if (failed[1 + i]) again.push_back(sorted[first + i]);
+        std::vector<DeflateJob> rest;
+        for (size_t i = 0; i < nfull; ++i) if (!failed[1 + i]) rest.push_back(sorted[first + i]);
+        std::copy(again.begin(), again.end(), sorted.begin() + first);
+        std::copy(rest.begin(), rest.end(), sorted.begin() + first + again.size());
+        return deflate_full_legacy(c, sorted, first, first + again.size(), dr, a, jslot);
+    }
+    return SPNG_DONE;
+}
+
+// shared by spng_deflate_batch / spng_encode_batch.  Per-stream link rings of the greedy / lazy kernel live in a context-owned slab.
+static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_result *dr, Arena &a, size_t jslot,
+                              size_t gzparts = (size_t)-1)
+{
+    // greedy / lazy streams first, then the full-search ones: two contiguous job tables
+    std::vector<DeflateJob> sorted;
+    sorted.reserve(jobs.size());
+    for (auto &j : jobs) if (j.level < 8) sorted.push_back(j);
+    const size_t nfast = sorted.size();
+    for (auto &j : jobs) if (j.level >= 8) sorted.push_back(j);
+    const bool legacy = c->cfg[SPNG_CFG_DEFLATE_MODE] == SPNG_DEFLATE_ONE_KERNEL;
+    const size_t nring = nfast;
+    const size_t ring_bytes = nring * 65536 * 4;
+    if (ring_bytes > c->ring_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_ring) HIP_TRY(hipFree(c->d_ring));
+        c->d_ring = nullptr; c->ring_cap = 0;
+        HIP_TRY(hipMalloc(&c->d_ring, ring_bytes));
+        c->ring_cap = ring_bytes;
+    }
+    for (size_t i = 0; i < nring; ++i) sorted[i].ring = (uint32_t *)c->d_ring + i * 65536;
+    memcpy(a.host<DeflateJob>(jslot), sorted.data(), sorted.size() * sizeof(DeflateJob));
+    if (int32_t st = c->upload(jslot, jslot + sorted.size() * sizeof(DeflateJob))) return st;
     {
         Timed t(c, SPNG_K_DEFLATE);
         if (nfast) HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)nfast, dr, c->stream));
-        for (auto &gr : groups)
-            HIP_TRY(launch_deflate_full(a.dev<DeflateJob>(jslot) + gr.first, (uint32_t)(gr.last - gr.first), gr.helpers, dr, c->stream));
+        if (legacy) { if (int32_t st = deflate_full_legacy(c, sorted, nfast, sorted.size(), dr, a, jslot)) return st; }
+        else if (int32_t st = deflate_full_rounds(c, sorted, nfast, sorted.size(), dr, a, jslot)) return st;
     }
     // gzip members: CRC-32 and byte count of the input behind the stream (DeflatorBuffers.swift:96-135)
     if (gzparts != (size_t)-1)
@@ -1514,7 +1679,7 @@ int32_t spng_deflate_batch(spng_ctx *c, const spng_stream_desc *descs, const int
                              descs[i].dst_cap, nullptr, descs[i].format, levels[i], i,
                              descs[i].format == SPNG_FORMAT_IOS ? 15u : (uint32_t)e, nullptr, 0, 0};
     }
-    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + 8 + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 4096)) return st;
+    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + sizeof(D2Stream) + sizeof(D2State) + 16 + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 8192)) return st;
     Arena a{c};
     const size_t jslot = a.take(count * sizeof(DeflateJob));
     const size_t res = a.take(count * sizeof(spng_result));

@@ -157,6 +157,30 @@ struct DeflateJob {
     uint32_t       graph_vertices, pad;
 };
 
+// levels >= 8, the two-kernel form (deflate.hip, "round 4"): what the search and the parse kernel share per stream.
+struct D2State {                  // device side, kept from round to round; arrives zeroed except rb / re / limit / generic
+    uint64_t rb, re;              // the positions of the current round
+    uint64_t pos;                 // first position not parsed yet
+    uint32_t limit, generic;      // block limit of the next block; the first block of a stream iterates twice as often
+    uint64_t acc, total;          // the bit writer: pending bits, bytes produced
+    uint32_t nacc, overflow;
+    uint32_t adlerS, adlerI;      // Adler-32 partial sums of the chunks searched so far (mod 65521 each time)
+    uint32_t fail, done;          // the pool ran dry under this stream (the one-kernel search takes it afterwards); finished
+    uint8_t  depths[544];         // LZ77.DeflatorMatches.Depths between blocks
+};
+struct D2Stream {
+    const uint8_t *src; uint8_t *dst;
+    uint64_t src_len, dst_cap;
+    int32_t  format, level;
+    uint32_t image, exponent;
+    D2State *state;
+    // scratch, round coordinates (vertex = position - rb): per vertex candidates << 9 | longest run; per batch of 64 the first
+    // word of its list in the pool and words | longest run << 16; block coordinates: which vertices keep their edges, the
+    // ways in, the path
+    uint16_t *vinfo; uint64_t *bbase; uint32_t *bwords; uint64_t *emask;
+    uint32_t *up, *step; uint8_t *pathb;
+};
+
 // PNG.adam7, PNG.Decoder.swift:6-15
 struct Pass { uint32_t bx, by, sx, sy, w, h; uint64_t pitch; };
 int passes(uint32_t w, uint32_t h, int volume, int interlaced, Pass out[7]);
@@ -193,6 +217,12 @@ hipError_t launch_gzip_deflate_post(const DeflateJob *d_jobs, spng_result *d_res
 hipError_t launch_resume_post(const InflateJob *d_jobs, spng_result *d_results, uint64_t *d_parts, uint32_t count, hipStream_t stream);
 hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, bool helpers, spng_result *d_results, hipStream_t stream);
 hipError_t launch_deflate_density(const DeflateJob *d_jobs, uint32_t count, uint32_t *d_dense, hipStream_t stream);
+uint32_t deflate2_rounds(uint64_t n);
+uint64_t deflate2_vertices(uint64_t n);
+hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t *d_pool, unsigned long long *d_pool_next,
+                                  uint64_t pool_words, uint32_t *d_rings, hipStream_t stream);
+hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, hipStream_t stream);
+hipError_t launch_deflate2_failed(const D2Stream *d_streams, uint32_t count, uint32_t *d_failed, hipStream_t stream);
 uint64_t deflate_graph_vertices(uint64_t n);
 uint64_t deflate_graph_bytes(uint64_t vertices);
 hipError_t launch_unpack(const UnpackJob *d_jobs, uint32_t count, uint32_t blocks_x, int target, hipStream_t stream);

@@ -71,21 +71,10 @@ __device__ __forceinline__ uint32_t dist_decade(uint32_t d)
     return 2 * e + 2 + ((x >> e) & 1);
 }
 
-struct DLds {
-    uint32_t head[(1 << HBITS) + 1];             // most recent position per bucket (low 32 bits); + a slot nobody reads
-    union {
-        uint32_t terms[2048];                    // greedy / lazy: the queued terms
-        uint32_t cslot[2][30 * 64];              // full: per lane and half, the best run of every distance decade (distance << 16 | run)
-    };
+struct DLds {                                    // what every kernel of this file needs
     // full search (levels >= 8), forward pass: the best way into each of the next vertices found so far, as
-    // one 64-bit key (depth << 32 | writer order: see full_forward), and the edge slots of the 64 vertices at hand
+    // one 64-bit key (depth << 32 | writer order: see full_forward)
     uint64_t win[512];
-    uint32_t batch[64 * 30];
-    // the full kernel's helper waves (forward pass): what wave 0 hands them per pass and per batch of 64 vertices
-    // (per-batch words twice: a helper may still be reading one batch's while wave 0 sets up the next)
-    uint64_t fw_bbase, fw_ems[2][16];            // which vertices of the next sixteen batches have edges
-    uint32_t fw_cmd, fw_count, fw_carry[2];
-    uint32_t fw_cin[2][64];
     uint8_t  depths[544];                        // LZ77.DeflatorMatches.Depths: cost of every symbol in quarter bits
     uint32_t freq[320];                          // 0..287 lit/len, 288..319 distance
     union { uint8_t out[OUTB]; uint32_t out32[OUTB / 4]; };   // output staging ring; bytes not written yet are zero
@@ -99,9 +88,26 @@ struct DLds {
     uint8_t  msym[320], mbits[320];              // code-length RLE terms
     uint8_t  cl[20];                             // code-length-code lengths in transmission order
 };
+struct DLdsSearch {                              // the match search: greedy / lazy kernel, one-wave full kernel
+    uint32_t head[(1 << HBITS) + 1];             // most recent position per bucket (low 32 bits); + a slot nobody reads
+    union {
+        uint32_t terms[2048];                    // greedy / lazy: the queued terms
+        uint32_t cslot[2][30 * 64];              // full: per lane and half, the best run of every distance decade (distance << 16 | run)
+    };
+};
+struct DLdsOld {                                 // the one-kernel full search (deflate_full_kernel)
+    uint32_t batch[64 * 30];                     // the edge slots of the 64 vertices at hand
+    // the full kernel's helper waves (forward pass): what wave 0 hands them per pass and per batch of 64 vertices
+    // (per-batch words twice: a helper may still be reading one batch's while wave 0 sets up the next)
+    uint64_t fw_bbase, fw_ems[2][16];            // which vertices of the next sixteen batches have edges
+    uint32_t fw_cmd, fw_count, fw_carry[2];
+    uint32_t fw_cin[2][64];
+};
 // One instance per workgroup, at namespace scope so that the (non-inlined) block writer reaches it
 // with LDS instructions instead of through a generic pointer.
 __shared__ __attribute__((aligned(16))) DLds g_lds;
+__shared__ __attribute__((aligned(16))) DLdsSearch g_sea;
+__shared__ __attribute__((aligned(16))) DLdsOld g_old;
 
 struct Bits {                                    // LSB-first bit writer (LZ77.DeflatorOut.append)
     uint64_t acc; uint32_t nacc;
@@ -428,7 +434,7 @@ __device__ __attribute__((noinline)) Bits write_block(Bits b, int count, bool fi
     for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     for (int i = lane; i < count; i += 64) {
-        const uint32_t t = s.terms[i];
+        const uint32_t t = g_sea.terms[i];
         atomicAdd(&s.freq[t & 0x1ff], 1u);
         atomicAdd(&s.freq[288 + (t >> 27)], 1u);
     }
@@ -443,7 +449,7 @@ __device__ __attribute__((noinline)) Bits write_block(Bits b, int count, bool fi
         const int i = i0 + lane;
         uint64_t v = 0; uint32_t nb = 0;
         if (i < count) {
-            const uint32_t t = s.terms[i];
+            const uint32_t t = g_sea.terms[i];
             const uint32_t sym = t & 0x1ff;
             if (sym > 256) v = match_bits(s, sym & 0xff, (t >> 9) & 0x1f, t >> 27, (t >> 14) & 0x1fff, nb);
             else v = literal_bits(s, sym, nb);
@@ -532,12 +538,12 @@ __device__ __forceinline__ uint32_t load_key(const gbyte *in, uint64_t n, uint64
 // lane hashes its 4-byte key; a position's link is the distance to the previous position of its bucket --
 // the nearest lower lane with the same bucket (radix match over the hash bits: one ballot per bit), else
 // the bucket head -- and the last lane of every bucket becomes the new head.  Adler-32 sums ride along.
-__device__ __forceinline__ void insert_batch(DLds &s, const gbyte *in, uint64_t n, gword *ring, uint64_t inserted, uint32_t key,
-                                             uint32_t &accS, uint32_t &accI, int lane)
+__device__ __forceinline__ void insert_batch(uint32_t *head, const gbyte *in, uint64_t n, gword *ring, uint64_t inserted, uint32_t key,
+                                             uint32_t &accS, uint32_t &accI, int lane, bool sum = true)
 {
     const uint64_t p = inserted + lane;
     const bool live = p + 4 <= n;                              // the last three positions never start a match
-    if (p < n) {                                               // Adler-32 accumulators
+    if (p < n && sum) {                                        // Adler-32 accumulators
         const uint32_t byte = key & 0xff;
         accS += byte;
         accI = (accI + (uint32_t)(p % 65521) * byte) % 65521;
@@ -553,7 +559,7 @@ __device__ __forceinline__ void insert_batch(DLds &s, const gbyte *in, uint64_t 
     }
     const unsigned long long lower = (1ull << lane) - 1;
     const unsigned long long below = same & lower, above = same & ~lower & ~(1ull << lane);
-    uint32_t prev = live ? s.head[h] : NONE;
+    uint32_t prev = live ? head[h] : NONE;
     if (below) prev = (uint32_t)(inserted + (63 - __clzll((long long)below)));
     uint32_t dist = 0;
     if (live && prev != NONE) {
@@ -561,7 +567,7 @@ __device__ __forceinline__ void insert_batch(DLds &s, const gbyte *in, uint64_t 
         dist = d <= 32767 ? (uint32_t)d : 0;
     }
     if (p < n) ring[p & 65535] = dist | tag << 16;
-    s.head[live && !above ? h : 1u << HBITS] = (uint32_t)p;    // (idle lanes: the spare slot)
+    head[live && !above ? h : 1u << HBITS] = (uint32_t)p;      // (idle lanes: the spare slot)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 }
 
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         // the trailer (CRC-32, byte count) is appended by gzip.hip
         put(s, b, 0x8b1f, 16, lane); put(s, b, 0x0008, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0xff00, 16, lane);
     }
-    for (int i = lane; i <= (1 << HBITS); i += 64) s.head[i] = NONE;
+    for (int i = lane; i <= (1 << HBITS); i += 64) g_sea.head[i] = NONE;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 
     DPROF_DECL
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
             while (inserted < target && inserted < n) {
                 const uint32_t key = key_next;
                 key_next = load_key(in, n, inserted + 64 + lane);
-                insert_batch(s, in, n, ring, inserted, key, accS, accI, lane);
+                insert_batch(g_sea.head, in, n, ring, inserted, key, accS, accI, lane);
                 inserted = uni64(inserted + 64);
             }
         };
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                 if (!(unfilled() > (lazy ? 1 : 0))) { DPROF_END(2); DPROF_BEGIN(); b = write_block(b, count, false, lane); count = 0; DPROF_END(3); DPROF_BEGIN(); }
                 const uint32_t run = at(mrunA, mrunB, t);
                 const uint32_t lit = at(litA, litB, t);
-                if (!run) { s.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
+                if (!run) { g_sea.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
                 uint32_t use_run = run, use_dist = at(bdA, bdB, t);
                 uint32_t adv = run;
                 if (lazy) {
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                     // lazy match at a+1 (:293-299); it exists only if that position is still searched
                     const uint32_t lrun = (w + t + 1 < last_main) ? at(mrunA, mrunB, t + 1) : 0u;
                     if (lrun > run) {
-                        s.terms[count] = 0xf8000000u | lit;
+                        g_sea.terms[count] = 0xf8000000u | lit;
                         ++count;
                         use_run = lrun; use_dist = at(bdA, bdB, t + 1);
                         adv = 1 + lrun;
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                 }
                 // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
                 const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
-                s.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
+                g_sea.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
                 ++count;
                 t += adv;
             }
@@ -705,7 +711,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
         for (uint64_t p = w; p < n; ++p) {
             if (!(unfilled() > 0)) { b = write_block(b, count, false, lane); count = 0; }
-            s.terms[count] = 0xf8000000u | UNI(in[p]);
+            g_sea.terms[count] = 0xf8000000u | UNI(in[p]);
             ++count;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -866,7 +872,7 @@ __device__ __attribute__((noinline)) void forward_body(const FullArrays g, const
             for (int q = 0; q < 16; ++q) {
                 const uint32_t vq = sb0 + 64u * q + (uint32_t)lane;
                 const unsigned long long e = __ballot(vq < count && g.flag_()[vq] != 0);
-                if (lane == 0) s.fw_ems[spar][q] = e;
+                if (lane == 0) g_old.fw_ems[spar][q] = e;
             }
         }
         if (WAVES > 1) __syncthreads();
@@ -882,7 +888,7 @@ __device__ __attribute__((noinline)) void forward_body(const FullArrays g, const
             const uint32_t vn = b0 + 64 + (uint32_t)lane;
             fl_next = vn < count ? g.flag_()[vn] : 0u;
         } else {
-            em = uni64(s.fw_ems[spar][(b0 - sb0) >> 6]);
+            em = uni64(g_old.fw_ems[spar][(b0 - sb0) >> 6]);
             if (!em) continue;                                 // (wave 0 scans through it alone)
         }
         uint32_t cin = 0;
@@ -897,17 +903,17 @@ __device__ __attribute__((noinline)) void forward_body(const FullArrays g, const
             inited = inited > need ? inited : need;
             if (em) {
                 const uint32_t ns = count - b0 < 64 ? count - b0 : 64;
-                for (uint32_t i = lane; i < ns * 30; i += 64) s.batch[i] = g.slots_()[(uint64_t)b0 * 30 + i];
+                for (uint32_t i = lane; i < ns * 30; i += 64) g_old.batch[i] = g.slots_()[(uint64_t)b0 * 30 + i];
             }
             cin = (v >= 1 && v <= count) ? s.depths[lb] : 0u;   // the literal edge INTO v
             if (WAVES > 1 && em) {
-                s.fw_cin[par][lane] = cin;
-                if (lane == 0) s.fw_carry[par] = carry;
+                g_old.fw_cin[par][lane] = cin;
+                if (lane == 0) g_old.fw_carry[par] = carry;
             }
         }
         if (WAVES > 1 && em) {
             __syncthreads();                                   // the batch is set up
-            if (wave != 0) { cin = s.fw_cin[par][lane]; carry = UNI(s.fw_carry[par]); }
+            if (wave != 0) { cin = g_old.fw_cin[par][lane]; carry = UNI(g_old.fw_carry[par]); }
         } else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         uint64_t W; uint32_t Wd, D;
         uint32_t k = 0;
@@ -923,7 +929,7 @@ __device__ __attribute__((noinline)) void forward_body(const FullArrays g, const
                 if (!((WAVES == 1 || wave < 3) && kq < 64 && ((em >> kq) & 1) && count - (b0 + kq) >= 3)) continue;
                 const uint32_t vv = b0 + kq, rem = count - vv;
                 const uint32_t Dk = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kq);
-                const uint32_t run = lane < 30 ? s.batch[kq * 30 + lane] & 0xffffu : 0u;
+                const uint32_t run = lane < 30 ? g_old.batch[kq * 30 + lane] & 0xffffu : 0u;
                 unsigned long long m = __ballot(run > 0);
                 // Of the decades that reach a length, only the cheapest (first among equals: the lowest) can be
                 // the way into that target from this vertex: one key per length instead of one per decade.
@@ -974,7 +980,7 @@ __device__ __attribute__((noinline)) void full_forward(const FullArrays g, const
     DLds &s = g_lds;
     if (WAVES > 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the vertices' flags and slots are in memory
-        if (lane == 0) { s.fw_cmd = FW_PASS; s.fw_bbase = bbase; s.fw_count = count; }
+        if (lane == 0) { g_old.fw_cmd = FW_PASS; g_old.fw_bbase = bbase; g_old.fw_count = count; }
         __syncthreads();
     }
     forward_body<WAVES>(g, in, bbase, count, lane, 0);
@@ -1130,8 +1136,8 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
         const gbyte *inh = (const gbyte *)uni64((uint64_t)jp->src);
         for (;;) {
             __syncthreads();
-            if (UNI(s.fw_cmd) != FW_PASS) return;
-            forward_body<WAVES>(gh, inh, uni64(s.fw_bbase), UNI(s.fw_count), lane, wave);
+            if (UNI(g_old.fw_cmd) != FW_PASS) return;
+            forward_body<WAVES>(gh, inh, uni64(g_old.fw_bbase), UNI(g_old.fw_count), lane, wave);
             __syncthreads();
         }
     }
@@ -1168,7 +1174,7 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
         // the trailer (CRC-32, byte count) is appended by gzip.hip
         put(s, b, 0x8b1f, 16, lane); put(s, b, 0x0008, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0xff00, 16, lane);
     }
-    for (int i = lane; i <= (1 << HBITS); i += 64) s.head[i] = NONE;
+    for (int i = lane; i <= (1 << HBITS); i += 64) g_sea.head[i] = NONE;
     for (uint32_t i = lane; i < 542; i += 64) s.depths[i] = (uint8_t)depth_default(i);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 
@@ -1198,7 +1204,7 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
             while (inserted < target && inserted < n) {
                 const uint32_t key = key_next;
                 key_next = load_key(in, n, inserted + 64 + lane);
-                insert_batch(s, in, n, ring, inserted, key, accS, accI, lane);
+                insert_batch(g_sea.head, in, n, ring, inserted, key, accS, accI, lane);
                 inserted = uni64(inserted + 64);
             }
         };
@@ -1212,13 +1218,13 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
             const bool liveA = pA < last_main, liveB = pB < last_main;
             const uint32_t keyA = liveA ? load32(in + pA) : 0u, keyB = liveB ? load32(in + pB) : 0u;
 #pragma unroll
-            for (int d = 0; d < 30; ++d) { s.cslot[0][d * 64 + lane] = 0; s.cslot[1][d * 64 + lane] = 0; }
+            for (int d = 0; d < 30; ++d) { g_sea.cslot[0][d * 64 + lane] = 0; g_sea.cslot[1][d * 64 + lane] = 0; }
             uint32_t extA = 1, extB = 1;
             chain_walk2(in, ring, n, pA, pB, liveA, liveB, keyA, keyB, wmask, attempts, goal,
                         [&](int which, uint32_t dist, uint32_t run) {
                             uint32_t &ext = which ? extB : extA;
                             ext = run > ext ? run : ext;
-                            uint32_t *slot = &s.cslot[which][dist_decade(dist) * 64 + lane];
+                            uint32_t *slot = &g_sea.cslot[which][dist_decade(dist) * 64 + lane];
                             if (run > (*slot & 0xffff)) *slot = dist << 16 | run;
                         });
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1235,7 +1241,7 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
                     const bool has = extent > 1;               // (a candidate matched: at least the four key bytes)
                     g.flag_()[count + lane] = has ? 1 : 0;
                     if (__ballot(has))
-                        for (uint32_t i = lane; i < 64 * 30; i += 64) { const uint32_t vtx = i / 30, d = i - vtx * 30; g.slots_()[(uint64_t)count * 30 + i] = s.cslot[hf][d * 64 + vtx]; }
+                        for (uint32_t i = lane; i < 64 * 30; i += 64) { const uint32_t vtx = i / 30, d = i - vtx * 30; g.slots_()[(uint64_t)count * 30 + i] = g_sea.cslot[hf][d * 64 + vtx]; }
                     count += 64;
                     t += 64;
                     continue;
@@ -1243,7 +1249,7 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
                 if (!(unfilled() > 0)) close_block(false);
                 if (count == 0) bbase = w + t;
                 const int ext = __builtin_amdgcn_readlane((int)extent, (int)tl);
-                if (ext > 1) { if (lane < 30) g.slots_()[(uint64_t)count * 30 + lane] = s.cslot[hf][lane * 64 + tl]; }
+                if (ext > 1) { if (lane < 30) g.slots_()[(uint64_t)count * 30 + lane] = g_sea.cslot[hf][lane * 64 + tl]; }
                 if (lane == 0) g.flag_()[count] = ext > 1 ? 1 : 0;
                 count += 1;
                 int skip = ext - 100 < unfilled() ? ext - 100 : unfilled();
@@ -1281,7 +1287,7 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
     if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
     drain(s, b, b.total, lane);
     if (WAVES > 1) {
-        if (lane == 0) s.fw_cmd = FW_EXIT;                     // the helper waves leave
+        if (lane == 0) g_old.fw_cmd = FW_EXIT;                     // the helper waves leave
         __syncthreads();
     }
 #ifdef SPNG_DEFLATE_PROF
@@ -1294,6 +1300,649 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
         res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_DONE; res.reserved = 0;
         res.written = b.total; res.consumed = n; res.aux[0] = res.aux[1] = 0;
     }
+}
+
+// =====================================================================================================================
+// levels >= 8, round 4: the search and the parse in kernels of their own
+// =====================================================================================================================
+// deflate_full_kernel above keeps a stream on ONE wave: insertion, chain walks, the shortest path, the trees and the bits, one
+// after the other -- a quarter of the chip's SIMDs with a single, latency-bound wave each, and a per-stream graph scratch (130
+// bytes per vertex) that lets ~370 streams of 64 MiB in at a time.  But the candidates of a position are a pure function of the
+// input (the design note at the top of this file), and the block boundaries of the full search are fixed vertex counts
+// (2047, 4095, ... 2^21 - 1: LZ77.DeflatorMatches.swift:229): nothing about them has to wait for the parse.  So a batch now
+// goes through in ROUNDS of up to 2^21 vertices per stream (the small blocks of a stream's start together, then one block at
+// the cap per round), each round two launches:
+//   * dfl2_search_kernel -- every stream's round cut into chunks, a 4-wave workgroup per chunk: wave 0 inserts (the hash
+//     heads in LDS, the 64 K links of the workgroup's ring in HBM; 32 KiB of warm-up in front of the chunk), then joins the
+//     other three, which take 64 positions at a time behind it, walk the chains and leave, per position, the longest run
+//     seen and its candidates -- ONE packed word each (position-in-batch, distance, run), only for positions that have any:
+//     a batch of 64 positions takes what it needs from a pool shared by all streams.  Incompressible input leaves no words.
+//   * dfl2_parse_kernel -- one wave per stream, 38 KB of LDS (four per CU): the skip rule of runs > 100 (which vertices lose
+//     their edges: the only thing about the graph that IS sequential), then per block the forward passes, the back-trace,
+//     the trees and the bits as before, its state (bit writer, symbol costs, block limit) kept in HBM from round to round.
+//     Forward pass: what a vertex offers each target length -- the cheapest decade that reaches it -- does not depend on the
+//     vertex's depth, so it is tabulated for the 64 vertices of a batch at once (LDS atomic min per candidate word, one
+//     suffix-min sweep over the lengths, all lanes busy) and the dependent part per vertex shrinks to one row read, one add
+//     and one ds_min_u64 per lane.
+// The old kernel stays as the path for streams the pool could not serve (dfl2 marks them; api.hip runs them afterwards).
+static constexpr uint32_t D2_RV = 1u << 21;                     // vertices per stream and round
+static constexpr uint32_t D2_PCOLS = 64, D2_PSTRIDE = 65;       // offer table: lengths 3 .. 66, rows padded against bank conflicts
+__shared__ uint32_t g_ptab[64 * D2_PSTRIDE];                    // (parse kernel only)
+struct D2ALds {                                                 // (search kernel only)
+    uint32_t head[(1 << HBITS) + 1];
+    uint32_t cslot[4][30 * 64];                                 // per wave: per lane, the best run of every distance decade
+    uint64_t inserted;                                          // positions < inserted are in the window (published by wave 0)
+    uint32_t next;                                              // batches claimed
+};
+__shared__ __attribute__((aligned(16))) D2ALds g_a;
+
+__host__ __device__ inline uint64_t d2_round_end(uint64_t pos, uint32_t limit, uint64_t n)
+{
+    // the blocks of a round: as many whole blocks from `pos` on as fit D2_RV vertices (at least one)
+    uint64_t end = pos;
+    uint32_t lim = limit;
+    for (;;) {
+        const uint64_t room = n - end, size = (uint64_t)(lim - 1) < room ? (uint64_t)(lim - 1) : room;
+        if (end > pos && end - pos + size > D2_RV) break;
+        end += size;
+        if (end == n) break;
+        lim = 2 * lim < (1u << 21) ? 2 * lim : 1u << 21;
+    }
+    return end;
+}
+uint32_t deflate2_rounds(uint64_t n)
+{
+    if (n < 3) return 1;
+    uint32_t rounds = 0, lim = 2048;
+    for (uint64_t pos = 0; pos < n; ++rounds) {
+        const uint64_t end = d2_round_end(pos, lim, n);
+        for (uint64_t at = pos; at < end;) {                    // (the limit as the blocks of the round leave it)
+            const uint64_t size = (uint64_t)(lim - 1) < n - at ? (uint64_t)(lim - 1) : n - at;
+            at += size;
+            if (at < n) lim = 2 * lim < (1u << 21) ? 2 * lim : 1u << 21;
+        }
+        pos = end;
+    }
+    return rounds;
+}
+uint64_t deflate2_vertices(uint64_t n) { return ((n < D2_RV ? n : D2_RV) + 63) / 64 * 64 + 128; }
+
+// LZ77.DeflatorWindow.match (:132-212) for one position per lane (chain_walk2 without its second half: here the latency of a
+// hop is hidden by the other waves of the CU).  Links come from the workgroup's ring, which another wave writes: L1-bypassing loads.
+__device__ __forceinline__ uint32_t ring_load(const gword *ring, uint64_t at)
+{
+    return __hip_atomic_load((const uint32_t *)(ring + (at & 65535)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class F>
+__device__ __forceinline__ void chain_walk1(const gbyte *in, const gword *ring, uint64_t n, uint64_t p, bool live, uint32_t key, uint32_t wmask,
+                                            int attempts, int goal, F &&hit)
+{
+    uint32_t tag = 0, d = 0, acc = 0;
+    int rem = attempts;
+    bool first = true;
+    if (live) { const uint32_t m = ring_load(ring, p); tag = m >> 16; d = m & 0xffff; }
+    const uint32_t lim = n - p < 258 ? (uint32_t)(n - p) : 258u;
+    while (d) {
+        bool go = true;
+        acc += d;
+        if (acc > wmask || (!first && acc >= wmask)) go = false;
+        uint32_t e = 0, k = 0;
+        if (go) { e = ring_load(ring, p - acc); k = load32(in + p - acc); }
+        if (go && (e >> 16) == tag && k == key) {
+            const uint32_t run = common_prefix(in, p - acc, p, lim);
+            hit(acc, run);
+            first = false; rem -= 1;
+            if (!(rem > 0 && goal > (int)run)) go = false;
+        }
+        d = go ? e & 0xffff : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void dfl2_search_kernel(const D2Stream *__restrict__ streams, uint32_t cps, uint32_t chunk_len, uint32_t *__restrict__ pool,
+                                                          unsigned long long *__restrict__ pool_next, uint64_t pool_cap, uint32_t *__restrict__ rings)
+{
+    D2ALds &s = g_a;
+    const int lane = threadIdx.x & 63, wave = (int)UNI(threadIdx.x >> 6);
+    const D2Stream &st = streams[blockIdx.x / cps];
+    D2State *state = (D2State *)uni64((uint64_t)st.state);
+    if (UNI(state->done) || UNI(state->fail)) return;
+    const uint64_t n = uni64(st.src_len), rb = uni64(state->rb), re = uni64(state->re);
+    const uint64_t c0 = rb + (uint64_t)(blockIdx.x % cps) * chunk_len, c1 = c0 + chunk_len < re ? c0 + chunk_len : re;
+    if (c0 >= re || n < 3) return;
+    const gbyte *in = (const gbyte *)uni64((uint64_t)st.src);
+    gword *ring = (gword *)(rings + (uint64_t)blockIdx.x * 65536);
+    const int lv = (int)UNI(st.level) > 13 ? 13 : (int)UNI(st.level);
+    // DeflatorSearch.init(level:) (:13-35), full rows
+    const int attempts = lv == 8 ? 14 : lv == 9 ? 20 : lv == 10 ? 30 : lv == 11 ? 60 : lv == 12 ? 100 : 0x7fffffff;
+    const int goal = lv == 8 ? 20 : lv == 9 ? 32 : lv == 10 ? 50 : lv == 11 ? 80 : lv == 12 ? 133 : 258;
+    const uint32_t wmask = (1u << UNI(st.exponent)) - 1;
+    const uint64_t last_main = n - 4 + 1;                      // positions 0 .. n-4 are searched
+    const uint32_t nbatches = (uint32_t)((c1 - c0 + 63) / 64);
+
+    for (int i = threadIdx.x; i <= (1 << HBITS); i += 256) s.head[i] = NONE;
+    const uint64_t warm = (c0 >= 32768 ? c0 - 32768 : 0) & ~(uint64_t)63;
+    if (threadIdx.x == 0) { s.inserted = warm; s.next = 0; }
+    __syncthreads();
+
+    if (wave == 0) {
+        // ---- the inserter: everything from the warm-up on, never more than 16 K positions ahead of the batches claimed
+        uint32_t accS = 0, accI = 0;
+        uint64_t inserted = warm;
+        uint32_t key_next = load_key(in, n, inserted + lane);
+        uint32_t since = 0;
+        while (inserted < c1) {
+            uint32_t spins = 0;
+            while (inserted >= c0 + 64ull * __hip_atomic_load(&s.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 16384) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 28)) __builtin_trap();
+            }
+            const uint32_t key = key_next;
+            key_next = load_key(in, n, inserted + 64 + lane);
+            insert_batch(s.head, in, n, ring, inserted, key, accS, accI, lane, inserted + lane >= c0 && inserted + lane < c1);   // (sums: this chunk's bytes only)
+            inserted = uni64(inserted + 64);
+            if (++since == 4 || inserted >= c1) {
+                since = 0;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the links are in memory before anybody is told
+                if (lane == 0) __hip_atomic_store(&s.inserted, inserted, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        // Adler-32 sums of the chunk (MRC32.swift:26-50 in the closed form of inflate.hip), added to the stream's
+        uint32_t S = accS % 65521, I = accI % 65521;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { S += __shfl_xor(S, m, 64); I += __shfl_xor(I, m, 64); }
+        if (lane == 0) { atomicAdd(&state->adlerS, S % 65521); atomicAdd(&state->adlerI, I % 65521); }
+    }
+    // ---- the searchers: 64 positions at a time
+    uint32_t *cs = s.cslot[wave];
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s.next, 1u);
+        b = UNI(b);
+        if (b >= nbatches) break;
+        const uint64_t p0 = c0 + 64ull * b, upto = p0 + 64 < c1 ? p0 + 64 : c1;
+        {
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&s.inserted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < upto) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 28)) __builtin_trap();
+            }
+        }
+        const uint64_t p = p0 + lane;
+        const bool inchunk = p < c1, live = inchunk && p < last_main;
+        const uint32_t key = live ? load32(in + p) : 0u;
+#pragma unroll
+        for (int d = 0; d < 30; ++d) cs[d * 64 + lane] = 0;
+        uint32_t ext = 1, mask = 0;
+        chain_walk1(in, ring, n, p, live, key, wmask, attempts, goal, [&](uint32_t dist, uint32_t run) {
+            ext = run > ext ? run : ext;
+            const uint32_t dec = dist_decade(dist);
+            uint32_t *slot = &cs[dec * 64 + lane];
+            if (run > (*slot & 0xffff)) *slot = dist << 16 | run;   // (strict: the closest candidate of a decade stays, DeflatorMatches.set(edge:) :183-194)
+            mask |= 1u << dec;
+        });
+        // ---- the batch's record: per position candidates << 9 | longest run; the words where the pool has room
+        const uint32_t cnt = (uint32_t)__popc(mask);
+        uint32_t T;
+        const uint32_t pre = wave_excl_scan(cnt, T, lane);
+        uint32_t mr = ext;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mr, m, 64); mr = o > mr ? o : mr; }
+        unsigned long long base = 0;
+        if (T && lane == 0) base = atomicAdd(pool_next, (unsigned long long)T);
+        base = uni64(base);
+        const bool ok = base + T <= pool_cap;
+        if (!ok && lane == 0) atomicOr(&state->fail, 1u);
+        const uint64_t v = p - rb;
+        if (inchunk) st.vinfo[v] = (uint16_t)(cnt << 9 | ext);
+        if (lane == 0) { st.bbase[v >> 6] = base; st.bwords[v >> 6] = T | mr << 16; }
+        if (ok) {
+            uint32_t k = 0;
+            for (uint32_t m = mask; m; m &= m - 1, ++k) {
+                const uint32_t sl = cs[(uint32_t)(__ffs((int)m) - 1) * 64 + lane];
+                pool[base + pre + k] = (uint32_t)lane << 24 | (sl >> 16) << 9 | (sl & 0x1ff);
+            }
+        }
+    }
+}
+
+// ---- the parse kernel -------------------------------------------------------------------------------------------
+struct D2Arrays {                                               // (pointers of one stream, wave-uniform)
+    const uint16_t *vinfo; const uint64_t *bbase; const uint32_t *bwords; uint64_t *emask;
+    gword *up, *step; gbyte *pathb;
+    const uint32_t *pool;
+};
+
+// Which vertices of the block keep their edges (Stream.compress full, DeflatorBuffers.Stream.swift:344-400): behind a
+// SEARCHED vertex whose longest run exceeds 100 the next run - 100 vertices -- not beyond the block's capacity -- are not
+// searched.  One 64-bit mask per batch of the block (block coordinates).
+__device__ __attribute__((noinline)) void d2_skip_rule(const D2Arrays g, uint64_t vr0, uint32_t count, uint32_t cap, int lane)
+{
+    uint32_t skip_until = 0;
+    for (uint32_t b0 = 0; b0 < count; b0 += 64) {
+        const uint32_t v = b0 + (uint32_t)lane;
+        const uint32_t info = v < count ? g.vinfo[vr0 + v] : 1u;
+        const uint32_t ext = info & 0x1ff;
+        unsigned long long em = __ballot((info >> 9) != 0), xm = __ballot(ext > 100);
+        if (xm || skip_until > b0) {
+            uint32_t cur = b0;
+            for (;;) {
+                if (skip_until > cur) {
+                    const uint32_t hi = skip_until < b0 + 64 ? skip_until : b0 + 64;
+                    const unsigned long long clear = (hi - b0 >= 64 ? ~0ull : (1ull << (hi - b0)) - 1) & ~((1ull << (cur - b0)) - 1);
+                    em &= ~clear; xm &= ~clear;
+                    cur = hi;
+                    if (cur >= b0 + 64) break;
+                }
+                const unsigned long long m = xm & ~((1ull << (cur - b0)) - 1);
+                if (!m) break;
+                const uint32_t x = (uint32_t)__ffsll((long long)m) - 1, vx = b0 + x;
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ext, (int)x);
+                const uint32_t room = cap - (vx + 1);                   // unfilled() once vx itself is in the block
+                const uint32_t skip = e - 100 < room ? e - 100 : room;
+                skip_until = vx + 1 + skip;
+                xm &= ~(1ull << x);
+                cur = vx + 1;
+                if (cur >= b0 + 64) break;
+            }
+        }
+        if (lane == 0) g.emask[b0 >> 6] = em;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// The offer table of a batch: g_ptab[vertex][L - 3] = cost << 20 | decade << 15 | distance of the cheapest decade (first among
+// equals: the lowest) whose run from that vertex reaches length L, for L = 3 .. 66; ~0: none.  `longm`: vertices with a run
+// beyond 66 (they take the per-entry path).  The words of the batch sit in the lists of one or two batches of the search kernel
+// (those are aligned in round coordinates, this batch in block coordinates).
+__device__ __forceinline__ unsigned long long d2_offers(const D2Arrays g, uint64_t vr, uint64_t rv, uint32_t b0, uint32_t count, unsigned long long em, uint32_t &cols,
+                                                          int lane)
+{
+    DLds &s = g_lds;
+    const uint32_t sh = (uint32_t)(vr & 63);
+    const uint64_t q0 = vr >> 6;
+    uint32_t T[2] = {0, 0}, maxr = 0;
+    uint64_t base[2] = {0, 0};
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        if ((qi && !sh) || ((q0 + qi) << 6) >= rv) break;           // (the second list: only a batch the round holds)
+        const uint32_t bw = UNI(g.bwords[q0 + qi]);
+        T[qi] = bw & 0xffff; base[qi] = uni64(g.bbase[q0 + qi]);
+        if (T[qi]) maxr = (bw >> 16) > maxr ? bw >> 16 : maxr;
+    }
+    cols = maxr >= 3 ? (maxr < 66 ? maxr : 66u) - 2 : 0u;             // lengths 3 .. min(maxr, 66)
+    for (uint32_t j = 0; j < cols; ++j) g_ptab[lane * D2_PSTRIDE + j] = ~0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    unsigned long long longm = 0;
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+        for (uint32_t i0 = 0; i0 < T[qi]; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const uint32_t w = i < T[qi] ? g.pool[base[qi] + i] : 0u;
+            const uint32_t vtx = w >> 24, run = w & 0x1ff, dist = (w >> 9) & 0x7fff;
+            const uint32_t ln = qi ? vtx + 64 - sh : vtx - sh;           // lane of the vertex in this batch (>= 64: not in it)
+            const bool mine = i < T[qi] && (qi ? vtx < sh : vtx >= sh) && ln < 64 && ((em >> ln) & 1);
+            const uint32_t rem = count - (b0 + ln);
+            const uint32_t r = run < rem ? run : rem;
+            const bool use = mine && b0 + ln < count && r >= 3;
+            if (use) {
+                const uint32_t dec = dist_decade(dist);
+                const uint32_t key = (uint32_t)s.depths[512 + dec] << 20 | dec << 15 | dist;
+                atomicMin(&g_ptab[ln * D2_PSTRIDE + (r < 66 ? r : 66u) - 3], key);
+            }
+            // vertices with a run beyond the table
+            unsigned long long lm = __ballot(use && r > 66);
+            while (lm) {
+                const int l = __ffsll((long long)lm) - 1;
+                lm &= lm - 1;
+                longm |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)ln, l);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    // suffix minimum over the lengths: what reaches L + 1 reaches L
+    uint32_t t = ~0u;
+    for (int j = (int)cols - 1; j >= 0; --j) {
+        const uint32_t x = g_ptab[lane * D2_PSTRIDE + j];
+        t = x < t ? x : t;
+        g_ptab[lane * D2_PSTRIDE + j] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    return longm;
+}
+
+// a vertex with a run beyond the table: the per-entry form of the one-kernel search (forward_body), lane = candidate word
+__device__ __forceinline__ void d2_relax_long(const D2Arrays g, uint64_t vr, uint32_t vv, uint32_t count, uint32_t Dk, const uint32_t (&rc)[4], int lane)
+{
+    DLds &s = g_lds;
+    const uint64_t q = vr >> 6;
+    const uint32_t vtx = (uint32_t)(vr & 63);
+    const uint32_t cntl = (uint32_t)g.vinfo[(q << 6) + lane] >> 9;
+    uint32_t tot;
+    const uint32_t prel = wave_excl_scan(cntl, tot, lane);
+    const uint32_t pre = (uint32_t)__builtin_amdgcn_readlane((int)prel, (int)vtx), cnt = (uint32_t)__builtin_amdgcn_readlane((int)cntl, (int)vtx);
+    const uint32_t w = (uint32_t)lane < cnt ? g.pool[uni64(g.bbase[q]) + pre + lane] : 0u;
+    const uint32_t rem = count - vv;
+    const uint32_t run = w & 0x1ff, dist = (w >> 9) & 0x7fff, dec = dist ? dist_decade(dist) : 0u;
+    const uint32_t r = run < rem ? run : rem;
+    const uint32_t dcost = s.depths[512 + dec];
+    unsigned long long m = __ballot((uint32_t)lane < cnt && r >= 3);
+    uint32_t bc[4] = {~0u, ~0u, ~0u, ~0u}, bd[4] = {0, 0, 0, 0}, reach = 0;
+    while (m) {
+        const int e = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const uint32_t maxlen = (uint32_t)__builtin_amdgcn_readlane((int)r, e);
+        const uint32_t dc = (uint32_t)__builtin_amdgcn_readlane((int)dcost, e);
+        const uint32_t dd = (uint32_t)__builtin_amdgcn_readlane((int)(dec << 15 | dist), e);
+        reach = maxlen > reach ? maxlen : reach;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (3u + 64u * j > maxlen) break;
+            const uint32_t L = 3u + (uint32_t)lane + 64u * j;
+            if (L <= maxlen && dc < bc[j]) { bc[j] = dc; bd[j] = dd; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (3u + 64u * j > reach) break;
+        const uint32_t L = 3u + (uint32_t)lane + 64u * j;
+        if (bc[j] != ~0u) {
+            const uint64_t key = (uint64_t)(Dk + bc[j] + rc[j]) << 32 | (258u - L) << 23 | (bd[j] + (1u << 15));
+            __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// minimize() forwards, as full_forward; keys: depth << 32 | (258 - length) << 23 | (decade + 1) << 15 | distance (the distance
+// rides along -- one per vertex and decade, it never decides -- so that the way in knows it without a look-up)
+__device__ __attribute__((noinline)) void d2_forward(const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint64_t rv, uint32_t count, int lane)
+{
+    DLds &s = g_lds;
+    uint32_t rc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const uint32_t L = 3u + (uint32_t)lane + 64u * j; rc[j] = L <= 258 ? s.depths[253 + L] : 0u; }
+    if (lane == 0) s.win[0] = 0;                               // vertex 0: depth 0
+    uint32_t inited = 1, carry = DINF;
+    uint32_t lb_next = (lane >= 1 && (uint32_t)lane <= count) ? in[bbase + lane - 1] : 0u;
+    unsigned long long em_next = count ? uni64(g.emask[0]) : 0ull;
+    for (uint32_t b0 = 0; b0 <= count; b0 += 64) {
+        const uint32_t nv = count + 1 - b0 < 64 ? count + 1 - b0 : 64;      // vertices b0 .. b0 + nv - 1 (the last one: `count`, the end)
+        const uint32_t v = b0 + (uint32_t)lane;
+        const unsigned long long em = em_next;
+        em_next = b0 + 64 < count ? uni64(g.emask[(b0 >> 6) + 1]) : 0ull;
+        const uint32_t lb = lb_next;
+        {
+            const uint32_t vn = b0 + 64 + (uint32_t)lane;
+            lb_next = vn <= count ? in[bbase + vn - 1] : 0u;
+        }
+        const uint32_t need = (b0 + 64 + 258 < count ? b0 + 64 + 258 : count) + 1;
+        for (uint32_t j = inited + lane; j < need; j += 64) s.win[j & 511] = ~0ull;
+        inited = inited > need ? inited : need;
+        const uint32_t cin = (v >= 1 && v <= count) ? s.depths[lb] : 0u;     // the literal edge INTO v
+        unsigned long long longm = 0;
+        uint32_t cols = 0;
+        if (em) longm = d2_offers(g, vr0 + b0, rv, b0, count, em, cols, lane);
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        uint64_t W; uint32_t Wd, D;
+        uint32_t k = 0;
+        for (;;) {
+            W = (uint32_t)lane < nv ? s.win[v & 511] : ~0ull;
+            Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
+            D = minplus_scan(cin, Wd, carry, lane);
+            const unsigned long long rest = k < 64 ? (em >> k) << k : 0ull;
+            if (!rest) break;
+            const uint32_t kk = (uint32_t)__ffsll((long long)rest) - 1;
+            // a match is at least 3 long: the depths of three consecutive vertices are final together
+            for (uint32_t kq = kk; kq < kk + 3; ++kq) {
+                if (!(kq < 64 && ((em >> kq) & 1) && count - (b0 + kq) >= 3)) continue;
+                const uint32_t vv = b0 + kq;
+                const uint32_t Dk = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kq);
+                if ((longm >> kq) & 1) { d2_relax_long(g, vr0 + vv, vv, count, Dk, rc, lane); continue; }
+                const uint32_t pk = (uint32_t)lane < cols ? g_ptab[kq * D2_PSTRIDE + lane] : ~0u;
+                if (pk != ~0u) {
+                    const uint32_t L = 3u + (uint32_t)lane;
+                    const uint64_t key = (uint64_t)(Dk + (pk >> 20) + rc[0]) << 32 | (258u - L) << 23 | ((pk & 0xfffffu) + (1u << 15));
+                    __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            k = kk + 3;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the group's keys are in the ring
+        }
+        // the way in: the literal only when strictly cheaper than what the matches offer.
+        // run << 16 | decade << 8 | distance (low byte; high bits from bit 25 up); literal: 1 << 16 | 0xff00
+        if ((uint32_t)lane < nv && v >= 1) {
+            const uint32_t low = (uint32_t)W, dist = low & 0x7fff;
+            g.up[v] = D < Wd ? 0x0001ff00u : (258u - (low >> 23)) << 16 | (((low >> 15) & 31u) - 1u) << 8 | (dist & 0xff) | (dist >> 8) << 25;
+        }
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)(nv - 1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// minimize() backwards (:282-320), as full_backward with the wider ways-in
+__device__ __attribute__((noinline)) void d2_backward(const D2Arrays g, const gbyte *in, uint64_t bbase, uint32_t count, int lane)
+{
+    DLds &s = g_lds;
+    for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    uint32_t hi = count;
+    uint32_t u_next = ((uint32_t)lane < hi) ? g.up[hi - (uint32_t)lane] : 0u, hi_next = hi;
+    for (;;) {
+        const bool valid = (uint32_t)lane <= hi;
+        const uint32_t c = valid ? hi - (uint32_t)lane : 0u;
+        uint32_t u = u_next;
+        if (hi_next != hi) u = (valid && c > 0) ? g.up[c] : 0u;
+        if (hi >= 64) { hi_next = hi - 64; u_next = ((uint32_t)lane < hi_next) ? g.up[hi_next - (uint32_t)lane] : 0u; }
+        const uint32_t len = (u >> 16) & 0x1ff;                // 0: vertex 0 (or nothing)
+        unsigned long long pm = 0;
+        uint32_t pos = 0;
+        if (!__ballot(valid && c > 0 && len != 1)) { pm = __ballot(valid); pos = 64; }
+        else {
+            while (pos < 64) {
+                pm |= 1ull << pos;
+                const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)pos);
+                if (!l) break;
+                pos += l;
+            }
+        }
+        const bool on = ((pm >> lane) & 1) != 0;
+        if (valid && c < count) g.pathb[c] = on ? 1 : 0;
+        if (on && c > 0) {
+            const uint32_t nxt = c - len;
+            g.step[nxt] = u;
+            if (len == 1) atomicAdd(&s.freq[in[bbase + nxt]], 1u);
+            else { atomicAdd(&s.freq[256 | run_decade(len)], 1u); atomicAdd(&s.freq[288 + ((u >> 8) & 0xff)], 1u); }
+        }
+        if (hi < 64 || pos > hi) break;                        // vertex 0 was in this batch
+        if (pos < 64) break;                                   // (cannot happen: a hop of length 0 above vertex 0)
+        const uint32_t nhi = hi - pos;
+        for (uint32_t cc = nhi + 1 + (uint32_t)lane; cc + 64 <= hi; cc += 64) g.pathb[cc] = 0;
+        hi = nhi;
+    }
+    if (lane == 0) s.freq[256] = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), full form, over the records of the search kernel
+__device__ __attribute__((noinline)) Bits d2_block(Bits b, const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint64_t rv, uint32_t count, uint32_t cap,
+                                                   bool final, int iterations, bool generic, int lane)
+{
+    DLds &s = g_lds;
+    d2_skip_rule(g, vr0, count, cap, lane);
+    for (int i = generic ? -iterations : 0;;) {
+        d2_forward(g, in, bbase, vr0, rv, count, lane);
+        d2_backward(g, in, bbase, count, lane);
+        build_tree(s.freq, 286, 15, s.ll, lane);
+        build_tree(s.freq + 288, 30, 15, s.dl, lane);
+        ++i;
+        if (!(i < iterations)) break;
+        full_depths_update(lane);
+    }
+    b = write_tables(b, final, lane);
+    // writeBlock(with:) (:661-707): the path's terms, 64 vertices at a time
+    uint32_t pb_next = (uint32_t)lane < count ? g.pathb[lane] : 0u, st_next = (uint32_t)lane < count ? g.step[lane] : 0u,
+             lt_next = (uint32_t)lane < count ? in[bbase + lane] : 0u;
+    for (uint32_t b0 = 0; b0 < count; b0 += 64) {
+        const uint32_t v = b0 + lane;
+        const bool on = v < count && pb_next != 0;
+        const uint32_t st = st_next, lt = lt_next;
+        {
+            const uint32_t vn = v + 64;
+            const bool inn = vn < count;
+            pb_next = inn ? g.pathb[vn] : 0u; st_next = inn ? g.step[vn] : 0u; lt_next = inn ? in[bbase + vn] : 0u;
+        }
+        uint64_t bits = 0; uint32_t nb = 0;
+        if (on) {
+            const uint32_t cnt = (st >> 16) & 0x1ff, dd = (st >> 8) & 0xff;
+            if (cnt == 1) bits = literal_bits(s, lt, nb);
+            else {
+                const uint32_t off = (st & 0xff) | (st >> 25) << 8, rd = run_decade(cnt);
+                bits = match_bits(s, rd, run_extra_value(cnt, rd), dd, dist_extra_value(off, dd), nb);
+            }
+        }
+        bulk_put(s, b, bits, nb, lane);
+        maybe_drain(s, b, lane);
+    }
+    put(s, b, s.lcode[256], s.ll[256], lane);
+    maybe_drain(s, b, lane);
+    // resetGraph -> Depths.generalize (Depths.swift:88-98)
+    for (uint32_t i = lane; i < 542; i += 64) {
+        const uint32_t x = s.depths[i], d = depth_default(i);
+        s.depths[i] = (uint8_t)((x & d) + ((x ^ d) >> 1));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    return b;
+}
+
+__global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restrict__ streams, const uint32_t *__restrict__ pool, spng_result *__restrict__ results)
+{
+    DLds &s = g_lds;
+    const D2Stream *sp = streams + blockIdx.x;
+    const int lane = threadIdx.x;
+    D2State *state = (D2State *)uni64((uint64_t)sp->state);
+    if (UNI(state->done) || UNI(state->fail)) return;
+    const gbyte *in = (const gbyte *)uni64((uint64_t)sp->src);
+    const uint64_t n = uni64(sp->src_len);
+    const int32_t format = (int32_t)UNI(sp->format);
+    D2Arrays g;
+    g.vinfo = (const uint16_t *)uni64((uint64_t)sp->vinfo); g.bbase = (const uint64_t *)uni64((uint64_t)sp->bbase);
+    g.bwords = (const uint32_t *)uni64((uint64_t)sp->bwords); g.emask = (uint64_t *)uni64((uint64_t)sp->emask);
+    g.up = (gword *)uni64((uint64_t)sp->up); g.step = (gword *)uni64((uint64_t)sp->step); g.pathb = (gbyte *)uni64((uint64_t)sp->pathb);
+    g.pool = pool;
+    const int lv = (int)UNI(sp->level) > 13 ? 13 : (int)UNI(sp->level);
+    const int iterations = lv - 7;
+
+    for (int i = lane; i < OUTB / 4; i += 64) s.out32[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    Bits b = {uni64(state->acc), UNI(state->nacc), uni64(state->total), uni64(state->total), (gbyte *)uni64((uint64_t)sp->dst), uni64(sp->dst_cap),
+              UNI(state->overflow) != 0};
+    uint64_t pos = uni64(state->pos);
+    uint32_t limit = UNI(state->limit);
+    bool generic = UNI(state->generic) != 0;
+    const uint64_t rb = uni64(state->rb), re = uni64(state->re);
+    if (pos == 0 && b.total == 0 && b.nacc == 0) {
+        // the stream's first round
+        if (format == SPNG_FORMAT_ZLIB) {
+            // StreamHeader.write (StreamHeader.swift:56-62)
+            const uint32_t unpaired = (UNI(sp->exponent) - 8) << 4 | 0x08;
+            const uint32_t check = ~(((unpaired << 8 | unpaired >> 8) & 0xffff) % 31) & 31;
+            put(s, b, check << 8 | unpaired, 16, lane);
+        } else if (format == SPNG_FORMAT_GZIP) {
+            // Gzip.StreamHeader.write (Gzip.StreamHeader.swift:84-96); the trailer is appended by gzip.hip
+            put(s, b, 0x8b1f, 16, lane); put(s, b, 0x0008, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0xff00, 16, lane);
+        }
+        for (uint32_t i = lane; i < 542; i += 64) s.depths[i] = (uint8_t)depth_default(i);
+    } else {
+        for (uint32_t i = lane; i < 542; i += 64) s.depths[i] = state->depths[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+
+    uint32_t tailS = 0, tailI = 0;
+    if (n < 3) {
+        // Stream.compressBlocks stored tail (:45-60, :417-434)
+        put(s, b, 1, 3, lane);
+        if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
+        put(s, b, (uint32_t)n, 16, lane); put(s, b, ~(uint32_t)n & 0xffff, 16, lane);
+        for (uint64_t k = 0; k < n; ++k) put(s, b, in[k], 8, lane);
+        if ((uint64_t)lane < n) { tailS = in[lane]; tailI = (uint32_t)lane * in[lane]; }
+        pos = n;
+    } else {
+        while (pos < re) {
+            const uint64_t room = n - pos;
+            const uint32_t count = (uint64_t)(limit - 1) < room ? limit - 1 : (uint32_t)room;
+            const bool final = pos + count == n;
+            b = d2_block(b, g, in, pos, pos - rb, re - rb, count, limit - 1, final, iterations, generic, lane);
+            generic = false;
+            pos += count;
+            if (!final) limit = 2 * limit < (1u << 21) ? 2 * limit : 1u << 21;     // trees(iterations:) :229
+        }
+    }
+    if (pos >= n) {
+        if (format == SPNG_FORMAT_ZLIB) {
+            // Adler-32 from the sums the search kernel left (s1 = 1 + S, s2 = N + N * S - I)
+            uint32_t S, I;
+            if (n < 3) {
+                S = tailS; I = tailI;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) { S += __shfl_xor(S, m, 64); I += __shfl_xor(I, m, 64); }
+            } else { S = UNI(state->adlerS); I = UNI(state->adlerI); }
+            S %= 65521; I %= 65521;
+            const uint32_t N = (uint32_t)(n % 65521);
+            const uint32_t sum = ((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
+            if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
+            put(s, b, sum >> 24, 8, lane); put(s, b, (sum >> 16) & 0xff, 8, lane);
+            put(s, b, (sum >> 8) & 0xff, 8, lane); put(s, b, sum & 0xff, 8, lane);
+        }
+        if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);            // DeflatorOut.pull flushes padding bits
+        drain(s, b, b.total, lane);
+        if (lane == 0) {
+            spng_result &res = results[UNI(sp->image)];
+            res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_DONE; res.reserved = 1;
+            res.written = b.total; res.consumed = n; res.aux[0] = res.aux[1] = 0;
+            state->done = 1;
+        }
+        return;
+    }
+    // the next round
+    drain(s, b, b.total, lane);
+    for (uint32_t i = lane; i < 542; i += 64) state->depths[i] = s.depths[i];
+    if (lane == 0) {
+        state->acc = b.acc; state->nacc = b.nacc; state->total = b.total; state->overflow = b.overflow ? 1u : 0u;
+        state->pos = pos; state->limit = limit; state->generic = generic ? 1u : 0u;
+        state->rb = pos; state->re = d2_round_end(pos, limit, n);
+    }
+}
+
+__global__ void dfl2_failed_kernel(const D2Stream *__restrict__ streams, uint32_t count, uint32_t *__restrict__ failed)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t f = streams[i].state->done ? 0u : 1u;       // (not finished: the pool ran dry under it)
+    failed[1 + i] = f;
+    if (f) atomicAdd(&failed[0], 1u);
+}
+hipError_t launch_deflate2_failed(const D2Stream *d_streams, uint32_t count, uint32_t *d_failed, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_failed, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    dfl2_failed_kernel<<<(count + 255) / 256, 256, 0, stream>>>(d_streams, count, d_failed);
+    return hipGetLastError();
+}
+
+hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t *d_pool, unsigned long long *d_pool_next,
+                                  uint64_t pool_words, uint32_t *d_rings, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_pool_next, 0, 8, stream);
+    if (e != hipSuccess) return e;
+    dfl2_search_kernel<<<count * cps, 256, 0, stream>>>(d_streams, cps, chunk_len, d_pool, d_pool_next, pool_words, d_rings);
+    return hipGetLastError();
+}
+hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    dfl2_parse_kernel<<<count, 64, 0, stream>>>(d_streams, d_pool, d_results);
+    return hipGetLastError();
 }
 
 // bytes of graph scratch a stream of n bytes needs at levels >= 8 (api.hip sizes the slab with it)
