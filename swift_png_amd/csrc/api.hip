@@ -1501,7 +1501,7 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
     auto scratch_of = [](uint64_t n) -> uint64_t {
         const uint64_t V = deflate2_vertices(n), B = V / 64 + 2;
         return ((2 * V + 255) & ~255ull) + ((8 * B + 255) & ~255ull) + ((4 * B + 255) & ~255ull) + ((8 * B + 255) & ~255ull) +
-               2 * ((4 * (V + 2) + 255) & ~255ull) + ((V + 2 + 255) & ~255ull);
+               2 * ((4 * (V + 2) + 255) & ~255ull) + ((V + 2 + 255) & ~255ull) + ((B + 255) & ~255ull);
     };
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -1572,7 +1572,7 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
             s.image = j.image; s.exponent = j.exponent;
             s.state = a.dev<D2State>(tslot) + (i - first);
             s.vinfo = (uint16_t *)take(2 * V); s.bbase = (uint64_t *)take(8 * B); s.bwords = (uint32_t *)take(4 * B); s.emask = (uint64_t *)take(8 * B);
-            s.up = (uint32_t *)take(4 * (V + 2)); s.step = (uint32_t *)take(4 * (V + 2)); s.pathb = (uint8_t *)take(V + 2);
+            s.up = (uint32_t *)take(4 * (V + 2)); s.step = (uint32_t *)take(4 * (V + 2)); s.pathb = (uint8_t *)take(V + 2); s.litb = (uint8_t *)take(B);
             D2State &t = ht[i - first];
             t.rb = 0; t.limit = 2048; t.generic = 1;
             t.re = j.src_len < 3 ? j.src_len : 0;

@@ -178,7 +178,7 @@ struct D2Stream {
     // word of its list in the pool and words | longest run << 16; block coordinates: which vertices keep their edges, the
     // ways in, the path
     uint16_t *vinfo; uint64_t *bbase; uint32_t *bwords; uint64_t *emask;
-    uint32_t *up, *step; uint8_t *pathb;
+    uint32_t *up, *step; uint8_t *pathb, *litb;   // (litb: per batch of the block, nothing but literal ways in)
 };
 
 // PNG.adam7, PNG.Decoder.swift:6-15

@@ -571,6 +571,41 @@ __device__ __forceinline__ void insert_batch(uint32_t *head, const gbyte *in, ui
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 }
 
+// The same with 16-bit heads (the search kernel's: half the LDS, three workgroups per CU): a head is its position mod 2^16.
+// A bucket nobody entered for 2^16 positions or more then reads as a small distance to a position that is not of this bucket.
+// So that a walk notices, the tag of a link is the TOP sixteen bits of the hash here -- the thirteen bucket bits and three
+// more: a link whose tag names another bucket is no link, the chain ends there (chain_walk1).  (A stale head that happens to
+// point into its own bucket -- one in 2^13 -- is a genuine earlier member of the chain: harmless.)  Heads start 2^15 behind the
+// first position.
+__device__ __forceinline__ void insert_batch16(uint16_t *head, const gbyte *in, uint64_t n, gword *ring, uint64_t inserted, uint32_t key,
+                                               uint32_t &accS, uint32_t &accI, int lane, bool sum)
+{
+    const uint64_t p = inserted + lane;
+    const bool live = p + 4 <= n;                              // the last three positions never start a match
+    if (p < n && sum) {                                        // Adler-32 accumulators
+        const uint32_t byte = key & 0xff;
+        accS += byte;
+        accI = (accI + (uint32_t)(p % 65521) * byte) % 65521;
+    }
+    const uint32_t mix = key * 0x9E3779B1u;
+    const uint32_t h = mix >> (32 - HBITS);
+    const uint32_t tag = mix >> 16;                            // (tag >> 3 == h)
+    unsigned long long same = __ballot(live);
+#pragma unroll
+    for (int k = 0; k < HBITS; ++k) {
+        const unsigned long long bk = __ballot((h >> k) & 1);
+        same &= (h >> k) & 1 ? bk : ~bk;
+    }
+    const unsigned long long lower = (1ull << lane) - 1;
+    const unsigned long long below = same & lower, above = same & ~lower & ~(1ull << lane);
+    uint32_t d = live ? ((uint32_t)p - (uint32_t)head[h]) & 0xffffu : 0u;
+    if (below) d = (uint32_t)lane - (uint32_t)(63 - __clzll((long long)below));
+    const uint32_t dist = d <= 32767 ? d : 0u;
+    if (p < n) ring[p & 65535] = dist | tag << 16;
+    head[live && !above ? h : 1u << HBITS] = (uint16_t)p;      // (idle lanes: the spare slot)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+}
+
 #ifdef SPNG_DEFLATE_PROF
 // full kernel: cycles per phase, kept in LDS so that the non-inlined passes can add to them
 __shared__ uint64_t g_prof[12];
@@ -1329,7 +1364,7 @@ static constexpr uint32_t D2_RV = 1u << 21;                     // vertices per 
 static constexpr uint32_t D2_PCOLS = 64, D2_PSTRIDE = 65;       // offer table: lengths 3 .. 66, rows padded against bank conflicts
 __shared__ uint32_t g_ptab[64 * D2_PSTRIDE];                    // (parse kernel only)
 struct D2ALds {                                                 // (search kernel only)
-    uint32_t head[(1 << HBITS) + 1];
+    uint16_t head[(1 << HBITS) + 2];                            // (16-bit: insert_batch16)
     uint32_t cslot[4][30 * 64];                                 // per wave: per lane, the best run of every distance decade
     uint64_t inserted;                                          // positions < inserted are in the window (published by wave 0)
     uint32_t next;                                              // batches claimed
@@ -1388,6 +1423,7 @@ __device__ __forceinline__ void chain_walk1(const gbyte *in, const gword *ring, 
         if (acc > wmask || (!first && acc >= wmask)) go = false;
         uint32_t e = 0, k = 0;
         if (go) { e = ring_load(ring, p - acc); k = load32(in + p - acc); }
+        if (go && (e >> 19) != (tag >> 3)) go = false;          // (not of this bucket: a stale head led here, insert_batch16)
         if (go && (e >> 16) == tag && k == key) {
             const uint32_t run = common_prefix(in, p - acc, p, lim);
             hit(acc, run);
@@ -1419,8 +1455,8 @@ __global__ __launch_bounds__(256) void dfl2_search_kernel(const D2Stream *__rest
     const uint64_t last_main = n - 4 + 1;                      // positions 0 .. n-4 are searched
     const uint32_t nbatches = (uint32_t)((c1 - c0 + 63) / 64);
 
-    for (int i = threadIdx.x; i <= (1 << HBITS); i += 256) s.head[i] = NONE;
     const uint64_t warm = (c0 >= 32768 ? c0 - 32768 : 0) & ~(uint64_t)63;
+    for (int i = threadIdx.x; i <= (1 << HBITS); i += 256) s.head[i] = (uint16_t)(warm - 32768);     // (2^15 behind the first position: no link)
     if (threadIdx.x == 0) { s.inserted = warm; s.next = 0; }
     __syncthreads();
 
@@ -1438,7 +1474,7 @@ __global__ __launch_bounds__(256) void dfl2_search_kernel(const D2Stream *__rest
             }
             const uint32_t key = key_next;
             key_next = load_key(in, n, inserted + 64 + lane);
-            insert_batch(s.head, in, n, ring, inserted, key, accS, accI, lane, inserted + lane >= c0 && inserted + lane < c1);   // (sums: this chunk's bytes only)
+            insert_batch16(s.head, in, n, ring, inserted, key, accS, accI, lane, inserted + lane >= c0 && inserted + lane < c1);   // (sums: this chunk's bytes only)
             inserted = uni64(inserted + 64);
             if (++since == 4 || inserted >= c1) {
                 since = 0;
@@ -1470,14 +1506,12 @@ __global__ __launch_bounds__(256) void dfl2_search_kernel(const D2Stream *__rest
         const uint64_t p = p0 + lane;
         const bool inchunk = p < c1, live = inchunk && p < last_main;
         const uint32_t key = live ? load32(in + p) : 0u;
-#pragma unroll
-        for (int d = 0; d < 30; ++d) cs[d * 64 + lane] = 0;
-        uint32_t ext = 1, mask = 0;
+        uint32_t ext = 1, mask = 0;                             // (a decade's slot holds something only where its bit is set: nothing to clear)
         chain_walk1(in, ring, n, p, live, key, wmask, attempts, goal, [&](uint32_t dist, uint32_t run) {
             ext = run > ext ? run : ext;
             const uint32_t dec = dist_decade(dist);
             uint32_t *slot = &cs[dec * 64 + lane];
-            if (run > (*slot & 0xffff)) *slot = dist << 16 | run;   // (strict: the closest candidate of a decade stays, DeflatorMatches.set(edge:) :183-194)
+            if (!((mask >> dec) & 1) || run > (*slot & 0xffff)) *slot = dist << 16 | run;   // (strict: the closest candidate of a decade stays, DeflatorMatches.set(edge:) :183-194)
             mask |= 1u << dec;
         });
         // ---- the batch's record: per position candidates << 9 | longest run; the words where the pool has room
@@ -1508,94 +1542,93 @@ __global__ __launch_bounds__(256) void dfl2_search_kernel(const D2Stream *__rest
 // ---- the parse kernel -------------------------------------------------------------------------------------------
 struct D2Arrays {                                               // (pointers of one stream, wave-uniform)
     const uint16_t *vinfo; const uint64_t *bbase; const uint32_t *bwords; uint64_t *emask;
-    gword *up, *step; gbyte *pathb;
+    gword *up, *step; gbyte *pathb, *litb;
     const uint32_t *pool;
 };
 
+// The parse kernel walks a block in batches of 64 vertices ALIGNED IN ROUND COORDINATES (the first one may start in front of the
+// block: sh = (block's first vertex in the round) mod 64 lanes idle), so that a batch is exactly one batch of the search kernel:
+// one candidate list, the word's position-in-batch is the lane.  Batch j holds the block's vertices 64 j - sh ... 64 j - sh + 63.
+//
 // Which vertices of the block keep their edges (Stream.compress full, DeflatorBuffers.Stream.swift:344-400): behind a
 // SEARCHED vertex whose longest run exceeds 100 the next run - 100 vertices -- not beyond the block's capacity -- are not
-// searched.  One 64-bit mask per batch of the block (block coordinates).
+// searched.  One 64-bit mask per batch.
 __device__ __attribute__((noinline)) void d2_skip_rule(const D2Arrays g, uint64_t vr0, uint32_t count, uint32_t cap, int lane)
 {
-    uint32_t skip_until = 0;
-    for (uint32_t b0 = 0; b0 < count; b0 += 64) {
-        const uint32_t v = b0 + (uint32_t)lane;
-        const uint32_t info = v < count ? g.vinfo[vr0 + v] : 1u;
+    const int sh = (int)(vr0 & 63);
+    const uint32_t nb = ((uint32_t)sh + count + 64) >> 6;      // (as the forward pass: the batch of the end vertex too)
+    int skip_until = 0, base = -sh;
+    auto info_of = [&](int v) -> uint32_t { return (v >= 0 && (uint32_t)v < count) ? (uint32_t)g.vinfo[vr0 + v] : 1u; };
+    uint32_t info_next = info_of(base + lane);
+    for (uint32_t j = 0; j < nb; ++j, base += 64) {
+        const int v = base + lane;
+        const bool valid = v >= 0 && (uint32_t)v < count;
+        const uint32_t info = info_next;
+        info_next = info_of(v + 64);
         const uint32_t ext = info & 0x1ff;
-        unsigned long long em = __ballot((info >> 9) != 0), xm = __ballot(ext > 100);
-        if (xm || skip_until > b0) {
-            uint32_t cur = b0;
+        unsigned long long em = __ballot(valid && (info >> 9) != 0), xm = __ballot(valid && ext > 100);
+        if (xm || skip_until > base) {
+            int cur = 0;                                        // (lane coordinates)
             for (;;) {
-                if (skip_until > cur) {
-                    const uint32_t hi = skip_until < b0 + 64 ? skip_until : b0 + 64;
-                    const unsigned long long clear = (hi - b0 >= 64 ? ~0ull : (1ull << (hi - b0)) - 1) & ~((1ull << (cur - b0)) - 1);
+                const int su = skip_until - base;
+                if (su > cur) {
+                    const int hi = su < 64 ? su : 64;
+                    const unsigned long long clear = (hi >= 64 ? ~0ull : (1ull << hi) - 1) & ~((1ull << cur) - 1);
                     em &= ~clear; xm &= ~clear;
                     cur = hi;
-                    if (cur >= b0 + 64) break;
+                    if (cur >= 64) break;
                 }
-                const unsigned long long m = xm & ~((1ull << (cur - b0)) - 1);
+                const unsigned long long m = xm & ~((1ull << cur) - 1);
                 if (!m) break;
-                const uint32_t x = (uint32_t)__ffsll((long long)m) - 1, vx = b0 + x;
-                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ext, (int)x);
-                const uint32_t room = cap - (vx + 1);                   // unfilled() once vx itself is in the block
+                const int x = __ffsll((long long)m) - 1, vx = base + x;
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)ext, x);
+                const uint32_t room = cap - (uint32_t)(vx + 1);         // unfilled() once vx itself is in the block
                 const uint32_t skip = e - 100 < room ? e - 100 : room;
-                skip_until = vx + 1 + skip;
+                skip_until = vx + 1 + (int)skip;
                 xm &= ~(1ull << x);
-                cur = vx + 1;
-                if (cur >= b0 + 64) break;
+                cur = x + 1;
+                if (cur >= 64) break;
             }
         }
-        if (lane == 0) g.emask[b0 >> 6] = em;
+        if (lane == 0) g.emask[j] = em;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// The offer table of a batch: g_ptab[vertex][L - 3] = cost << 20 | decade << 15 | distance of the cheapest decade (first among
-// equals: the lowest) whose run from that vertex reaches length L, for L = 3 .. 66; ~0: none.  `longm`: vertices with a run
-// beyond 66 (they take the per-entry path).  The words of the batch sit in the lists of one or two batches of the search kernel
-// (those are aligned in round coordinates, this batch in block coordinates).
-__device__ __forceinline__ unsigned long long d2_offers(const D2Arrays g, uint64_t vr, uint64_t rv, uint32_t b0, uint32_t count, unsigned long long em, uint32_t &cols,
-                                                          int lane)
+// The offer table of a batch: g_ptab[lane of the vertex][L - 3] = cost << 20 | decade << 15 | distance of the cheapest decade (first
+// among equals: the lowest) whose run from that vertex reaches length L, for L = 3 .. 66; ~0: none.  Returns the vertices with a
+// run beyond 66 (they take the per-entry path); `cols`: the columns in use.  w4: the first 256 words of the list, fetched a batch ahead.
+__device__ __forceinline__ unsigned long long d2_offers(const D2Arrays g, uint32_t bw, uint64_t lbase, const uint32_t (&w4)[4], int base, uint32_t count,
+                                                        unsigned long long em, uint32_t &cols, int lane)
 {
     DLds &s = g_lds;
-    const uint32_t sh = (uint32_t)(vr & 63);
-    const uint64_t q0 = vr >> 6;
-    uint32_t T[2] = {0, 0}, maxr = 0;
-    uint64_t base[2] = {0, 0};
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        if ((qi && !sh) || ((q0 + qi) << 6) >= rv) break;           // (the second list: only a batch the round holds)
-        const uint32_t bw = UNI(g.bwords[q0 + qi]);
-        T[qi] = bw & 0xffff; base[qi] = uni64(g.bbase[q0 + qi]);
-        if (T[qi]) maxr = (bw >> 16) > maxr ? bw >> 16 : maxr;
-    }
-    cols = maxr >= 3 ? (maxr < 66 ? maxr : 66u) - 2 : 0u;             // lengths 3 .. min(maxr, 66)
+    const uint32_t T = bw & 0xffff, maxr = bw >> 16;
+    cols = (T && maxr >= 3) ? (maxr < 66 ? maxr : 66u) - 2 : 0u;       // lengths 3 .. min(maxr, 66)
     for (uint32_t j = 0; j < cols; ++j) g_ptab[lane * D2_PSTRIDE + j] = ~0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     unsigned long long longm = 0;
-#pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-        for (uint32_t i0 = 0; i0 < T[qi]; i0 += 64) {
-            const uint32_t i = i0 + (uint32_t)lane;
-            const uint32_t w = i < T[qi] ? g.pool[base[qi] + i] : 0u;
-            const uint32_t vtx = w >> 24, run = w & 0x1ff, dist = (w >> 9) & 0x7fff;
-            const uint32_t ln = qi ? vtx + 64 - sh : vtx - sh;           // lane of the vertex in this batch (>= 64: not in it)
-            const bool mine = i < T[qi] && (qi ? vtx < sh : vtx >= sh) && ln < 64 && ((em >> ln) & 1);
-            const uint32_t rem = count - (b0 + ln);
-            const uint32_t r = run < rem ? run : rem;
-            const bool use = mine && b0 + ln < count && r >= 3;
-            if (use) {
-                const uint32_t dec = dist_decade(dist);
-                const uint32_t key = (uint32_t)s.depths[512 + dec] << 20 | dec << 15 | dist;
-                atomicMin(&g_ptab[ln * D2_PSTRIDE + (r < 66 ? r : 66u) - 3], key);
-            }
-            // vertices with a run beyond the table
-            unsigned long long lm = __ballot(use && r > 66);
-            while (lm) {
-                const int l = __ffsll((long long)lm) - 1;
-                lm &= lm - 1;
-                longm |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)ln, l);
-            }
+    for (uint32_t i0 = 0; i0 < T; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        uint32_t w = 0;
+        if (i0 < 256) { w = i0 == 0 ? w4[0] : i0 == 64 ? w4[1] : i0 == 128 ? w4[2] : w4[3]; }
+        else if (i < T) w = g.pool[lbase + i];
+        const uint32_t ln = w >> 24, run = w & 0x1ff, dist = (w >> 9) & 0x7fff;
+        const int vv = base + (int)ln;
+        const bool mine = i < T && ((em >> ln) & 1) && vv >= 0 && (uint32_t)vv < count;
+        const uint32_t rem = count - (uint32_t)vv;
+        const uint32_t r = run < rem ? run : rem;
+        const bool use = mine && r >= 3;
+        if (use) {
+            const uint32_t dec = dist_decade(dist);
+            const uint32_t key = (uint32_t)s.depths[512 + dec] << 20 | dec << 15 | dist;
+            atomicMin(&g_ptab[ln * D2_PSTRIDE + (r < 66 ? r : 66u) - 3], key);
+        }
+        // vertices with a run beyond the table
+        unsigned long long lm = __ballot(use && r > 66);
+        while (lm) {
+            const int l = __ffsll((long long)lm) - 1;
+            lm &= lm - 1;
+            longm |= 1ull << (uint32_t)__builtin_amdgcn_readlane((int)ln, l);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1652,86 +1685,246 @@ __device__ __forceinline__ void d2_relax_long(const D2Arrays g, uint64_t vr, uin
     }
 }
 
+// sum over the wave, in scalar registers (DPP row scans + four v_readlane: no LDS round trips -- __shfl_xor is ds_bpermute)
+__device__ __forceinline__ uint32_t wave_total(uint32_t v)
+{
+    const uint32_t incl = row_scan(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)incl, 15) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 31) +
+           (uint32_t)__builtin_amdgcn_readlane((int)incl, 47) + (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+}
+
 // minimize() forwards, as full_forward; keys: depth << 32 | (258 - length) << 23 | (decade + 1) << 15 | distance (the distance
-// rides along -- one per vertex and decade, it never decides -- so that the way in knows it without a look-up)
-__device__ __attribute__((noinline)) void d2_forward(const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint64_t rv, uint32_t count, int lane)
+// rides along -- one per vertex and decade, it never decides -- so that the way in knows it without a look-up).
+//   * A batch without edges that no earlier edge reaches is a run of literals: its depths are a plain sum, its ways in are not
+//     written at all (g.litb[batch] = 1 says so to the back-trace) -- the whole of an incompressible stream but a few batches.
+//   * In a batch with edges the depths are scanned over all 64 lanes only at its start and at its end; between two groups of
+//     vertices (three consecutive ones are final together) only the few lanes up to the next group are recomputed, one DPP
+//     step per lane.
+__device__ __attribute__((noinline)) void d2_forward(const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint32_t count, int lane)
 {
     DLds &s = g_lds;
     uint32_t rc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const uint32_t L = 3u + (uint32_t)lane + 64u * j; rc[j] = L <= 258 ? s.depths[253 + L] : 0u; }
+    // (packed groups: lane = 21 * (vertex of the group) + (length - 3))
+    const uint32_t pq = (uint32_t)lane / 21, pl = (uint32_t)lane % 21;
+    const uint32_t rcp = s.depths[253 + 3 + pl];
     if (lane == 0) s.win[0] = 0;                               // vertex 0: depth 0
+    const int sh = (int)(vr0 & 63);
+    const uint64_t qbase = vr0 >> 6;
+    const uint32_t nb = ((uint32_t)sh + count + 64) >> 6;      // batches that hold the vertices 0 .. count (the last one: the end)
     uint32_t inited = 1, carry = DINF;
-    uint32_t lb_next = (lane >= 1 && (uint32_t)lane <= count) ? in[bbase + lane - 1] : 0u;
-    unsigned long long em_next = count ? uni64(g.emask[0]) : 0ull;
-    for (uint32_t b0 = 0; b0 <= count; b0 += 64) {
-        const uint32_t nv = count + 1 - b0 < 64 ? count + 1 - b0 : 64;      // vertices b0 .. b0 + nv - 1 (the last one: `count`, the end)
-        const uint32_t v = b0 + (uint32_t)lane;
-        const unsigned long long em = em_next;
-        em_next = b0 + 64 < count ? uni64(g.emask[(b0 >> 6) + 1]) : 0ull;
+    int pend = 0;                                              // no vertex behind it holds a key yet
+    // a batch ahead: literals, edge masks, list heads; the first words of the next batch's list
+    auto lit_of = [&](int v) -> uint32_t { return (v >= 1 && (uint32_t)v <= count) ? (uint32_t)in[bbase + (uint32_t)v - 1] : 0u; };
+    uint32_t lb_next = lit_of(-sh + lane);
+    // (what a batch needs from memory is asked for two batches ahead and only looked at -- made wave-uniform -- one batch later:
+    //  this wave has nobody to hide a load behind)
+    unsigned long long em1 = uni64(g.emask[0]);
+    uint32_t bw1 = UNI(g.bwords[qbase]);
+    uint64_t bb1 = uni64(g.bbase[qbase]);
+    unsigned long long r_em = nb > 1 ? g.emask[1] : 0ull;      // raw: batch j + 1
+    uint32_t r_bw = g.bwords[qbase + 1];
+    uint64_t r_bb = g.bbase[qbase + 1];
+    uint32_t wn[4] = {0, 0, 0, 0};
+    auto fetch_words = [&](unsigned long long em, uint32_t bw, uint64_t bb) {
+        const uint32_t T = em ? bw & 0xffff : 0u;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wn[c] = 64u * c + (uint32_t)lane < T ? g.pool[bb + 64u * c + lane] : 0u;
+    };
+    fetch_words(em1, bw1, bb1);
+    int base = -sh;
+    for (uint32_t j = 0; j < nb; ++j, base += 64) {
+        const int v = base + lane;
+        const bool act = v >= 0 && (uint32_t)v <= count;       // a vertex of the block (the end vertex included)
+        const unsigned long long em = em1;
+        const uint32_t bw = bw1;
+        const uint64_t bb = bb1;
+        const uint32_t w4[4] = {wn[0], wn[1], wn[2], wn[3]};
         const uint32_t lb = lb_next;
-        {
-            const uint32_t vn = b0 + 64 + (uint32_t)lane;
-            lb_next = vn <= count ? in[bbase + vn - 1] : 0u;
+        em1 = uni64(r_em); bw1 = UNI(r_bw); bb1 = uni64(r_bb);  // (asked for a batch ago)
+        fetch_words(em1, bw1, bb1);
+        lb_next = lit_of(v + 64);
+        r_em = j + 2 < nb ? g.emask[j + 2] : 0ull;
+        r_bw = g.bwords[qbase + j + 2]; r_bb = g.bbase[qbase + j + 2];
+        const uint32_t cin = (v >= 1 && (uint32_t)v <= count) ? s.depths[lb] : 0u;     // the literal edge INTO v
+        if (!em && base > pend && (uint32_t)(base + 63) < count) {
+            // Literals only -- and so, in incompressible data, are the batches behind it: the whole run in one tight loop (a
+            // literal load, a cost look-up and an add per batch; one sum over the wave at its end).
+            const uint32_t most = (count - 64 - (uint32_t)base) / 64;          // batches behind this one that lie inside the block
+            const unsigned long long ahead = j + 1 + (uint32_t)lane < nb ? g.emask[j + 1 + lane] : ~0ull;
+            const unsigned long long busy = __ballot(ahead != 0);
+            uint32_t z = busy ? (uint32_t)__ffsll((long long)busy) - 1 : 63u;   // (at most 64 batches a run: one litb store per lane)
+            z = z < 63 ? z : 63u;
+            z = z < most ? z : most;
+            uint32_t acc = cin;
+            {
+                uint32_t lbq = lit_of(v + 64);                               // (batch j + 1; fetched once more below when z == 0: harmless)
+                for (uint32_t i = 1; i <= z; ++i) {
+                    const uint32_t lbc = lbq;
+                    lbq = lit_of(v + 64 * (int)(i + 1));
+                    acc += s.depths[lbc];
+                }
+            }
+            carry += wave_total(acc);
+            if ((uint32_t)lane <= z) g.litb[j + lane] = 1;
+#ifdef SPNG_DEFLATE_PROF
+            if (threadIdx.x == 0) g_prof[0] += (uint64_t)(1 + z) << 20;       // (count of literal batches)
+#endif
+            if (z) {
+                // on behind the run: what the loop's head expects of batch j + z + 1
+                j += z; base += 64 * (int)z;
+                const uint32_t jn = j + 1;
+                em1 = jn < nb ? uni64(g.emask[jn]) : 0ull;
+                bw1 = UNI(g.bwords[qbase + jn]); bb1 = uni64(g.bbase[qbase + jn]);
+                fetch_words(em1, bw1, bb1);
+                lb_next = lit_of(base + 64 + lane);
+                r_em = jn + 1 < nb ? g.emask[jn + 1] : 0ull;
+                r_bw = g.bwords[qbase + jn + 1]; r_bb = g.bbase[qbase + jn + 1];
+            }
+            continue;
         }
-        const uint32_t need = (b0 + 64 + 258 < count ? b0 + 64 + 258 : count) + 1;
-        for (uint32_t j = inited + lane; j < need; j += 64) s.win[j & 511] = ~0ull;
+        if (lane == 0) g.litb[j] = 0;
+        const uint32_t top = (uint32_t)(base + 64 + 258);
+        const uint32_t need = (top < count ? top : count) + 1;
+        if (need > inited + 512) inited = need - 512;          // (behind a stretch of literals: nothing older is alive)
+        for (uint32_t q = inited + lane; q < need; q += 64) s.win[q & 511] = ~0ull;
         inited = inited > need ? inited : need;
-        const uint32_t cin = (v >= 1 && v <= count) ? s.depths[lb] : 0u;     // the literal edge INTO v
         unsigned long long longm = 0;
         uint32_t cols = 0;
-        if (em) longm = d2_offers(g, vr0 + b0, rv, b0, count, em, cols, lane);
+#ifdef SPNG_DEFLATE_PROF
+        const uint64_t o_t0 = __builtin_readcyclecounter();
+#endif
+        if (em) longm = d2_offers(g, bw, bb, w4, base, count, em, cols, lane);
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        uint64_t W; uint32_t Wd, D;
+#ifdef SPNG_DEFLATE_PROF
+        if (threadIdx.x == 0) g_prof[9] += __builtin_readcyclecounter() - o_t0;
+#endif
+        uint64_t W = act ? s.win[(uint32_t)v & 511] : ~0ull;
+        uint32_t Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
+        uint32_t D = minplus_scan(cin, Wd, carry, lane);
         uint32_t k = 0;
+        bool dirty = false;                                    // keys were written since D was computed
         for (;;) {
-            W = (uint32_t)lane < nv ? s.win[v & 511] : ~0ull;
-            Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
-            D = minplus_scan(cin, Wd, carry, lane);
             const unsigned long long rest = k < 64 ? (em >> k) << k : 0ull;
             if (!rest) break;
             const uint32_t kk = (uint32_t)__ffsll((long long)rest) - 1;
-            // a match is at least 3 long: the depths of three consecutive vertices are final together
-            for (uint32_t kq = kk; kq < kk + 3; ++kq) {
-                if (!(kq < 64 && ((em >> kq) & 1) && count - (b0 + kq) >= 3)) continue;
-                const uint32_t vv = b0 + kq;
-                const uint32_t Dk = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kq);
-                if ((longm >> kq) & 1) { d2_relax_long(g, vr0 + vv, vv, count, Dk, rc, lane); continue; }
-                const uint32_t pk = (uint32_t)lane < cols ? g_ptab[kq * D2_PSTRIDE + lane] : ~0u;
-                if (pk != ~0u) {
-                    const uint32_t L = 3u + (uint32_t)lane;
-                    const uint64_t key = (uint64_t)(Dk + (pk >> 20) + rc[0]) << 32 | (258u - L) << 23 | ((pk & 0xfffffu) + (1u << 15));
+            // A match is at least 3 long: the depths of three consecutive vertices are final together.  D is final below lane k;
+            // the group needs it through lane kk + 2: a few lanes are recomputed one by one, many by the scan over all of them.
+            // (their offer rows are asked for first: they do not depend on the depths)
+            // Runs up to 23 -- most batches of image data: the offers of the group's three vertices side by side, 21 lanes each,
+            // so that ONE row read, one key and one ds_min_u64 per lane serve the whole group; otherwise vertex by vertex.
+            const bool packed = cols <= 21;
+#ifdef SPNG_DEFLATE_PROF
+            if (threadIdx.x == 0) { g_prof[packed ? 7 : 8] += 1ull << 20; if (dirty && kk + 3 - k > 8) g_prof[9] += 0; }
+#endif
+            uint32_t row[3];
+            if (packed) row[0] = (pl < cols && kk + pq < 64) ? g_ptab[(kk + pq) * D2_PSTRIDE + pl] : ~0u;
+            else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) row[q] = ((uint32_t)lane < cols && kk + q < 64) ? g_ptab[(kk + q) * D2_PSTRIDE + lane] : ~0u;
+            }
+            if (dirty) {
+                W = act ? s.win[(uint32_t)v & 511] : ~0ull;
+                Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
+                if (kk + 3 - k <= 8) {
+                    const uint32_t hi = kk + 2 < 63 ? kk + 2 : 63;
+                    for (uint32_t x = k; x <= hi; ++x) {
+                        const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)D, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                        const uint32_t cand = prev + cin, nd = cand < Wd ? cand : Wd;
+                        D = (uint32_t)lane == x ? nd : D;
+                    }
+                } else D = minplus_scan(cin, Wd, carry, lane);
+            }
+            if (packed) {
+                const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kk);
+                const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)(kk + 1 < 63 ? kk + 1 : 63));
+                const uint32_t D2 = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)(kk + 2 < 63 ? kk + 2 : 63));
+                const uint32_t kq = kk + pq, vv = (uint32_t)(base + (int)kq);
+                const uint32_t pk = row[0];
+                const bool edge = pq < 3 && kq < 64 && ((em >> (kq & 63)) & 1) && count - vv >= 3;
+                if (edge && !((longm >> (kq & 63)) & 1) && pk != ~0u) {
+                    const uint32_t Dq = pq == 0 ? D0 : pq == 1 ? D1 : D2, L = 3u + pl;
+                    const uint64_t key = (uint64_t)(Dq + (pk >> 20) + rcp) << 32 | (258u - L) << 23 | ((pk & 0xfffffu) + (1u << 15));
                     __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
+                pend = (int)(base + (int)kk + 2 + (int)cols + 2) > pend ? (int)(base + (int)kk + 2 + (int)cols + 2) : pend;
+                // (vertices of the group with a run beyond the table)
+                unsigned long long lg = (longm >> kk) & 7ull & (em >> kk);
+                while (lg) {
+                    const uint32_t kl = kk + (uint32_t)__ffsll((long long)lg) - 1;
+                    lg &= lg - 1;
+                    const uint32_t vl = (uint32_t)(base + (int)kl);
+                    if (kl >= 64 || count - vl < 3) continue;
+                    d2_relax_long(g, vr0 + vl, vl, count, (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kl), rc, lane);
+                    pend = (int)vl + 258 > pend ? (int)vl + 258 : pend;
+                }
+            } else {
+                for (uint32_t kq = kk; kq < kk + 3; ++kq) {
+                    if (!(kq < 64 && ((em >> kq) & 1))) continue;
+                    const uint32_t vv = (uint32_t)(base + (int)kq);
+                    if (count - vv < 3) continue;
+                    const uint32_t Dk = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kq);
+                    if ((longm >> kq) & 1) {
+                        d2_relax_long(g, vr0 + vv, vv, count, Dk, rc, lane);
+                        pend = (int)vv + 258 > pend ? (int)vv + 258 : pend;
+                        continue;
+                    }
+                    const uint32_t pk = kq == kk ? row[0] : kq == kk + 1 ? row[1] : row[2];
+                    if (pk != ~0u) {
+                        const uint32_t L = 3u + (uint32_t)lane;
+                        const uint64_t key = (uint64_t)(Dk + (pk >> 20) + rc[0]) << 32 | (258u - L) << 23 | ((pk & 0xfffffu) + (1u << 15));
+                        __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    pend = (int)(vv + cols + 2) > pend ? (int)(vv + cols + 2) : pend;
+                }
             }
+            dirty = true;
             k = kk + 3;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // the group's keys are in the ring
+            // (LDS serves a wave's operations in order: the next read of the ring sees these keys without waiting for them here)
+            asm volatile("" ::: "memory");
+        }
+        if (dirty) {
+            W = act ? s.win[(uint32_t)v & 511] : ~0ull;
+            Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
+            D = minplus_scan(cin, Wd, carry, lane);
         }
         // the way in: the literal only when strictly cheaper than what the matches offer.
         // run << 16 | decade << 8 | distance (low byte; high bits from bit 25 up); literal: 1 << 16 | 0xff00
-        if ((uint32_t)lane < nv && v >= 1) {
+        if (act && v >= 1) {
             const uint32_t low = (uint32_t)W, dist = low & 0x7fff;
             g.up[v] = D < Wd ? 0x0001ff00u : (258u - (low >> 23)) << 16 | (((low >> 15) & 31u) - 1u) << 8 | (dist & 0xff) | (dist >> 8) << 25;
         }
-        carry = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)(nv - 1));
+        const uint32_t last = count - (uint32_t)base < 63 ? count - (uint32_t)base : 63;      // (base <= count in every batch)
+        carry = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)last);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // minimize() backwards (:282-320), as full_backward with the wider ways-in
-__device__ __attribute__((noinline)) void d2_backward(const D2Arrays g, const gbyte *in, uint64_t bbase, uint32_t count, int lane)
+__device__ __attribute__((noinline)) void d2_backward(const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint32_t count, int lane)
 {
     DLds &s = g_lds;
+    const uint32_t sh = (uint32_t)(vr0 & 63);
+    // (a batch of literals only: the forward pass wrote no ways in for it)
+    auto way_in = [&](uint32_t c) -> uint32_t { return g.litb[(sh + c) >> 6] ? 0x0001ff00u : g.up[c]; };
     for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     uint32_t hi = count;
-    uint32_t u_next = ((uint32_t)lane < hi) ? g.up[hi - (uint32_t)lane] : 0u, hi_next = hi;
+    // (the ways into the next 64 vertices -- and the literal in front of each -- are fetched ahead on the guess that the path
+    //  leaves this batch exactly at its end, as it does through literals; a longer hop refetches)
+    uint32_t u_next = ((uint32_t)lane < hi) ? way_in(hi - (uint32_t)lane) : 0u, hi_next = hi;
+    uint32_t l_next = ((uint32_t)lane < hi) ? (uint32_t)in[bbase + hi - (uint32_t)lane - 1] : 0u;
     for (;;) {
         const bool valid = (uint32_t)lane <= hi;
         const uint32_t c = valid ? hi - (uint32_t)lane : 0u;
-        uint32_t u = u_next;
-        if (hi_next != hi) u = (valid && c > 0) ? g.up[c] : 0u;
-        if (hi >= 64) { hi_next = hi - 64; u_next = ((uint32_t)lane < hi_next) ? g.up[hi_next - (uint32_t)lane] : 0u; }
+        uint32_t u = u_next, lit = l_next;
+        if (hi_next != hi) { u = (valid && c > 0) ? way_in(c) : 0u; lit = (valid && c > 0) ? (uint32_t)in[bbase + c - 1] : 0u; }
+        if (hi >= 64) {
+            hi_next = hi - 64;
+            u_next = ((uint32_t)lane < hi_next) ? way_in(hi_next - (uint32_t)lane) : 0u;
+            l_next = ((uint32_t)lane < hi_next) ? (uint32_t)in[bbase + hi_next - (uint32_t)lane - 1] : 0u;
+        }
         const uint32_t len = (u >> 16) & 0x1ff;                // 0: vertex 0 (or nothing)
         unsigned long long pm = 0;
         uint32_t pos = 0;
@@ -1749,12 +1942,13 @@ __device__ __attribute__((noinline)) void d2_backward(const D2Arrays g, const gb
         if (on && c > 0) {
             const uint32_t nxt = c - len;
             g.step[nxt] = u;
-            if (len == 1) atomicAdd(&s.freq[in[bbase + nxt]], 1u);
+            if (len == 1) atomicAdd(&s.freq[lit], 1u);           // (the literal in front of c: in[bbase + c - 1])
             else { atomicAdd(&s.freq[256 | run_decade(len)], 1u); atomicAdd(&s.freq[288 + ((u >> 8) & 0xff)], 1u); }
         }
         if (hi < 64 || pos > hi) break;                        // vertex 0 was in this batch
         if (pos < 64) break;                                   // (cannot happen: a hop of length 0 above vertex 0)
         const uint32_t nhi = hi - pos;
+        // vertices the leaving hop jumped over are not on the path
         for (uint32_t cc = nhi + 1 + (uint32_t)lane; cc + 64 <= hi; cc += 64) g.pathb[cc] = 0;
         hi = nhi;
     }
@@ -1764,21 +1958,27 @@ __device__ __attribute__((noinline)) void d2_backward(const D2Arrays g, const gb
 }
 
 // Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), full form, over the records of the search kernel
-__device__ __attribute__((noinline)) Bits d2_block(Bits b, const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint64_t rv, uint32_t count, uint32_t cap,
+__device__ __attribute__((noinline)) Bits d2_block(Bits b, const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint32_t count, uint32_t cap,
                                                    bool final, int iterations, bool generic, int lane)
 {
     DLds &s = g_lds;
+    FPROF(0);
     d2_skip_rule(g, vr0, count, cap, lane);
+    FPROF(1);
     for (int i = generic ? -iterations : 0;;) {
-        d2_forward(g, in, bbase, vr0, rv, count, lane);
-        d2_backward(g, in, bbase, count, lane);
+        d2_forward(g, in, bbase, vr0, count, lane);
+        FPROF(2);
+        d2_backward(g, in, bbase, vr0, count, lane);
+        FPROF(3);
         build_tree(s.freq, 286, 15, s.ll, lane);
         build_tree(s.freq + 288, 30, 15, s.dl, lane);
         ++i;
+        FPROF(4);
         if (!(i < iterations)) break;
         full_depths_update(lane);
     }
     b = write_tables(b, final, lane);
+    FPROF(5);
     // writeBlock(with:) (:661-707): the path's terms, 64 vertices at a time
     uint32_t pb_next = (uint32_t)lane < count ? g.pathb[lane] : 0u, st_next = (uint32_t)lane < count ? g.step[lane] : 0u,
              lt_next = (uint32_t)lane < count ? in[bbase + lane] : 0u;
@@ -1805,6 +2005,7 @@ __device__ __attribute__((noinline)) Bits d2_block(Bits b, const D2Arrays g, con
     }
     put(s, b, s.lcode[256], s.ll[256], lane);
     maybe_drain(s, b, lane);
+    FPROF(6);
     // resetGraph -> Depths.generalize (Depths.swift:88-98)
     for (uint32_t i = lane; i < 542; i += 64) {
         const uint32_t x = s.depths[i], d = depth_default(i);
@@ -1828,9 +2029,13 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
     g.vinfo = (const uint16_t *)uni64((uint64_t)sp->vinfo); g.bbase = (const uint64_t *)uni64((uint64_t)sp->bbase);
     g.bwords = (const uint32_t *)uni64((uint64_t)sp->bwords); g.emask = (uint64_t *)uni64((uint64_t)sp->emask);
     g.up = (gword *)uni64((uint64_t)sp->up); g.step = (gword *)uni64((uint64_t)sp->step); g.pathb = (gbyte *)uni64((uint64_t)sp->pathb);
+    g.litb = (gbyte *)uni64((uint64_t)sp->litb);
     g.pool = pool;
     const int lv = (int)UNI(sp->level) > 13 ? 13 : (int)UNI(sp->level);
     const int iterations = lv - 7;
+#ifdef SPNG_DEFLATE_PROF
+    if (lane < 12) g_prof[lane] = lane == 11 ? __builtin_readcyclecounter() : 0;
+#endif
 
     for (int i = lane; i < OUTB / 4; i += 64) s.out32[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1871,7 +2076,7 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
             const uint64_t room = n - pos;
             const uint32_t count = (uint64_t)(limit - 1) < room ? limit - 1 : (uint32_t)room;
             const bool final = pos + count == n;
-            b = d2_block(b, g, in, pos, pos - rb, re - rb, count, limit - 1, final, iterations, generic, lane);
+            b = d2_block(b, g, in, pos, pos - rb, count, limit - 1, final, iterations, generic, lane);
             generic = false;
             pos += count;
             if (!final) limit = 2 * limit < (1u << 21) ? 2 * limit : 1u << 21;     // trees(iterations:) :229
@@ -1895,6 +2100,10 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
         }
         if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);            // DeflatorOut.pull flushes padding bits
         drain(s, b, b.total, lane);
+#ifdef SPNG_DEFLATE_PROF
+        if (lane == 0 && blockIdx.x == 0) printf("dfl2_parse prof Mcycles (last round, from %llu): other %llu skip-rule %llu forward %llu backward %llu trees %llu tables %llu emit %llu; offers %llu long %llu\n",
+            (unsigned long long)rb, g_prof[0] >> 20, g_prof[1] >> 20, g_prof[2] >> 20, g_prof[3] >> 20, g_prof[4] >> 20, g_prof[5] >> 20, g_prof[6] >> 20, g_prof[9] >> 20, g_prof[10] >> 20);
+#endif
         if (lane == 0) {
             spng_result &res = results[UNI(sp->image)];
             res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_DONE; res.reserved = 1;
@@ -1903,6 +2112,13 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
         }
         return;
     }
+#ifdef SPNG_DEFLATE_PROF
+#define D2_PROF_PRINT() if (lane == 0 && blockIdx.x == 0) printf("dfl2_parse prof Mcycles (round from %llu): other %llu skip-rule %llu forward %llu backward %llu trees %llu tables %llu emit %llu; offers %llu long %llu; literal batches %llu packed groups %llu vertex-wise groups %llu\n", \
+        (unsigned long long)rb, 0ull, g_prof[1] >> 20, g_prof[2] >> 20, g_prof[3] >> 20, g_prof[4] >> 20, g_prof[5] >> 20, g_prof[6] >> 20, g_prof[9] >> 20, g_prof[10] >> 20, g_prof[0] >> 20, g_prof[7] >> 20, g_prof[8] >> 20)
+#else
+#define D2_PROF_PRINT()
+#endif
+    D2_PROF_PRINT();
     // the next round
     drain(s, b, b.total, lane);
     for (uint32_t i = lane; i < 542; i += 64) state->depths[i] = s.depths[i];

@@ -1,0 +1,30 @@
+"""GPU probe: the two kernels of the level >= 8 rounds -- time of a batch, of its search launches and of its parse launches."""
+import sys, time, os; sys.path.insert(0, ".")
+import numpy as np, torch
+import swift_png_amd as spng
+from swift_png_amd import synth
+
+s = spng.load(0)
+level = int(os.environ.get("PROBE_LEVEL", "9"))
+def run(name, tensors):
+    outs, res = s.deflate_batch(tensors, level)          # warm-up: slab allocation
+    del outs
+    torch.cuda.synchronize(); s.profile(True); t0 = time.perf_counter()
+    outs, res = s.deflate_batch(tensors, level)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    a = s.profile_get(spng.K_DFL_SEARCH)[0]; b = s.profile_get(spng.K_DFL_PARSE)[0]; d = s.profile_get(spng.K_DEFLATE)[0]; s.profile(False)
+    n = sum(t.numel() for t in tensors)
+    print(f"{name}: {len(tensors)} streams, {n/1e6:.0f} MB in {dt:.3f} s = {n/dt/1e6:.1f} MB/s ({n/dt/1e6/len(tensors):.2f} MB/s per stream); "
+          f"search {a:.0f} ms, parse {b:.0f} ms, deflate span {d:.0f} ms; ratio {n/sum(r.written for r in res):.3f}", flush=True)
+    del outs
+gen = torch.Generator(device=s.tdev); gen.manual_seed(7)
+N = int(os.environ.get("PROBE_N", "256"))
+which = os.environ.get("PROBE_WHICH", "random,photo,one")
+if "random" in which:
+    rnd = [torch.randint(0, 256, (64 << 20,), dtype=torch.uint8, device=s.tdev, generator=gen) for _ in range(8)]
+    run("random 64 MiB", [rnd[i % 8] for i in range(N)])
+    del rnd
+if "photo" in which:
+    ph = [s.to_device(s.filter(synth.image(k, 1024, 1024).tobytes(), 1024, 1024, 8, 4, False)) for k in range(8)]
+    run("photographic 1024^2 rows", [ph[i % 8] for i in range(N)])
+    if "one" in which: run("photographic, one stream", ph[:1])
