@@ -1532,7 +1532,7 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
         Lay l;
         l.scratch = 0;
         for (size_t i = gr.first; i < gr.second; ++i) l.scratch += scratch_of(sorted[i].src_len);
-        uint32_t cps = (1536 + cnt - 1) / cnt;
+        uint32_t cps = (1536 + cnt - 1) / cnt;                // (two rounds of resident workgroups: three per CU)
         cps = cps < 1 ? 1 : cps > 64 ? 64 : cps;
         l.cps = cps; l.chunk = (((1u << 21) / cps + 63) / 64) * 64;
         l.rings = (uint64_t)cnt * cps * 65536 * 4;

@@ -1363,9 +1363,12 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
 static constexpr uint32_t D2_RV = 1u << 21;                     // vertices per stream and round
 static constexpr uint32_t D2_PCOLS = 64, D2_PSTRIDE = 65;       // offer table: lengths 3 .. 66, rows padded against bank conflicts
 __shared__ uint32_t g_ptab[64 * D2_PSTRIDE];                    // (parse kernel only)
+#ifndef SPNG_D2_WAVES
+#define SPNG_D2_WAVES 4          // waves of a search workgroup: one of them inserts first.  4 waves = 47 KB of LDS = three per CU
+#endif                           // (2 waves, five per CU, more inserters: measured 30 % slower -- profiles/r04_probe_deflate2d.log)
 struct D2ALds {                                                 // (search kernel only)
     uint16_t head[(1 << HBITS) + 2];                            // (16-bit: insert_batch16)
-    uint32_t cslot[4][30 * 64];                                 // per wave: per lane, the best run of every distance decade
+    uint32_t cslot[SPNG_D2_WAVES][30 * 64];                     // per wave: per lane, the best run of every distance decade
     uint64_t inserted;                                          // positions < inserted are in the window (published by wave 0)
     uint32_t next;                                              // batches claimed
 };
@@ -1434,7 +1437,7 @@ __device__ __forceinline__ void chain_walk1(const gbyte *in, const gword *ring, 
     }
 }
 
-__global__ __launch_bounds__(256) void dfl2_search_kernel(const D2Stream *__restrict__ streams, uint32_t cps, uint32_t chunk_len, uint32_t *__restrict__ pool,
+__global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D2Stream *__restrict__ streams, uint32_t cps, uint32_t chunk_len, uint32_t *__restrict__ pool,
                                                           unsigned long long *__restrict__ pool_next, uint64_t pool_cap, uint32_t *__restrict__ rings)
 {
     D2ALds &s = g_a;
@@ -1456,7 +1459,7 @@ __global__ __launch_bounds__(256) void dfl2_search_kernel(const D2Stream *__rest
     const uint32_t nbatches = (uint32_t)((c1 - c0 + 63) / 64);
 
     const uint64_t warm = (c0 >= 32768 ? c0 - 32768 : 0) & ~(uint64_t)63;
-    for (int i = threadIdx.x; i <= (1 << HBITS); i += 256) s.head[i] = (uint16_t)(warm - 32768);     // (2^15 behind the first position: no link)
+    for (int i = threadIdx.x; i <= (1 << HBITS); i += SPNG_D2_WAVES * 64) s.head[i] = (uint16_t)(warm - 32768);     // (2^15 behind the first position: no link)
     if (threadIdx.x == 0) { s.inserted = warm; s.next = 0; }
     __syncthreads();
 
@@ -2151,7 +2154,7 @@ hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uin
     if (!count) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_pool_next, 0, 8, stream);
     if (e != hipSuccess) return e;
-    dfl2_search_kernel<<<count * cps, 256, 0, stream>>>(d_streams, cps, chunk_len, d_pool, d_pool_next, pool_words, d_rings);
+    dfl2_search_kernel<<<count * cps, SPNG_D2_WAVES * 64, 0, stream>>>(d_streams, cps, chunk_len, d_pool, d_pool_next, pool_words, d_rings);
     return hipGetLastError();
 }
 hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, hipStream_t stream)
