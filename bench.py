@@ -309,9 +309,12 @@ def kernel_report(m, traffic):
 
 # ---- the other BASELINE configs and the neighbours of the path, reported in the same line --------------------------
 def copy_ceiling(torch, s):
-    """Measured device copy next to the 8 TB/s spec peak: read + write bytes per second of a
-    plain 16-bytes-per-lane HBM-to-HBM copy of 8 GiB."""
+    """Measured device copy next to the 8 TB/s spec peak: read + write bytes per second of the library's
+    own 16-bytes-per-lane grid-stride copy kernel (spng_copy_ceiling) over 8 GiB, a torch tensor copy of the same buffers beside
+    it, and the same bytes in the access pattern the scanline kernel had before round 4 (stores that straddle lines)."""
     n = 8 << 30
+    gbps, ms = s.copy_ceiling(n, 0, 5)
+    skew_gbps, skew_ms = s.copy_ceiling(n, 1, 3)
     a = torch.empty(n // 8, dtype=torch.int64, device=s.tdev)
     b = torch.empty(n // 8, dtype=torch.int64, device=s.tdev)
     a.zero_(); b.copy_(a)
@@ -322,11 +325,16 @@ def copy_ceiling(torch, s):
         b.copy_(a)
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
+    tms = e0.elapsed_time(e1) / 5
     del a, b
     torch.cuda.empty_cache()
-    return {"gbps": round(2 * n / (ms * 1e-3) / 1e9, 1), "ms": round(ms, 3), "bytes": 2 * n,
-            "how": "torch tensor copy of 8 GiB (int64 elements), read + write counted, HIP events, 5 repeats"}
+    return {"gbps": round(gbps, 1), "ms": round(ms, 3), "bytes": 2 * n,
+            "how": "spng_copy_ceiling pattern 0: the library's 16-bytes-per-lane grid-stride copy of 8 GiB, read + write counted, HIP "
+                   "events, 5 repeats",
+            "torch_copy_gbps": round(2 * n / (tms * 1e-3) / 1e9, 1),
+            "skewed_rows_gbps": round(skew_gbps, 1),
+            "skewed_rows_how": "pattern 1: 64 rows per wave, 256-byte tiles, row r trailing row r - 1 by 4 bytes (unaligned stores): the "
+                               "unfilter kernel's access pattern of rounds 1-3"}
 
 
 def parallel_zlib(rows: bytes, level: int, threads: int) -> bytes:
@@ -484,11 +492,13 @@ def main():
     ap.add_argument("--mode", choices=("decode", "encode"), default="decode")
     ap.add_argument("--images", type=int, default=1024, help="batch size (BASELINE: 1024)")
     ap.add_argument("--unique", type=int, default=32, help="distinct images; slot i holds image i mod unique")
-    ap.add_argument("--streams", choices=("zlib", "swiftpng"), default="zlib",
-                    help="level-6 encoder of the headline's input streams: host zlib, or the device deflater "
-                         "(swift-png's own bitstream)")
-    ap.add_argument("--no-swiftpng", action="store_true", help="skip the second measurement on swift-png-made streams")
-    ap.add_argument("--swiftpng-unique", type=int, default=8)
+    ap.add_argument("--streams", choices=("zlib", "swiftpng"), default="swiftpng",
+                    help="level-6 encoder of the headline's input streams: the device deflater = swift-png's own bitstream "
+                         "(BASELINE.md section 1: what generates the config-2 inputs), or host zlib")
+    ap.add_argument("--no-swiftpng", "--no-alt", dest="no_swiftpng", action="store_true",
+                    help="skip the second measurement (the same batch from the other encoder)")
+    ap.add_argument("--swiftpng-unique", "--alt-unique", dest="swiftpng_unique", type=int, default=16,
+                    help="distinct images of the second measurement (>= 10: the compressed input exceeds the 256 MiB Infinity Cache)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: --images in total, sharded (strong, BASELINE configs[2]); or --images per GPU (weak)")
     ap.add_argument("--groups", type=int, default=1,
@@ -498,8 +508,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="decode mode: skip the copy ceiling, configs[3] / configs[4] and file -> pixels legs")
-    ap.add_argument("--encode-images", type=int, default=256,
-                    help="decode mode: images of the bounded configs[3] leg (one wave per stream: fewer leave the chip idle)")
+    ap.add_argument("--encode-images", type=int, default=1024,
+                    help="decode mode: images of the configs[3] leg (BASELINE: 1024)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -554,7 +564,7 @@ def main():
             "scaling": "weak" if (weak and world > 1) else "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.images} x 4096x4096 RGBA8 PNG decode (inflate+unfilter), mixed filters "
-                                   f"(reference heuristic), level 6 ({args.streams} encoder); BASELINE configs[1]"
+                                   f"(reference heuristic), level 6 ({'swift-png-made streams: the device deflater, bit-exact with LZ77.Deflator' if args.streams == 'swiftpng' else 'zlib-made streams'}); BASELINE configs[1]"
                                    + ("" if world == 1 else
                                       f" per GPU (global batch {args.images * world}); each rank's {m['hi_lo']}-image share "
                                       f"gathered to rank 0 over RCCL" if weak else
@@ -604,13 +614,13 @@ def main():
             def enc():
                 from bench_encode import run_encode
                 ea = argparse.Namespace(**vars(args))
-                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), 1, 1, args.no_cpu_baseline   # (the first call of a context allocates the match-graph slab: ~2 s)
+                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), 1, 1, args.no_cpu_baseline   # (the first call of a context allocates the deflate slab)
                 return run_encode(ea, torch, dist, spng, s, rank, world)
             leg("encode", enc)
 
             def enc_photo():
                 from bench_encode import run_encode_photographic
-                return run_encode_photographic(torch, spng, s, args.level)
+                return run_encode_photographic(torch, spng, s, args.level, cpu=not args.no_cpu_baseline)
             leg("encode_photographic", enc_photo)
         print(json.dumps(out))
     if world > 1:

@@ -134,17 +134,20 @@ def run_encode(args, torch, dist, spng, s, rank, world):
         # whole 64 MiB image takes minutes on a core); also the bit-exactness anchor of this run
         sys.path.insert(0, str(ROOT / "tests"))
         import pnghelp as ph
+        import hashlib
         z, rows = streams[0]
-        sample = rows[:2 << 20]
+        # the WHOLE stream of image 0 -- 64 MiB of scanlines, 32 blocks at the vertex cap -- against the oracle's (bit for bit,
+        # by digest), timed as the one-core figure
         t0 = time.perf_counter()
-        want = ph.orc_deflate(sample, args.level)
+        want = ph.orc_deflate(rows, args.level)
         dtc = time.perf_counter() - t0
-        got = s.deflate(sample, args.level)
-        assert got == want, "device level-%d stream differs from the oracle's" % args.level
-        out["cpu_baseline"] = {"value": round(len(sample) / 4 / 1e6 / dtc, 3), "unit": "MPixels/s", "cores": 1, "kind": "port",
-                               "sample": f"oracle deflate level {args.level} of the first {len(sample)} scanline bytes of "
-                                         f"stream 0 (filter excluded), {dtc:.1f} s; the device stream of the same bytes is "
-                                         f"identical"}
+        assert len(z) == len(want) and hashlib.sha256(z).digest() == hashlib.sha256(want).digest(), \
+            "device level-%d stream of image 0 differs from the oracle's" % args.level
+        out["parity"] = {"stream": 0, "bytes": len(rows), "stream_bytes": len(z), "sha256": hashlib.sha256(z).hexdigest()[:16],
+                         "equals_oracle": True, "all_streams_inflate_to_their_scanlines": True}
+        out["cpu_baseline"] = {"value": round(len(rows) / 4 / 1e6 / dtc, 3), "unit": "MPixels/s", "cores": 1, "kind": "port",
+                               "sample": f"oracle deflate level {args.level} of all {len(rows)} scanline bytes of stream 0 "
+                                         f"(filter excluded), {dtc:.1f} s; the device stream of the same bytes is identical"}
         try:
             from bench import host_cores
             allc = encode_cpu_all_cores(rows, args.level, host_cores())
@@ -155,7 +158,7 @@ def run_encode(args, torch, dist, spng, s, rank, world):
     return out
 
 
-def run_encode_photographic(torch, spng, s, level=9, images=256, size=1024):
+def run_encode_photographic(torch, spng, s, level=9, images=256, size=1024, cpu=True):
     """SURVEY 8d item 3's second encode input: images with structure (swift_png_amd.synth: gradients, edges, texture -- what a
     photograph gives a PNG encoder) instead of noise.  Compressible input is where the level >= 8 search has work to do
     (DESIGN 4.5), so the rasters are 1024 x 1024: `images` streams of 4 MiB, all resident at once."""
@@ -188,7 +191,33 @@ def run_encode_photographic(torch, spng, s, level=9, images=256, size=1024):
     for j in range(unique):
         z = bytes(d_out[j * cap:j * cap + res[j].written].cpu().numpy())
         assert zlib.decompress(z) == bytes(d_rows[j * U:(j + 1) * U].cpu().numpy()), f"stream {j} does not inflate to its scanlines"
-    return {"workload": f"{images} x {w}x{h} RGBA8 synthetic photographs (swift_png_amd.synth) -> filter-select + DEFLATE level {level}",
-            "ms": round(dt * 1e3, 1), "mpixels_per_s": round(images * w * h / 1e6 / dt, 2),
-            "per_stream_mb_per_s": round(U / 1e6 / (prof["deflate"] * 1e-3), 3), "compressed_ratio": round(images * U / total_c, 3),
-            "kernels_ms": {k: round(v, 2) for k, v in prof.items()}, "inflates_to_its_scanlines": True}
+    out = {"workload": f"{images} x {w}x{h} RGBA8 synthetic photographs (swift_png_amd.synth) -> filter-select + DEFLATE level {level}",
+           "ms": round(dt * 1e3, 1), "mpixels_per_s": round(images * w * h / 1e6 / dt, 2),
+           "per_stream_mb_per_s": round(U / 1e6 / (prof["deflate"] * 1e-3), 3), "aggregate_mb_per_s": round(images * U / 1e6 / (prof["deflate"] * 1e-3), 1),
+           "compressed_ratio": round(images * U / total_c, 3),
+           "kernels_ms": {k: round(v, 2) for k, v in prof.items()}, "inflates_to_its_scanlines": True}
+    if cpu:
+        # the oracle on the same scanlines: one worker process per core, one whole 4 MiB stream each (the match search has work
+        # to do here, unlike on the random rasters of configs[3])
+        try:
+            from bench import host_cores
+            rows0 = bytes(d_rows[:U].cpu().numpy())
+            cores = host_cores()
+            import shutil
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="spng_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            try:
+                (Path(tmp) / "rows").write_bytes(rows0)
+                r = subprocess.run([sys.executable, str(ROOT / "bench_cpu.py"), "deflate", str(Path(tmp) / "rows"), str(cores), str(level), str(U)],
+                                   capture_output=True, text=True, timeout=900)
+                assert r.returncode == 0, r.stderr[-400:]
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+            out["cpu_baseline"] = {"value": round(j["tasks"] * w * h / 1e6 / j["wall_s"], 2), "unit": "MPixels/s", "cores": cores, "kind": "port",
+                                   "per_core_mb_per_s": round(U / 1e6 / j["task_s"], 3),
+                                   "sample": f"{j['tasks']} whole streams of the same scanlines ({U} bytes each), oracle deflate level {level}, one "
+                                             f"worker process per core, {j['wall_s']:.1f} s wall, {j['task_s']:.2f} s per stream"}
+        except Exception as exc:                                   # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(exc)[:200]}
+    return out

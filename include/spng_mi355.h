@@ -320,10 +320,49 @@ int32_t spng_deflate(spng_ctx *ctx, const void *src, uint64_t n, int32_t format,
                      void *dst, uint64_t cap, spng_result *result);
 int32_t spng_deflate_window(spng_ctx *ctx, const void *src, uint64_t n, int32_t format, int32_t level, int32_t exponent,
                             void *dst, uint64_t cap, spng_result *result);
+/* LZ77.Deflator.push(_:last:) for streams that arrive in pieces (Sources/LZ77/Deflator/LZ77.Deflator.swift:14-30; the reference
+ * compresses whenever more than 4096 bytes are buffered, LZ77.DeflatorBuffers.swift:68-93, and its output does not depend on how
+ * the input was pushed): d_src / src_len = ALL input bytes received so far (the caller appends to its device buffer), d_dst = the
+ * stream so far, kept between calls.  d_states[i]: spng_deflate_state_bytes() bytes of device memory per stream, zero-filled
+ * before the first push and left alone afterwards -- the device-side counterpart of LZ77.DeflatorBuffers.Stream (parse position,
+ * queued terms, symbol costs, block limit, bit writer, checksum).  last[i] != 0: this is all the input.  A call emits what the
+ * bytes so far determine: levels 0-7 every term whose positions see their whole 258-byte look-ahead, levels 8 and up every whole
+ * block (2047, 4095, ... vertices); the rest waits for the next push.  Results: SPNG_NEED_MORE_INPUT with written = stream bytes
+ * so far, consumed = input bytes parsed, aux = the host-side part of the state to hand to the next call as h_state[2 i], [2 i + 1]
+ * (levels >= 8: it sizes the call's launches; NULL / {0, 0} at the first push); SPNG_DONE with the final counts when last. */
+uint64_t spng_deflate_state_bytes(void);
+int32_t spng_deflate_resume_batch(spng_ctx *ctx, const spng_stream_desc *descs, const int32_t *levels, void *const *d_states,
+                                  const uint8_t *last, const uint64_t *h_state, uint32_t count,
+                                  spng_result *d_results, spng_result *h_results);
 /* replaces PNG.Encoder.pull end to end (PNG.Encoder.swift:33-129): storage -> zlib stream; d_rows is
  * scratch for the filtered scanlines (>= U bytes), d_idat receives the stream (capacity idat_len). */
 int32_t spng_encode_batch(spng_ctx *ctx, const spng_image_desc *descs, int32_t level, uint32_t count,
                           spng_result *d_results, spng_result *h_results);
+
+/* ---- several devices ------------------------------------------------------- */
+/* Images are independent units: a batch is cut into contiguous blocks of ceil(count / parts) -- block `index` is
+ * [*first, *first + *n) -- one per device (128 per GPU for 1024 images on 8). */
+int32_t spng_shard(uint32_t count, uint32_t parts, uint32_t index, uint32_t *first, uint32_t *n);
+/* spng_decode_batch (PNG.Context.push end to end) over n_ctx contexts, one per device of the node: descs[i]'s device
+ * pointers live on the device of the context its block belongs to (spng_shard); every context decodes its block without
+ * talking to the others.  d_gather (NULL: leave the rasters where they are): per image, where on the FIRST context's device its
+ * raster is wanted -- the one exchange step of the path; each goes as a peer-to-peer copy behind its context's decode (xGMI is
+ * point to point: the seven peers' copies ride their own links at once).  Returns when everything has arrived; results in
+ * h_results. */
+int32_t spng_decode_batch_multi(spng_ctx *const *ctxs, uint32_t n_ctx, const spng_image_desc *descs, uint32_t count,
+                                void *const *d_gather, spng_result *h_results);
+
+/* ---- measurement and housekeeping ------------------------------------------------------------------ */
+/* The copy ceiling: milliseconds per copy of `bytes` from d_src to d_dst by a kernel of this library with nothing to do in
+ * between (HIP events on the context's stream, `repeats` copies after a first touch).  pattern 0: 16 bytes per lane,
+ * grid-stride -- the denominator next to the 8 TB/s spec peak.  pattern 1: 64 rows of 16384 bytes per wave in 256-byte tiles,
+ * row r trailing row r - 1 by 4 bytes on both sides -- the access pattern of the scanline kernel before its stores were made
+ * line-aligned: what that cost, and a known byte count in that pattern to calibrate FETCH_SIZE / WRITE_SIZE against. */
+int32_t spng_copy_ceiling(spng_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes, int32_t pattern, int32_t repeats,
+                          double *ms_per_copy);
+/* Gives the context's scratch back to the device (token pool, symbol scratch, deflate slab and rings): the next call that
+ * needs one allocates it again.  Waits for the context's work first. */
+int32_t spng_trim(spng_ctx *ctx);
 
 #ifdef __cplusplus
 }

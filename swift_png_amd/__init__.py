@@ -52,6 +52,7 @@ EXPORTS = [
     "spng_unfilter_resume_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
     "spng_lex_batch", "spng_write_idat_batch", "spng_crc32", "spng_unpack_batch", "spng_unpack", "spng_unpack_as", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
+    "spng_shard", "spng_decode_batch_multi", "spng_copy_ceiling", "spng_trim", "spng_deflate_state_bytes", "spng_deflate_resume_batch",
 ]
 
 
@@ -222,6 +223,13 @@ def load_library():
     lib.spng_deflate.argtypes = [vp, vp, u64, i32, i32, vp, u64, rp]
     lib.spng_deflate_window.argtypes = [vp, vp, u64, i32, i32, i32, vp, u64, rp]
     lib.spng_encode_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), i32, u32, vp, rp]
+    lib.spng_deflate_state_bytes.restype = u64
+    lib.spng_deflate_resume_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), ctypes.POINTER(i32), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_uint8),
+                                              ctypes.POINTER(u64), u32, vp, rp]
+    lib.spng_shard.argtypes = [u32, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    lib.spng_decode_batch_multi.argtypes = [ctypes.POINTER(vp), u32, ctypes.POINTER(ImageDesc), u32, ctypes.POINTER(vp), rp]
+    lib.spng_copy_ceiling.argtypes = [vp, vp, vp, u64, i32, i32, ctypes.POINTER(ctypes.c_double)]
+    lib.spng_trim.argtypes = [vp]
     for name in EXPORTS:
         getattr(lib, name)
     _lib = lib
@@ -236,6 +244,30 @@ def load(device: int = 0) -> "Session":
     if device not in _sessions:
         _sessions[device] = Session(device)
     return _sessions[device]
+
+
+def shard_of(count: int, parts: int, index: int):
+    """(first, n) of block `index` when `count` images are cut into `parts` contiguous blocks (spng_shard)"""
+    first, n = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    lib = load_library()
+    _check(lib, lib.spng_shard(count, parts, index, ctypes.byref(first), ctypes.byref(n)))
+    return first.value, n.value
+
+
+def decode_batch_multi(sessions, descs, gather=None):
+    """spng_decode_batch_multi: `descs` (ImageDesc, device pointers on the device of each block's session) decoded by the
+    sessions' contexts, block k by sessions[k]; gather: per image a device pointer on sessions[0]'s device (or 0 / None)
+    where its raster is wanted.  -> list[Result]"""
+    lib = load_library()
+    n = len(descs)
+    arr = descs if isinstance(descs, ctypes.Array) else (ImageDesc * n)(*descs)
+    ctxs = (ctypes.c_void_p * len(sessions))(*[s.ctx for s in sessions])
+    res = (Result * n)()
+    g = None
+    if gather is not None:
+        g = (ctypes.c_void_p * n)(*[int(x) if x else None for x in gather])
+    _check(lib, lib.spng_decode_batch_multi(ctxs, len(sessions), arr, n, g, res))
+    return list(res)
 
 
 def inflated_size(w, h, depth, channels, interlaced) -> int:
@@ -286,6 +318,21 @@ class Session:
 
     def profile(self, enable=True):
         _check(self.lib, self.lib.spng_profile(self.ctx, int(enable)))
+
+    def trim(self):
+        """gives the context's scratch (token pool, deflate slab ...) back to the device"""
+        _check(self.lib, self.lib.spng_trim(self.ctx))
+
+    def copy_ceiling(self, nbytes=8 << 30, pattern=0, repeats=5):
+        """GB/s (read + write) of the library's own copy kernel between two buffers of nbytes: the measured ceiling next to the
+        8 TB/s spec peak (pattern 0), or the bandwidth of the scanline kernel's former access pattern (pattern 1)"""
+        t = self.torch
+        a = t.zeros(nbytes // 8, dtype=t.int64, device=self.tdev)
+        b = t.empty(nbytes // 8, dtype=t.int64, device=self.tdev)
+        ms = ctypes.c_double(0)
+        _check(self.lib, self.lib.spng_copy_ceiling(self.ctx, b.data_ptr(), a.data_ptr(), nbytes, pattern, repeats, ctypes.byref(ms)))
+        del a, b
+        return 2 * nbytes / (ms.value * 1e-3) / 1e9, ms.value
 
     def profile_get(self, kernel):
         ms, n = ctypes.c_double(0), ctypes.c_uint64(0)
@@ -481,6 +528,20 @@ class Session:
         if res.status != DONE:
             raise SpngError(res.status)
         return bytes(dst[:res.written])
+
+    def deflate_resume(self, src, src_len, dst, level, state, last, fmt=FORMAT_ZLIB, exponent=15, hstate=(0, 0)):
+        """One push of a stream that is compressed as it arrives (spng_deflate_resume_batch): src holds ALL input so far, dst the
+        stream so far, state: a zero-initialised device tensor of spng_deflate_state_bytes() bytes kept between the calls, hstate
+        what the previous call returned.  -> (Result, next hstate)"""
+        desc = (StreamDesc * 1)(StreamDesc(self._ptr(src), int(src_len), self._ptr(dst), dst.numel(), fmt, exponent))
+        lv = (ctypes.c_int32 * 1)(level)
+        st = (ctypes.c_void_p * 1)(state.data_ptr())
+        la = (ctypes.c_uint8 * 1)(1 if last else 0)
+        hs = (ctypes.c_uint64 * 2)(int(hstate[0]), int(hstate[1]))
+        res = (Result * 1)()
+        _check(self.lib, self.lib.spng_deflate_resume_batch(self.ctx, desc, lv, st, la, hs, 1, None, res))
+        r = res[0]
+        return r, (r.aux[0], r.aux[1])
 
     def deflate_batch(self, streams, level, fmt=FORMAT_ZLIB):
         """streams: list of uint8 device tensors -> (list of output tensors, list[Result])"""

@@ -1558,8 +1558,8 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
     const size_t sslot = a.take(nfull * sizeof(D2Stream)), tslot = a.take(nfull * sizeof(D2State)), fslot = a.take((nfull + 1) * 4);
     D2Stream *hs = a.host<D2Stream>(sslot);
     D2State *ht = a.host<D2State>(tslot);
-    memset(ht, 0, nfull * sizeof(D2State));
-    uint32_t max_rounds = 0;
+    memset(ht, 0, nfull * sizeof(D2State));                    // (a zeroed state = a stream's beginning: dfl2_begin_kernel)
+    std::vector<uint32_t> rounds_of(nfull, 1);
     for (size_t g = 0; g < groups.size(); ++g) {
         char *base = (char *)c->d_graph;
         uint64_t at = 0;
@@ -1569,27 +1569,14 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
             D2Stream &s = hs[i - first];
             const uint64_t V = deflate2_vertices(j.src_len), B = V / 64 + 2;
             s.src = j.src; s.dst = j.dst; s.src_len = j.src_len; s.dst_cap = j.dst_cap; s.format = j.format; s.level = j.level;
-            s.image = j.image; s.exponent = j.exponent;
-            s.state = a.dev<D2State>(tslot) + (i - first);
+            s.image = j.image; s.exponent = j.exponent; s.more = j.more; s.pad = 0;
+            // (spng_deflate_resume_batch: the caller's state, kept from push to push; else the call's own)
+            s.state = j.state ? (D2State *)j.state : a.dev<D2State>(tslot) + (i - first);
             s.vinfo = (uint16_t *)take(2 * V); s.bbase = (uint64_t *)take(8 * B); s.bwords = (uint32_t *)take(4 * B); s.emask = (uint64_t *)take(8 * B);
             s.up = (uint32_t *)take(4 * (V + 2)); s.step = (uint32_t *)take(4 * (V + 2)); s.pathb = (uint8_t *)take(V + 2); s.litb = (uint8_t *)take(B);
-            D2State &t = ht[i - first];
-            t.rb = 0; t.limit = 2048; t.generic = 1;
-            t.re = j.src_len < 3 ? j.src_len : 0;
-            if (j.src_len >= 3) {
-                // (= d2_round_end(0, 2048, n): the blocks below the cap fit one round)
-                uint64_t end = 0; uint32_t lim = 2048;
-                for (;;) {
-                    const uint64_t room = j.src_len - end, size = (uint64_t)(lim - 1) < room ? (uint64_t)(lim - 1) : room;
-                    if (end > 0 && end + size > (1u << 21)) break;
-                    end += size;
-                    if (end == j.src_len) break;
-                    lim = 2 * lim < (1u << 21) ? 2 * lim : 1u << 21;
-                }
-                t.re = end;
-            }
-            const uint32_t r = deflate2_rounds(j.src_len);
-            max_rounds = r > max_rounds ? r : max_rounds;
+            uint64_t pos = j.state ? j.plan_pos : 0;
+            uint32_t lim = j.state && j.plan_limit ? j.plan_limit : 2048;
+            rounds_of[i - first] = deflate2_plan(j.src_len, j.more != 0, pos, lim);
         }
     }
     if (int32_t st = c->upload(sslot, tslot + nfull * sizeof(D2State))) return st;
@@ -1601,7 +1588,8 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
         char *pool = rings + l.rings;
         unsigned long long *pool_next = (unsigned long long *)(pool + l.pool);
         uint32_t rounds = 0;
-        for (size_t i = groups[g].first; i < groups[g].second; ++i) { const uint32_t r = deflate2_rounds(sorted[i].src_len); rounds = r > rounds ? r : rounds; }
+        for (size_t i = groups[g].first; i < groups[g].second; ++i) rounds = rounds_of[i - first] > rounds ? rounds_of[i - first] : rounds;
+        HIP_TRY(launch_deflate2_begin(a.dev<D2Stream>(sslot) + (groups[g].first - first), cnt, c->stream));
         for (uint32_t r = 0; r < rounds; ++r) {
             { Timed t(c, SPNG_K_DFL_SEARCH); HIP_TRY(launch_deflate2_search(a.dev<D2Stream>(sslot) + (groups[g].first - first), cnt, l.cps, l.chunk, (uint32_t *)pool,
                                                                             pool_next, l.pool / 4, (uint32_t *)rings, c->stream)); }
@@ -1613,6 +1601,12 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
     std::vector<uint32_t> failed(nfull + 1, 0);
     HIP_TRY(hipMemcpyAsync(failed.data(), d_failed, (nfull + 1) * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < nfull; ++i) if (failed[1 + i] == 1 && sorted[first + i].more) { failed[1 + i] = 0; failed[0] -= 1; }   // (a push that is not the last is never "finished")
+    for (size_t i = 0; i < nfull; ++i)
+        if (failed[1 + i] && sorted[first + i].state) {
+            snprintf(g_err, sizeof g_err, "spng_deflate_resume_batch: the candidate pool ran dry under stream %u (raise SPNG_CFG_DEFLATE_BYTES)", sorted[first + i].image);
+            return SPNG_E_DEVICE;
+        }
     if (failed[0]) {
         std::vector<DeflateJob> again;
         for (size_t i = 0; i < nfull; ++i) if (failed[1 + i]) again.push_back(sorted[first + i]);
@@ -1635,7 +1629,8 @@ static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_r
     for (auto &j : jobs) if (j.level < 8) sorted.push_back(j);
     const size_t nfast = sorted.size();
     for (auto &j : jobs) if (j.level >= 8) sorted.push_back(j);
-    const bool legacy = c->cfg[SPNG_CFG_DEFLATE_MODE] == SPNG_DEFLATE_ONE_KERNEL;
+    bool legacy = c->cfg[SPNG_CFG_DEFLATE_MODE] == SPNG_DEFLATE_ONE_KERNEL;
+    for (auto &j : jobs) if (j.state) legacy = false;          // (streams that arrive in pieces: only the two-kernel search keeps a state)
     const size_t nring = nfast;
     const size_t ring_bytes = nring * 65536 * 4;
     if (ring_bytes > c->ring_cap) {
@@ -1693,6 +1688,44 @@ int32_t spng_deflate_batch(spng_ctx *c, const spng_stream_desc *descs, const int
     return SPNG_DONE;
 }
 
+uint64_t spng_deflate_state_bytes(void) { return deflate_state_bytes(); }
+
+int32_t spng_deflate_resume_batch(spng_ctx *c, const spng_stream_desc *descs, const int32_t *levels, void *const *d_states, const uint8_t *last,
+                                  const uint64_t *h_state, uint32_t count, spng_result *d_results, spng_result *h_results)
+{
+    if (!c || (!descs && count) || !levels || !d_states || !last) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    std::vector<DeflateJob> jobs(count);
+    bool gzip = false;
+    for (uint32_t i = 0; i < count; ++i) {
+        const int32_t e = descs[i].reserved ? descs[i].reserved : 15;
+        if ((!descs[i].d_src && descs[i].src_len) || !descs[i].d_dst || !d_states[i] || e < 8 || e > 15 || descs[i].format < SPNG_FORMAT_ZLIB ||
+            descs[i].format > SPNG_FORMAT_GZIP) return SPNG_E_ARGUMENT;
+        gzip = gzip || descs[i].format == SPNG_FORMAT_GZIP;
+        DeflateJob j{};
+        j.src = (const uint8_t *)descs[i].d_src; j.dst = (uint8_t *)descs[i].d_dst; j.src_len = descs[i].src_len; j.dst_cap = descs[i].dst_cap;
+        j.format = descs[i].format; j.level = levels[i]; j.image = i; j.exponent = descs[i].format == SPNG_FORMAT_IOS ? 15u : (uint32_t)e;
+        j.more = last[i] ? 0u : 1u; j.state = (D1State *)d_states[i];
+        if (h_state) { j.plan_pos = h_state[2 * i]; j.plan_limit = (uint32_t)h_state[2 * i + 1]; }
+        if (j.plan_pos > j.src_len) return SPNG_E_ARGUMENT;     // (a state is only ever what an earlier call handed out)
+        jobs[i] = j;
+    }
+    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + sizeof(D2Stream) + sizeof(D2State) + 16 + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 8192)) return st;
+    Arena a{c};
+    const size_t jslot = a.take(count * sizeof(DeflateJob));
+    const size_t res = a.take(count * sizeof(spng_result));
+    const size_t gzparts = gzip ? a.take((size_t)count * 4 * gzip_pieces()) : (size_t)-1;
+    spng_result *dr = d_results ? d_results : a.dev<spng_result>(res);
+    if (int32_t st = deflate_launch(c, jobs, dr, a, jslot, gzparts)) return st;
+    if (h_results) {
+        HIP_TRY(hipMemcpyAsync(h_results, dr, count * sizeof(spng_result), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SPNG_DONE;
+}
+
 int32_t spng_deflate(spng_ctx *c, const void *src, uint64_t n, int32_t format, int32_t level,
                      void *dst, uint64_t cap, spng_result *result)
 {
@@ -1730,6 +1763,99 @@ int32_t spng_encode_batch(spng_ctx *c, const spng_image_desc *descs, int32_t lev
                                  (void *)d.d_idat, d.idat_len, d.format, 0};
     }
     return spng_deflate_batch(c, sd.data(), lv.data(), count, d_results, h_results);
+}
+
+
+// ---- measurement and housekeeping --------------------------------------------------------------------------------
+int32_t spng_copy_ceiling(spng_ctx *c, void *d_dst, const void *d_src, uint64_t bytes, int32_t pattern, int32_t repeats, double *ms_per_copy)
+{
+    if (!c || !d_dst || !d_src || bytes < 65536 || pattern < 0 || pattern > 1 || repeats < 1 || !ms_per_copy) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    hipEvent_t e0 = c->event(), e1 = c->event();
+    HIP_TRY(launch_copy_probe(d_src, d_dst, bytes, pattern, c->stream));      // (first touch)
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    for (int32_t i = 0; i < repeats; ++i) HIP_TRY(launch_copy_probe(d_src, d_dst, bytes, pattern, c->stream));
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    c->pool.push_back(e0); c->pool.push_back(e1);
+    *ms_per_copy = (double)ms / repeats;
+    return SPNG_DONE;
+}
+
+int32_t spng_trim(spng_ctx *c)
+{
+    if (!c) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->stream2) HIP_TRY(hipStreamSynchronize(c->stream2));
+    void **bufs[] = {&c->d_ring, &c->d_ring2, &c->d_graph, &c->d_log, &c->d_tok, &c->d_sym, &c->d_win};
+    size_t *caps[] = {&c->ring_cap, &c->ring2_cap, &c->graph_cap, &c->log_cap, &c->tok_cap, &c->sym_cap, &c->win_cap};
+    for (int i = 0; i < 7; ++i) {
+        if (*bufs[i]) HIP_TRY(hipFree(*bufs[i]));
+        *bufs[i] = nullptr; *caps[i] = 0;
+    }
+    c->pool_ratio = 0;                                         // (what the token pool had learned went with it)
+    return SPNG_DONE;
+}
+
+// spng_decode_batch over several devices: contiguous blocks of ceil(count / n_ctx) images per context,
+// no communication while decoding; then, where d_gather names a destination on the FIRST context's device, every raster of the
+// other contexts leaves for it as a peer-to-peer copy behind its context's decode (xGMI: one link per peer, all at once).
+int32_t spng_shard(uint32_t count, uint32_t parts, uint32_t index, uint32_t *first, uint32_t *n)
+{
+    if (!parts || index >= parts || !first || !n) return SPNG_E_ARGUMENT;
+    const uint32_t per = (count + parts - 1) / parts;
+    const uint64_t lo = (uint64_t)per * index;
+    *first = lo < count ? (uint32_t)lo : count;
+    *n = lo >= count ? 0u : (count - lo < per ? count - (uint32_t)lo : per);
+    return SPNG_DONE;
+}
+
+int32_t spng_decode_batch_multi(spng_ctx *const *ctxs, uint32_t n_ctx, const spng_image_desc *descs, uint32_t count, void *const *d_gather,
+                                spng_result *h_results)
+{
+    if (!ctxs || !n_ctx || (!descs && count) || !h_results) return SPNG_E_ARGUMENT;
+    for (uint32_t k = 0; k < n_ctx; ++k) if (!ctxs[k]) return SPNG_E_ARGUMENT;
+    if (!count) return SPNG_DONE;
+    // every context's shard is enqueued (asynchronous calls: results stay on the devices), then its rasters' way to the root
+    std::vector<spng_result *> d_res(n_ctx, nullptr);
+    int32_t status = SPNG_DONE;
+    for (uint32_t k = 0; k < n_ctx && status == SPNG_DONE; ++k) {
+        uint32_t first = 0, n = 0;
+        (void)spng_shard(count, n_ctx, k, &first, &n);
+        if (!n) continue;
+        spng_ctx *c = ctxs[k];
+        if (hipSetDevice(c->device) != hipSuccess) { status = SPNG_E_DEVICE; break; }
+        if (hipMalloc((void **)&d_res[k], (size_t)n * sizeof(spng_result)) != hipSuccess) { (void)hipGetLastError(); status = SPNG_E_DEVICE; break; }
+        status = spng_decode_batch(c, descs + first, n, d_res[k], nullptr);
+        if (status != SPNG_DONE) break;
+        if (d_gather) {
+            for (uint32_t i = first; i < first + n; ++i) {
+                if (!d_gather[i] || d_gather[i] == descs[i].d_storage) continue;
+                const uint64_t s = spng_storage_size(descs[i].width, descs[i].height, descs[i].depth, descs[i].channels);
+                const hipError_t e = hipMemcpyPeerAsync(d_gather[i], ctxs[0]->device, descs[i].d_storage, c->device, s, c->stream);
+                if (e != hipSuccess) { status = fail_hip(e, "hipMemcpyPeerAsync"); break; }
+            }
+        }
+    }
+    for (uint32_t k = 0; k < n_ctx; ++k) {
+        uint32_t first = 0, n = 0;
+        (void)spng_shard(count, n_ctx, k, &first, &n);
+        if (!d_res[k]) continue;
+        (void)hipSetDevice(ctxs[k]->device);
+        if (status == SPNG_DONE) {
+            const hipError_t e = hipMemcpyAsync(h_results + first, d_res[k], (size_t)n * sizeof(spng_result), hipMemcpyDeviceToHost, ctxs[k]->stream);
+            if (e != hipSuccess) status = fail_hip(e, "hipMemcpyAsync");
+        }
+        const hipError_t e = hipStreamSynchronize(ctxs[k]->stream);
+        if (e != hipSuccess && status == SPNG_DONE) status = fail_hip(e, "hipStreamSynchronize");
+        (void)hipFree(d_res[k]);
+    }
+    return status;
 }
 
 }  // extern "C"

@@ -154,7 +154,21 @@ struct DeflateJob {
     uint32_t       image;
     uint32_t       exponent;      // window = 2^exponent (LZ77.Deflator(exponent:); PNG: 15)
     uint32_t      *graph;         // levels >= 8: match-graph scratch (deflate_graph_bytes)
-    uint32_t       graph_vertices, pad;
+    uint32_t       graph_vertices;
+    uint32_t       more;          // spng_deflate_resume_batch: more input will follow (src_len is what arrived so far)
+    struct D1State *state;        // ... and where the stream keeps itself between pushes (levels 0-7: a D1State, 8 and up: a D2State; null: one-shot)
+    uint64_t       plan_pos;      // (host side, levels >= 8: where the previous push left the parse, and its block limit)
+    uint32_t       plan_limit, pad2;
+};
+
+// Greedy / lazy kernel between two pushes (spng_deflate_resume_batch, levels 0-7): the parse position, the terms queued for the
+// block being filled, the bit writer, the Adler sums.  The hash window is not kept: the next push enters the last 32 KiB again.
+struct D1State {
+    uint64_t w, inserted;         // first unparsed position; positions below `inserted` are in the Adler sums
+    uint64_t acc, total;          // the bit writer: pending bits, bytes produced
+    uint32_t nacc, overflow, count, started;
+    uint32_t adlerS, adlerI, pad[2];
+    uint32_t terms[2048];
 };
 
 // levels >= 8, the two-kernel form (deflate.hip, "round 4"): what the search and the parse kernel share per stream.
@@ -167,12 +181,15 @@ struct D2State {                  // device side, kept from round to round; arri
     uint32_t adlerS, adlerI;      // Adler-32 partial sums of the chunks searched so far (mod 65521 each time)
     uint32_t fail, done;          // the pool ran dry under this stream (the one-kernel search takes it afterwards); finished
     uint8_t  depths[544];         // LZ77.DeflatorMatches.Depths between blocks
+    uint32_t started, pad;        // (a state arrives zeroed: the first round of the first call sets the block limit)
 };
 struct D2Stream {
     const uint8_t *src; uint8_t *dst;
     uint64_t src_len, dst_cap;
     int32_t  format, level;
     uint32_t image, exponent;
+    uint32_t more, pad;           // spng_deflate_resume_batch: more input will follow -- only blocks whose every vertex has its whole
+                                  // look-ahead (258 bytes, + 3 for the key) are taken now
     D2State *state;
     // scratch, round coordinates (vertex = position - rb): per vertex candidates << 9 | longest run; per batch of 64 the first
     // word of its list in the pool and words | longest run << 16; block coordinates: which vertices keep their edges, the
@@ -188,6 +205,7 @@ int passes(uint32_t w, uint32_t h, int volume, int interlaced, Pass out[7]);
 // kernel launchers (each returns the hipError_t of the launch)
 hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, spng_result *d_results,
                            uint32_t pieces, uint32_t piece_rows, hipStream_t stream);
+hipError_t launch_copy_probe(const void *d_src, void *d_dst, uint64_t bytes, int pattern, hipStream_t stream);
 hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32_t *d_job_image,
                           const spng_result *d_results, uint32_t blocks_x, hipStream_t stream);
 hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results,
@@ -218,6 +236,9 @@ hipError_t launch_resume_post(const InflateJob *d_jobs, spng_result *d_results, 
 hipError_t launch_deflate_full(const DeflateJob *d_jobs, uint32_t count, bool helpers, spng_result *d_results, hipStream_t stream);
 hipError_t launch_deflate_density(const DeflateJob *d_jobs, uint32_t count, uint32_t *d_dense, hipStream_t stream);
 uint32_t deflate2_rounds(uint64_t n);
+uint64_t deflate_state_bytes();
+uint32_t deflate2_plan(uint64_t n, bool more, uint64_t &pos, uint32_t &lim);
+hipError_t launch_deflate2_begin(const D2Stream *d_streams, uint32_t count, hipStream_t stream);
 uint64_t deflate2_vertices(uint64_t n);
 hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t *d_pool, unsigned long long *d_pool_next,
                                   uint64_t pool_words, uint32_t *d_rings, hipStream_t stream);

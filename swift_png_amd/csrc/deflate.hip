@@ -645,7 +645,23 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     Bits b = {0, 0, 0, 0, job.dst, job.dst_cap, false};
     const uint32_t wmask = (1u << UNI(jp->exponent)) - 1;    // window 2^exponent (LZ77.Deflator(exponent:); PNG: 15)
-    if (job.format == SPNG_FORMAT_ZLIB) {
+    // spng_deflate_resume_batch: the stream arrives in pieces.  `more`: src_len is what has arrived so far; st1: where the
+    // previous push left off (parse position, queued terms, bit writer, Adler sums)
+    const bool more = UNI(jp->more) != 0;
+    D1State *st1 = (D1State *)uni64((uint64_t)jp->state);
+    const bool resumed = st1 && UNI(st1->started);
+    if (resumed) { b.acc = uni64(st1->acc); b.nacc = UNI(st1->nacc); b.total = b.flushed = uni64(st1->total); b.overflow = UNI(st1->overflow) != 0; }
+    if (n < 3 && more) {
+        // (nothing can be decided yet: not even whether this will be a stored tail)
+        if (lane == 0) {
+            spng_result &res = results[job.image];
+            res.status = SPNG_NEED_MORE_INPUT; res.reserved = 0; res.written = b.total; res.consumed = resumed ? uni64(st1->w) : 0;
+            res.aux[0] = res.consumed; res.aux[1] = 0;
+        }
+        return;
+    }
+    if (resumed) {}
+    else if (job.format == SPNG_FORMAT_ZLIB) {
         // StreamHeader.write (StreamHeader.swift:56-62)
         const uint32_t unpaired = (UNI(jp->exponent) - 8) << 4 | 0x08;
         const uint32_t check = ~(((unpaired << 8 | unpaired >> 8) & 0xffff) % 31) & 31;
@@ -663,6 +679,13 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
     int count = 0;                                             // queued terms
     const int limit_terms = 2048;
     auto unfilled = [&]() { return limit_terms - 1 - count; };
+    uint64_t w0 = 0, summed = 0;                               // where the parse goes on; positions below `summed` are in the sums already
+    if (resumed) {
+        w0 = uni64(st1->w); summed = uni64(st1->inserted); count = (int)UNI(st1->count);
+        for (int i = lane; i < count; i += 64) g_sea.terms[i] = st1->terms[i];
+        if (lane == 0) { accS = st1->adlerS; accI = st1->adlerI; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    }
 
     if (n < 3) {
         // Stream.compressBlocks stored tail (:45-60, :417-434)
@@ -673,19 +696,21 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         if ((uint64_t)lane < n) { accS = in[lane]; accI = (uint32_t)lane * in[lane]; }
     } else {
         const uint64_t last_main = n - 4 + 1;                  // positions 0 .. n-4 are searched
-        uint64_t inserted = 0;                                 // positions < inserted are in the window
-        uint64_t w = 0;                                        // parse position
-        uint32_t key_next = load_key(in, n, (uint64_t)lane);      // (keys travel one batch ahead of their insertion)
+        // (a resumed stream: the 32 KiB in front of the parse position enter the window again)
+        uint64_t inserted = (w0 >= 32768 ? w0 - 32768 : 0) & ~(uint64_t)63;    // positions < inserted are in the window
+        uint64_t w = w0;                                       // parse position
+        uint32_t key_next = load_key(in, n, inserted + (uint64_t)lane);      // (keys travel one batch ahead of their insertion)
         auto insert_upto = [&](uint64_t target) {
             while (inserted < target && inserted < n) {
                 const uint32_t key = key_next;
                 key_next = load_key(in, n, inserted + 64 + lane);
-                insert_batch(g_sea.head, in, n, ring, inserted, key, accS, accI, lane);
+                insert_batch(g_sea.head, in, n, ring, inserted, key, accS, accI, lane, inserted + lane >= summed);
                 inserted = uni64(inserted + 64);
             }
         };
 
-        while (w < last_main) {
+        // (more input to come: a batch of 128 positions is only searched when each of them sees its whole look-ahead)
+        while (w < last_main && (!more || w + 128 + 259 <= n)) {
             // keep the window filled well ahead of the 64 positions searched now (+258 of look-ahead
             // is irrelevant for insertion: links only point backwards)
             DPROF_BEGIN();
@@ -741,6 +766,23 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
             }
             w = uni64(w + t);
             DPROF_END(2);
+        }
+        if (more) {
+            // on with the next push: whole bytes out, the rest into the state
+            drain(s, b, b.total, lane);
+            uint32_t S = accS % 65521, I = accI % 65521;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { S += __shfl_xor(S, m, 64); I += __shfl_xor(I, m, 64); }
+            for (int i = lane; i < count; i += 64) st1->terms[i] = g_sea.terms[i];
+            if (lane == 0) {
+                st1->w = w; st1->inserted = inserted > summed ? inserted : summed; st1->acc = b.acc; st1->nacc = b.nacc; st1->total = b.total;
+                st1->overflow = b.overflow ? 1u : 0u; st1->count = (uint32_t)count; st1->started = 1;
+                st1->adlerS = S % 65521; st1->adlerI = I % 65521;
+                spng_result &res = results[job.image];
+                res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_NEED_MORE_INPUT; res.reserved = 0;
+                res.written = b.total; res.consumed = w; res.aux[0] = w; res.aux[1] = 0;
+            }
+            return;
         }
         insert_upto(n);                                        // Adler-32 over the tail
         // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
@@ -1374,35 +1416,47 @@ struct D2ALds {                                                 // (search kerne
 };
 __shared__ __attribute__((aligned(16))) D2ALds g_a;
 
-__host__ __device__ inline uint64_t d2_round_end(uint64_t pos, uint32_t limit, uint64_t n)
+__host__ __device__ inline uint64_t d2_round_end(uint64_t pos, uint32_t limit, uint64_t n, bool more = false)
 {
-    // the blocks of a round: as many whole blocks from `pos` on as fit D2_RV vertices (at least one)
+    // the blocks of a round: as many whole blocks from `pos` on as fit D2_RV vertices (at least one).  more: the input goes on
+    // behind n -- a block is only taken when it is full AND all of its vertices can see their whole look-ahead (none otherwise).
+    const uint64_t upto = more ? (n > 261 ? n - 261 : 0) : n;
     uint64_t end = pos;
     uint32_t lim = limit;
     for (;;) {
-        const uint64_t room = n - end, size = (uint64_t)(lim - 1) < room ? (uint64_t)(lim - 1) : room;
+        const uint64_t room = upto > end ? upto - end : 0, size = (uint64_t)(lim - 1) < room ? (uint64_t)(lim - 1) : room;
+        if (more && size < (uint64_t)(lim - 1)) break;
         if (end > pos && end - pos + size > D2_RV) break;
         end += size;
-        if (end == n) break;
+        if (!more && end == n) break;
         lim = 2 * lim < (1u << 21) ? 2 * lim : 1u << 21;
     }
     return end;
 }
+// rounds a call takes from (pos, limit) on, and where it leaves them
+uint32_t deflate2_plan(uint64_t n, bool more, uint64_t &pos, uint32_t &lim)
+{
+    if (!more && n < 3) { pos = n; return 1; }
+    uint32_t rounds = 0;
+    for (;;) {
+        const uint64_t end = d2_round_end(pos, lim, n, more);
+        if (end == pos) break;
+        for (uint64_t at = pos; at < end;) {                    // (the limit as the blocks of the round leave it)
+            const uint64_t size = (uint64_t)(lim - 1) < end - at ? (uint64_t)(lim - 1) : end - at;
+            at += size;
+            if (more || at < n) lim = 2 * lim < (1u << 21) ? 2 * lim : 1u << 21;
+        }
+        pos = end; ++rounds;
+        if (!more && pos >= n) break;
+    }
+    return rounds ? rounds : 1;                                 // (one launch at least: it reports where the stream stands)
+}
 uint32_t deflate2_rounds(uint64_t n)
 {
-    if (n < 3) return 1;
-    uint32_t rounds = 0, lim = 2048;
-    for (uint64_t pos = 0; pos < n; ++rounds) {
-        const uint64_t end = d2_round_end(pos, lim, n);
-        for (uint64_t at = pos; at < end;) {                    // (the limit as the blocks of the round leave it)
-            const uint64_t size = (uint64_t)(lim - 1) < n - at ? (uint64_t)(lim - 1) : n - at;
-            at += size;
-            if (at < n) lim = 2 * lim < (1u << 21) ? 2 * lim : 1u << 21;
-        }
-        pos = end;
-    }
-    return rounds;
+    uint64_t pos = 0; uint32_t lim = 2048;
+    return deflate2_plan(n, false, pos, lim);
 }
+uint64_t deflate_state_bytes() { return ((sizeof(D1State) > sizeof(D2State) ? sizeof(D1State) : sizeof(D2State)) + 255) & ~(uint64_t)255; }
 uint64_t deflate2_vertices(uint64_t n) { return ((n < D2_RV ? n : D2_RV) + 63) / 64 * 64 + 128; }
 
 // LZ77.DeflatorWindow.match (:132-212) for one position per lane (chain_walk2 without its second half: here the latency of a
@@ -2036,6 +2090,7 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
     g.pool = pool;
     const int lv = (int)UNI(sp->level) > 13 ? 13 : (int)UNI(sp->level);
     const int iterations = lv - 7;
+    const bool more = UNI(sp->more) != 0;                      // spng_deflate_resume_batch: the input goes on behind src_len
 #ifdef SPNG_DEFLATE_PROF
     if (lane < 12) g_prof[lane] = lane == 11 ? __builtin_readcyclecounter() : 0;
 #endif
@@ -2066,7 +2121,8 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 
     uint32_t tailS = 0, tailI = 0;
-    if (n < 3) {
+    if (n < 3 && more) {}                                      // (nothing can be decided yet)
+    else if (n < 3) {
         // Stream.compressBlocks stored tail (:45-60, :417-434)
         put(s, b, 1, 3, lane);
         if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
@@ -2078,14 +2134,14 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
         while (pos < re) {
             const uint64_t room = n - pos;
             const uint32_t count = (uint64_t)(limit - 1) < room ? limit - 1 : (uint32_t)room;
-            const bool final = pos + count == n;
+            const bool final = !more && pos + count == n;
             b = d2_block(b, g, in, pos, pos - rb, count, limit - 1, final, iterations, generic, lane);
             generic = false;
             pos += count;
             if (!final) limit = 2 * limit < (1u << 21) ? 2 * limit : 1u << 21;     // trees(iterations:) :229
         }
     }
-    if (pos >= n) {
+    if (!more && pos >= n) {
         if (format == SPNG_FORMAT_ZLIB) {
             // Adler-32 from the sums the search kernel left (s1 = 1 + S, s2 = N + N * S - I)
             uint32_t S, I;
@@ -2128,7 +2184,11 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
     if (lane == 0) {
         state->acc = b.acc; state->nacc = b.nacc; state->total = b.total; state->overflow = b.overflow ? 1u : 0u;
         state->pos = pos; state->limit = limit; state->generic = generic ? 1u : 0u;
-        state->rb = pos; state->re = d2_round_end(pos, limit, n);
+        state->rb = pos; state->re = d2_round_end(pos, limit, n, more);
+        // (where the stream stands: the answer of a push that did not carry its end; overwritten by the round that finishes it)
+        spng_result &res = results[UNI(sp->image)];
+        res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_NEED_MORE_INPUT; res.reserved = 1;
+        res.written = b.total; res.consumed = pos; res.aux[0] = pos; res.aux[1] = limit;
     }
 }
 
@@ -2136,7 +2196,7 @@ __global__ void dfl2_failed_kernel(const D2Stream *__restrict__ streams, uint32_
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const uint32_t f = streams[i].state->done ? 0u : 1u;       // (not finished: the pool ran dry under it)
+    const uint32_t f = streams[i].state->fail ? 2u : streams[i].state->done ? 0u : 1u;     // 2: the pool ran dry under it; 1: not finished
     failed[1 + i] = f;
     if (f) atomicAdd(&failed[0], 1u);
 }
@@ -2145,6 +2205,25 @@ hipError_t launch_deflate2_failed(const D2Stream *d_streams, uint32_t count, uin
     hipError_t e = hipMemsetAsync(d_failed, 0, 4, stream);
     if (e != hipSuccess) return e;
     dfl2_failed_kernel<<<(count + 255) / 256, 256, 0, stream>>>(d_streams, count, d_failed);
+    return hipGetLastError();
+}
+
+// The first round of a call: a state that arrives zeroed is a stream's beginning; the round = the blocks the input allows now.
+__global__ void dfl2_begin_kernel(const D2Stream *__restrict__ streams, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const D2Stream &st = streams[i];
+    D2State &t = *st.state;
+    if (!t.started) { t.started = 1; t.pos = 0; t.limit = 2048; t.generic = 1; }
+    t.fail = 0;
+    t.rb = t.pos;
+    t.re = st.src_len < 3 ? t.pos : d2_round_end(t.pos, t.limit, st.src_len, st.more != 0);
+}
+hipError_t launch_deflate2_begin(const D2Stream *d_streams, uint32_t count, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    dfl2_begin_kernel<<<(count + 255) / 256, 256, 0, stream>>>(d_streams, count);
     return hipGetLastError();
 }
 

@@ -656,6 +656,50 @@ hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, s
 }
 
 // ---------------------------------------------------------------------------------------------
+// The copy ceiling (spng_copy_ceiling): what a kernel of this library can move between two HBM buffers with nothing to do
+// in between -- the denominator next to the 8 TB/s spec peak.  pattern 0: 16 bytes per lane, grid-stride.  pattern 1: the
+// round-3 unfilter's access pattern (a wave owns 64 rows of `pitch` bytes, 256-byte tiles, row r trailing row r - 1 by 4 bytes on
+// BOTH sides): what unaligned stores cost, and a known byte count in that pattern to calibrate FETCH_SIZE / WRITE_SIZE against.
+__global__ __launch_bounds__(256) void copy16_kernel(const u32x4 *__restrict__ in, u32x4 *__restrict__ out, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void copy_skewed_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, uint32_t pitch, uint64_t rows)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t band = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (band * 64 >= rows) return;
+    const int r0 = lane >> 4, cj = lane & 15;
+    const uint32_t ntiles = (pitch + 63 * 4 + 255) / 256;
+    for (uint32_t T = 0; T < ntiles; ++T) {
+        u32x4 v[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const uint64_t row = band * 64 + (uint64_t)(r0 + 4 * m);
+            const int64_t off = (int64_t)T * 256 - (int64_t)(r0 + 4 * m) * 4 + 16 * cj;
+            v[m] = u32x4{0, 0, 0, 0};
+            if (row < rows && off >= 0 && off + 16 <= (int64_t)pitch) v[m] = ((const U128u *)(in + row * pitch + off))->v;
+        }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const uint64_t row = band * 64 + (uint64_t)(r0 + 4 * m);
+            const int64_t off = (int64_t)T * 256 - (int64_t)(r0 + 4 * m) * 4 + 16 * cj;
+            if (row < rows && off >= 0 && off + 16 <= (int64_t)pitch) ((U128u *)(out + row * pitch + off))->v = v[m];
+        }
+    }
+}
+hipError_t launch_copy_probe(const void *d_src, void *d_dst, uint64_t bytes, int pattern, hipStream_t stream)
+{
+    if (pattern == 0) copy16_kernel<<<256 * 32, 256, 0, stream>>>((const u32x4 *)d_src, (u32x4 *)d_dst, bytes / 16);
+    else {
+        const uint32_t pitch = 16384;
+        const uint64_t rows = bytes / pitch;
+        copy_skewed_kernel<<<(uint32_t)((rows + 255) / 256), 256, 0, stream>>>((const uint8_t *)d_src, (uint8_t *)d_dst, pitch, rows);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Scatter of defiltered sub-image rows into PNG.Image.storage (PNG.Image.assign,
 // Sources/PNG/PNG.Image.swift:186-285): Adam7 placement (base + i*stride) and MSB-first expansion
 // of 1/2/4-bit samples to one unscaled byte each.  One thread per destination pixel.

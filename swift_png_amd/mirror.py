@@ -8,7 +8,7 @@ inflated bytes so far, and the point (a block boundary) from which the next push
 """
 from __future__ import annotations
 
-from . import (DONE, FORMAT_GZIP, FORMAT_IOS, FORMAT_ZLIB, NEED_MORE_INPUT, DecodingError,
+from . import (DONE, FORMAT_GZIP, FORMAT_IOS, FORMAT_ZLIB, NEED_MORE_INPUT, DecodingError, SpngError,
                E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM, E_OUTPUT_CAPACITY)
 
 _DELAY_FORMATS = {1: (8, 1), 2: (8, 2), 3: (8, 3), 4: (8, 4), 6: (16, 3), 8: (16, 4)}
@@ -104,14 +104,16 @@ class LZ77:
 
     class Deflator:
         """LZ77.Deflator (Sources/LZ77/Deflator/LZ77.Deflator.swift:8-44): init(format:level:exponent:hint:),
-        push(_:last:), pull(), pop().  The device compresses whole streams (the concatenated output does not
-        depend on how the input was pushed), so the bytes become available with the push
-        that carries last: true; pop() then hands out complete chunks of 2 * hint bytes (the reference's chunk is
-        2 * ManagedBuffer.capacity >= 2 * hint bytes, a platform-dependent size) and pull() also the final
-        partial one -- their concatenation is the reference's stream bit for bit.  One known difference, on a
-        reference bug: a row-by-row pushed stream whose last non-final compress() leaves fewer than three bytes
-        queued makes the reference emit a corrupt stored tail (DeflatorBuffers.Stream.swift:45-60); this class
-        emits the correct stream instead."""
+        push(_:last:), pull(), pop().  Every push goes to the device (spng_deflate_resume_batch): the input so far and the
+        stream so far live in HBM, the compressor's state -- parse position, queued terms, symbol costs, block limit, bit
+        writer -- in a device-side state block, and a push emits what the bytes so far determine (the reference compresses
+        whenever more than 4096 bytes are buffered, LZ77.DeflatorBuffers.swift:68-93; its output does not depend on how the
+        input was pushed, SURVEY 8a row a13, and neither does this one).  pop() hands out complete chunks of 2 * hint bytes
+        (the reference's chunk is 2 * ManagedBuffer.capacity >= 2 * hint bytes, a platform-dependent size) and pull() also
+        whatever has been written so far -- their concatenation is the reference's stream bit for bit.  One known difference,
+        on a reference bug: a row-by-row pushed stream whose last non-final compress() leaves fewer than three bytes queued
+        makes the reference emit a corrupt stored tail (DeflatorBuffers.Stream.swift:45-60); this class emits the correct
+        stream instead."""
 
         def __init__(self, format=FORMAT_ZLIB, level=9, exponent=15, hint=1 << 12, session=None):
             from . import load
@@ -120,23 +122,45 @@ class LZ77:
             self._s = session or load()
             self._format, self._level, self._exponent = format, level, exponent
             self._chunk = 2 * max(int(hint), 1)
-            self._in = bytearray()
-            self._out = None
+            s = self._s
+            self._d_in, self._n = s.empty(1 << 16), 0
+            self._d_out = s.empty(s.lib.spng_deflate_bound(1 << 16))
+            self._state = s.torch.zeros(int(s.lib.spng_deflate_state_bytes()), dtype=s.torch.uint8, device=s.tdev)
+            self._hstate = (0, 0)
+            self._avail = 0                      # stream bytes the device has produced so far
             self._cursor = 0
+            self._done = False
+            self.device_calls = 0
 
         def push(self, data, last=False):
-            if self._out is not None:
+            if self._done:
                 raise RuntimeError("push after the last block")
-            self._in += bytes(data)
-            if last:
-                self._out = self._s.deflate(bytes(self._in), self._level, self._format, self._exponent)
-                self._in = bytearray()
+            s, data = self._s, bytes(data)
+            need = self._n + len(data)
+            if self._d_in.numel() < need:
+                grown = s.empty(2 * need); grown[:self._n] = self._d_in[:self._n]; self._d_in = grown
+            if data:
+                self._d_in[self._n:need] = s.to_device(data)
+            self._n = need
+            cap = int(s.lib.spng_deflate_bound(need)) + 64
+            if self._d_out.numel() < cap:
+                grown = s.empty(2 * cap); grown[:self._avail + 8] = self._d_out[:self._avail + 8]; self._d_out = grown
+            res, self._hstate = s.deflate_resume(self._d_in, self._n, self._d_out, self._level, self._state, last, self._format,
+                                                 self._exponent, self._hstate)
+            self.device_calls += 1
+            if res.status not in (DONE, NEED_MORE_INPUT):
+                raise SpngError(res.status)
+            self._avail = res.written
+            self._done = bool(last)
+
+        def _bytes(self, a, b):
+            return bytes(self._d_out[a:b].cpu().numpy()) if b > a else b""
 
         def pop(self):
             """A complete chunk, or None (:40-43)."""
-            if self._out is None or len(self._out) - self._cursor < self._chunk:
+            if self._avail - self._cursor < self._chunk:
                 return None
-            data = self._out[self._cursor:self._cursor + self._chunk]
+            data = self._bytes(self._cursor, self._cursor + self._chunk)
             self._cursor += self._chunk
             return data
 
@@ -145,9 +169,9 @@ class LZ77:
             data = self.pop()
             if data is not None:
                 return data
-            if self._out is None or self._cursor >= len(self._out):
+            if self._cursor >= self._avail:
                 return None
-            data, self._cursor = self._out[self._cursor:], len(self._out)
+            data, self._cursor = self._bytes(self._cursor, self._avail), self._avail
             return data
 
 

@@ -229,3 +229,82 @@ def test_resume_single_push_checks_the_adler32(gpu, mode):
             assert res.reserved == (0 if mode == spng.INFLATE_SERIAL else 1)
     finally:
         s.configure(spng.CFG_INFLATE_MODE, spng.INFLATE_AUTO)
+
+
+# ---- spng_deflate_resume_batch: LZ77.Deflator.push(_:last:) with the compressor's state on the device ------------------------
+def _push_deflate(s, data, sizes, level, fmt=spng.FORMAT_ZLIB, exponent=15):
+    """-> (final stream, [stream bytes available after each push])"""
+    t = s.torch
+    d_in = s.empty(len(data) + 16)
+    d_out = s.empty(int(s.lib.spng_deflate_bound(len(data))) + 64)
+    state = t.zeros(int(s.lib.spng_deflate_state_bytes()), dtype=t.uint8, device=s.tdev)
+    hstate, at, k, avail, prefix = (0, 0), 0, 0, [], b""
+    while True:
+        n = sizes[k % len(sizes)]; k += 1
+        piece = data[at:at + n]
+        if piece:
+            d_in[at:at + len(piece)] = s.to_device(piece)
+        at += len(piece)
+        last = at >= len(data)
+        res, hstate = s.deflate_resume(d_in, at, d_out, level, state, last, fmt, exponent, hstate)
+        assert res.status == (spng.DONE if last else spng.NEED_MORE_INPUT), (res.status, at, last)
+        assert res.written >= (avail[-1] if avail else 0)
+        now = bytes(d_out[:res.written].cpu().numpy())
+        assert now[:len(prefix)] == prefix                               # what was handed out stays what it was
+        prefix = now
+        avail.append(res.written)
+        if last:
+            assert res.consumed == len(data)
+            return now, avail
+
+
+@pytest.mark.parametrize("level", [0, 3, 6, 7, 8, 9, 13])
+def test_deflate_pushed_in_pieces_equals_one_shot(gpu, level):
+    """The concatenated output of LZ77.Deflator does not depend on how the input was pushed: pieces of 1 byte
+    to 200 KB, whole streams from 0 bytes to 3 MB -- crossing the 2047-term blocks of levels 0-7 and the 2047 / 4095 / ... vertex
+    blocks of the full search, 2^21 included -- give the oracle's stream, and every push but the last leaves a prefix of it."""
+    s = gpu.load()
+    rng = np.random.default_rng(level)
+    text = b"lorem ipsum dolor sit amet, consectetur adipiscing elit, sed do eiusmod tempor " * 3000
+    cases = [(b"", [10]), (b"ab", [1]), (b"abc", [1]), (scanlines(5, 4096 * 3), [1, 2, 3, 700]), (scanlines(6, 4096 * 30), [5000]),
+             (text[:150001], [4097, 33, 70000]), (rng.integers(0, 256, 30000, dtype=np.uint8).tobytes(), [2047, 2048, 1]),
+             (scanlines(7, 4096 * 200), [200000, 1000])]
+    if level in (6, 9):
+        cases.append((scanlines(8, 4096 * 768), [1 << 20, 4096]))      # 3 MiB: the first block at the vertex cap arrives in pieces
+    for data, sizes in cases:
+        if level == 13 and len(data) > 200000:
+            continue
+        got, avail = _push_deflate(s, data, sizes, level)
+        assert got == ph.orc_deflate(data, level), (len(data), sizes)
+        if len(data) > 100000 and len(sizes) > 1:
+            assert avail[len(avail) // 2] > 0                           # (bytes came out before the last push)
+
+
+def test_deflate_pushes_gzip_and_small_window(gpu):
+    s = gpu.load()
+    data = scanlines(9, 4096 * 40)
+    got, _ = _push_deflate(s, data, [30000, 7], 7, spng.FORMAT_GZIP)
+    assert got == s.deflate(data, 7, spng.FORMAT_GZIP)
+    import gzip as pygzip
+    assert pygzip.decompress(got) == data
+    got, _ = _push_deflate(s, data, [9999], 9, spng.FORMAT_ZLIB, 9)
+    assert got == ph.orc_deflate(data, 9, 0, 9)
+
+
+def test_mirror_deflator_streams_every_push(gpu):
+    """LZ77.Deflator in the mirror no longer buffers until last: every push is a device call, pull() hands out bytes as they come."""
+    s = gpu.load()
+    data = scanlines(11, 4096 * 120)
+    for level in (6, 9):
+        d = gpu.LZ77.Deflator(level=level, hint=1 << 12)
+        out, pushes, early = b"", 0, 0
+        for at in range(0, len(data), 50000):
+            d.push(data[at:at + 50000], last=at + 50000 >= len(data))
+            pushes += 1
+            while (chunk := d.pop()) is not None:
+                out += chunk
+                early += at + 50000 < len(data)
+        while (chunk := d.pull()) is not None:
+            out += chunk
+        assert out == ph.orc_deflate(data, level)
+        assert d.device_calls == pushes and early > 0

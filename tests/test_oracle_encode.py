@@ -165,3 +165,42 @@ def test_filter_roundtrip_all_delays():
             assert (back[1:] == line[1:]).all()
             last = line
         assert len(seen) >= 2
+
+
+def test_levels_other_than_9_follow_the_published_size_curve():
+    """A SOFT pin for the levels the reference holds no golden stream of ("parity unpinned" beyond round trips).
+    Benchmarks/README.md:72-206 publishes, for Tests/Baselines/rgb8-color-photographic.png at commit 89aa614, swift-png's file
+    size as a percentage of libpng's at the same level (levels 10-13: of libpng's level 9).  The libpng side is Pillow 12 /
+    zlib here -- an independent encoder with libpng's filter heuristic, ~1 % larger than libpng itself -- so the comparison is
+    of the CURVE: level 0 absolutely (libpng stores at level 0: its size is the raster's), every other level relative to level 9,
+    whose stream is pinned bit for bit (test_level9_reference_outputs).  A restatement that searched less, closed blocks
+    elsewhere or costed its trees differently at some level would leave the curve there.  Tolerances: 0.35 percentage points
+    for levels 4-13 (measured: <= 0.25), 1.2 for levels 1-3 (zlib's deflate_fast levels, where Pillow and libpng differ more)."""
+    import io
+    Image = pytest.importorskip("PIL.Image")
+    published = {0: 58.4, 1: 99.64, 2: 99.78, 3: 99.99, 4: 100.93, 5: 101.1, 6: 101.71, 7: 101.84, 8: 99.13, 9: 98.27,
+                 10: 98.04, 11: 97.89, 12: 97.82, 13: 97.74}
+    data = (ph.GOLDEN / "encode" / "rgb8-color-photographic.baseline.png").read_bytes()
+    png = ph.parse_png(data)
+    st, storage, _ = ph.orc_decode(png)
+    assert st == 0
+    rows = ph.orc_filter(storage, png.width, png.height, png.depth, png.channels, False)
+    im = Image.open(io.BytesIO(data))
+    im.load()
+
+    def libpng_like(level):
+        b = io.BytesIO()
+        im.save(b, "PNG", compress_level=level)
+        return len(b.getvalue())
+
+    ours = {}
+    for level in range(14):
+        z = ph.orc_deflate(rows, level)
+        size = 8 + 25 + 12 + len(z) + 12 * ((len(z) + 32767) // 32768)         # signature, IHDR, IEND, IDAT chunks of 32 KiB
+        ours[level] = 100.0 * size / libpng_like(min(level, 9))
+    assert abs(ours[0] - published[0]) <= 0.3, ours[0]
+    gap = ours[9] - published[9]                                                 # (Pillow vs libpng, at the pinned level)
+    assert -2.0 <= gap <= 0.0, gap
+    for level in range(1, 14):
+        tol = 1.2 if level <= 3 else 0.35
+        assert abs(ours[level] - published[level] - gap) <= tol, (level, ours[level], published[level], gap)
