@@ -1,9 +1,9 @@
 """Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one bench.py step into
-profiles/r03_pmc_traffic.json (the file bench.py reads `roofline.traffic` / `kernels.*.traffic` from).
+profiles/r04_pmc_traffic.json (the file bench.py reads `roofline.traffic` / `kernels.*.traffic` from).
 
     python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <kind> <images> <unique> <out.json>
 
-The passes run `python bench.py --steps 1 --warmup 0 --no-swiftpng --no-cpu-baseline [--streams <kind>]`, i.e. the very
+The passes run `python bench.py --steps 1 --warmup 0 --no-swiftpng --no-cpu-baseline --no-extras [--streams <kind>]`, i.e. the very
 workload of the headline line, one decode step; every launch of a kernel inside that step is summed ("per launch" =
 per step; the parallel inflate stages launch once per token-buffer pass).
 Corrections as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: both counters are in KiB; FETCH_SIZE reports
@@ -13,7 +13,7 @@ units, resolve reads tokens and writes bytes in 16-byte units, unfilter as befor
 import csv, glob, json, os, sys
 
 NAMES = {"pinf2_find_kernel": "pinf_find", "pinf2_decode_kernel": "pinf_decode", "pinf2_resolve_kernel": "pinf_resolve",
-         "::inflate_kernel": "inflate", "unfilter_kernel": "unfilter"}
+         "::inflate_kernel": "inflate", "unfilter_kernel": "unfilter", "unfilter_pk_kernel": "unfilter"}
 
 
 def collect(d, counter):
