@@ -600,6 +600,7 @@ def main():
             # the other BASELINE configs and the path's neighbours, each on a bounded workload (never lose the headline to one)
             def leg(name, fn):
                 try:
+                    s.trim()                                   # (the context's scratch of the leg before: each leg sizes its own)
                     torch.cuda.empty_cache()
                     out[name] = fn()
                 except Exception as exc:                       # noqa: BLE001

@@ -176,6 +176,8 @@ def run_encode_photographic(torch, spng, s, level=9, images=256, size=1024, cpu=
         r = rasters[j % unique]
         descs[j] = spng.ImageDesc(d_out.data_ptr() + j * cap, cap, d_rows.data_ptr() + j * U, U, r.data_ptr(), w, h, DEPTH, CHANNELS, 0, 0, 0)
     dres = s.empty(images * ctypes.sizeof(spng.Result))
+    st = s.lib.spng_encode_batch(s.ctx, descs, level, images, ctypes.c_void_p(dres.data_ptr()), None)     # (warm-up: the first call allocates the slab)
+    assert st == 0, st
     torch.cuda.synchronize()
     s.profile(True)
     t0 = time.perf_counter()

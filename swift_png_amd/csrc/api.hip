@@ -434,6 +434,13 @@ static int32_t launch_plan(spng_ctx *c, const UnfilterPlan &plan, Arena &a, cons
                 if (!piece_rows) {
                     piece_rows = (uint32_t)((total_rows / 4096 + 63) & ~(uint64_t)63);
                     if (piece_rows < 128) piece_rows = 128;
+                    if (k == 4 || k == 8) {
+                        // (the line-aligned kernel: bands of 128 / bpp rows, 64 / that many chains per wave -- pieces may be
+                        //  shorter, and a few images still fill the chip)
+                        const uint32_t rr = 128u / (uint32_t)k;
+                        piece_rows = (uint32_t)((total_rows / 8192 + rr - 1) / rr * rr);
+                        if (piece_rows < rr) piece_rows = rr;
+                    }
                 }
                 const uint32_t pieces = (max_rows + piece_rows - 1) / piece_rows;
                 HIP_TRY(launch_unfilter(a.dev<UnfJob>(slots.unf[k]), (uint32_t)plan.unf[k].size(), k,
