@@ -199,7 +199,7 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
     n = args.images if weak else hi - lo
     first = rank * args.images if weak else lo
     do_gather = with_gather and world > 1 and not args.no_gather
-    groups = max(1, min(args.groups, -(-args.images // world))) if do_gather else 1
+    groups = max(1, min(args.groups or 2, -(-args.images // world))) if do_gather else 1
     # what this rank is about to hold: its shard's scanline scratch + rasters, the compressed inputs, on rank 0 the gathered
     # rasters of the whole job, and the pipeline's token pool (sized by the library to at most half of what is then free:
     # planned here with its cautious 3.2 token bytes per compressed byte of one group).  Checked before anything is allocated.
@@ -501,9 +501,11 @@ def main():
                     help="distinct images of the second measurement (>= 10: the compressed input exceeds the 256 MiB Infinity Cache)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: --images in total, sharded (strong, BASELINE configs[2]); or --images per GPU (weak)")
-    ap.add_argument("--groups", type=int, default=1,
+    ap.add_argument("--groups", type=int, default=0,
                     help="N > 1: calls a rank cuts its shard into, each one's rasters leaving for rank 0 while the next decodes "
-                         "(1: a call pays every stream's serial resolve once, profiles/r03_probe_groups.log)")
+                         "(0 = automatic: 2 -- a call pays every stream's serial resolve once, so 128 images cost 99 ms in one call, "
+                         "111 ms in two and 134 ms in four (profiles/r03_probe_groups.log); with two, the first half's rasters (4 GiB, "
+                         "28 ms on one xGMI link) travel under the second half's decode and only the second half's gather is exposed)")
     ap.add_argument("--level", type=int, default=9, help="encode mode: DEFLATE level (BASELINE configs[3]: 9)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")

@@ -120,3 +120,11 @@ def test_deflate_kernel_resources():
     for v in full:
         assert v["private_segment_fixed_size"] <= 64 and v["vgpr_spill_count"] <= 10     # (40 bytes today, outside the passes' inner loops)
         assert v["group_segment_fixed_size"] <= 81920           # (the helper-wave form: 76 KiB, one workgroup of four waves per stream)
+    # the two kernels of a level >= 8 round: three 4-wave search workgroups per CU, four parse waves per CU --
+    # all 1024 streams of BASELINE configs[3] resident
+    search = [v for k, v in table.items() if "dfl2_search_kernel" in k]
+    parse = [v for k, v in table.items() if "dfl2_parse_kernel" in k]
+    assert len(search) == 1 and len(parse) == 1
+    assert search[0]["group_segment_fixed_size"] <= 53248 and search[0]["private_segment_fixed_size"] == 0 and search[0]["vgpr_count"] <= 128
+    assert parse[0]["group_segment_fixed_size"] <= 40960 and parse[0]["private_segment_fixed_size"] <= 256 and parse[0]["max_flat_workgroup_size"] == 64
+
