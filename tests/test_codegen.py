@@ -126,5 +126,7 @@ def test_deflate_kernel_resources():
     parse = [v for k, v in table.items() if "dfl2_parse_kernel" in k]
     assert len(search) == 1 and len(parse) == 1
     assert search[0]["group_segment_fixed_size"] <= 53248 and search[0]["private_segment_fixed_size"] == 0 and search[0]["vgpr_count"] <= 128
-    assert parse[0]["group_segment_fixed_size"] <= 40960 and parse[0]["private_segment_fixed_size"] <= 256 and parse[0]["max_flat_workgroup_size"] == 64
+    # (scratch: 384 bytes, the by-value argument structs of the non-inlined passes at their call sites -- a few per block -- and
+    #  callee-saved registers; nothing inside the passes' loops)
+    assert parse[0]["group_segment_fixed_size"] <= 40960 and parse[0]["private_segment_fixed_size"] <= 512 and parse[0]["max_flat_workgroup_size"] == 64
 
