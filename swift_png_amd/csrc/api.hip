@@ -84,7 +84,8 @@ struct spng_ctx {
     // so that the next batch of the same kind takes one pass), and the pinned word the page counter is read back into
     double   pool_ratio = 0;
     uint32_t *h_pool_used = nullptr;
-    uint64_t pool_pages_planned = 0, pool_src_bytes = 0;
+    uint64_t pool_pages_planned = 0, pool_src_bytes = 0, pool_src_pending = 0;   // (source bytes of the batch planned / of the one whose counters are on their way)
+    double   block_bytes = 0;        // compressed bytes per DEFLATE block in the last batch (0: not known)
     hipEvent_t pool_ev = nullptr; bool pool_pending = false;
     // second stream of the pipeline: the decode of one half of a batch runs beside the resolve of the other
     hipStream_t stream2 = nullptr;
@@ -506,19 +507,6 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
     if (!p.parallel) return SPNG_DONE;
     uint64_t total = 0;
     for (auto &j : p.jobs) total += j.src_len;
-    uint64_t seg_bytes = (uint64_t)c->cfg[SPNG_CFG_SEGMENT_BYTES];
-    if (!seg_bytes) {
-        // (~9 rounds of resident waves, so that the last, partly filled one costs little; the search costs 7 ms per 10^4 segments)
-        // (small batches: >= 4096 segments if that leaves them 64 KiB -- a zlib block is ~40 KB, and a segment without a block
-        // start is a wave without work; one 4K image: 15.1 ms per decode with 256 KiB segments, 10.3 with 64 KiB)
-        seg_bytes = total / 32768;
-        uint64_t least = total / 4096;
-        if (least < (64u << 10)) least = 64u << 10;
-        if (least > (256u << 10)) least = 256u << 10;
-        if (seg_bytes < least) seg_bytes = least;
-    }
-    seg_bytes = (seg_bytes + 255) & ~(uint64_t)255;
-    p.streams.resize(p.jobs.size());
     // what the last batch taught about token volume (its page count comes back behind its kernels: when the planning
     // figure would cut THIS batch into groups, waiting for that number is cheaper than not knowing it)
     if (c->pool_pending && c->pool_ratio == 0 && hipEventQuery(c->pool_ev) != hipSuccess) {
@@ -529,10 +517,27 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
     }
     if (c->pool_pending && hipEventQuery(c->pool_ev) == hipSuccess) {
         c->pool_pending = false;
-        const uint64_t used = c->h_pool_used[0];
+        const uint64_t used = c->h_pool_used[0], blocks = c->h_pool_used[2];
         if (c->h_pool_used[1]) c->pool_ratio = 0;                                   // it ran dry: back to the default
-        else if (c->pool_src_bytes > (1u << 20)) c->pool_ratio = (double)used * 65536.0 / (double)c->pool_src_bytes;
+        else if (c->pool_src_pending > (1u << 20)) c->pool_ratio = (double)used * 65536.0 / (double)c->pool_src_pending;
+        c->block_bytes = (blocks && c->pool_src_pending > (1u << 20)) ? (double)c->pool_src_pending / (double)blocks : 0;
     }
+    uint64_t seg_bytes = (uint64_t)c->cfg[SPNG_CFG_SEGMENT_BYTES];
+    if (!seg_bytes) {
+        // (~9 rounds of resident waves, so that the last, partly filled one costs little; the search costs 7 ms per 10^4 segments)
+        // (small batches: >= 4096 segments if that leaves them 64 KiB -- a zlib block is ~40 KB, and a segment without a block
+        // start is a wave without work; one 4K image: 15.1 ms per decode with 256 KiB segments, 10.3 with 64 KiB)
+        // (streams of small blocks -- swift-png closes one every 2047 terms, ~2 KB -- as the last batch showed them: their
+        // search is nearly free, and twice the segments halve what the last round of resident waves leaves idle:
+        // 1024 x 4K images, decode 317 -> 301 ms)
+        seg_bytes = total / ((c->block_bytes > 0 && c->block_bytes < 8192) ? 65536 : 32768);
+        uint64_t least = total / 4096;
+        if (least < (64u << 10)) least = 64u << 10;
+        if (least > (256u << 10)) least = 256u << 10;
+        if (seg_bytes < least) seg_bytes = least;
+    }
+    seg_bytes = (seg_bytes + 255) & ~(uint64_t)255;
+    p.streams.resize(p.jobs.size());
     const double per_byte = c->pool_ratio > 0 ? (c->pool_ratio * 1.25 < 1.0 ? 1.0 : c->pool_ratio * 1.25) : 3.2;
     std::vector<uint64_t> est(p.jobs.size(), 0);
     size_t log = 0;
@@ -796,6 +801,7 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
         if (!c->pool_pending) {
             // pages this batch took: read at the start of the next one (never waited for)
             HIP_TRY(hipMemcpyAsync(c->h_pool_used, dnext + 8, 16, hipMemcpyDeviceToHost, c->stream));
+            c->pool_src_pending = c->pool_src_bytes;
             HIP_TRY(hipEventRecord(c->pool_ev, c->stream));
             c->pool_pending = true;
         }
@@ -1805,7 +1811,7 @@ int32_t spng_trim(spng_ctx *c)
         if (*bufs[i]) HIP_TRY(hipFree(*bufs[i]));
         *bufs[i] = nullptr; *caps[i] = 0;
     }
-    c->pool_ratio = 0;                                         // (what the token pool had learned went with it)
+    c->pool_ratio = 0; c->block_bytes = 0;                     // (what the token pool had learned went with it)
     return SPNG_DONE;
 }
 

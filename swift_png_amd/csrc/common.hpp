@@ -221,7 +221,7 @@ hipError_t launch_pinf2_parts(PStream *d_streams, uint32_t nstreams, PSeg *d_seg
                               spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax, uint16_t *d_sym, hipStream_t stream);
 hipError_t launch_pinf2_join(PStream *d_streams, uint32_t nstreams, spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax,
                              uint16_t *d_sym, uint8_t *d_win, hipStream_t stream);
-hipError_t launch_pinf2_account(const uint32_t *d_ctr, uint32_t *d_totals, uint32_t pages, hipStream_t stream);
+hipError_t launch_pinf2_account(uint32_t *d_ctr, uint32_t *d_totals, uint32_t pages, hipStream_t stream);
 hipError_t launch_deflate(const DeflateJob *d_jobs, uint32_t count, spng_result *d_results, hipStream_t stream);
 // gzip.hip
 static constexpr uint64_t GZ_NONE = ~0ull;

@@ -82,7 +82,7 @@ static constexpr uint32_t TK_NULL = 0xffffu;           // padding halfword (a "s
 __device__ __forceinline__ uint32_t tk_m0(uint32_t run, uint32_t dist) { return 0x8000u | ((dist - 1) & 63) << 8 | (run - 3); }
 __device__ __forceinline__ uint32_t tk_m1(uint32_t dist) { return 0xC000u | (dist - 1) >> 6; }
 
-struct DPool { uint8_t *base; uint32_t *next; uint32_t pages, pad; };
+struct DPool { uint8_t *base; uint32_t *next; uint32_t pages, pad; };   // next[0]: pages taken, next[1]: blocks decoded
 
 // phase cycle counters of a tuning build (-DSPNG_D_PROF; SPNG_LIB=... tools/probe_v2.py): one wave / workgroup prints
 #ifdef SPNG_D_PROF
@@ -206,6 +206,66 @@ struct Hdr2 {
     uint32_t pairs;                    //   the lit/len table holds pairs of literals
 };
 
+template <int ROOT, int KIND>
+__device__ __forceinline__ void place_symbol(uint32_t *lut, uint32_t sym, uint32_t my, uint32_t code)
+{
+    // While it is built the root table is indexed by the code's bits MSB first: a code of length L <= ROOT owns the
+    // 2^(ROOT - L) entries from code << (ROOT - L) on and writes the first of them; a root prefix of longer codes learns how
+    // long the codes behind it get.  (finish_root fills the entries in between and turns the index round.)
+    if (my <= (uint32_t)ROOT) lut[code << ((uint32_t)ROOT - my)] = KIND == 0 ? lit_entry2(sym, my) : dist_entry2(sym, my);
+    else atomicMax(&lut[code >> (my - (uint32_t)ROOT)], my);
+}
+template <int ROOT, int KIND>
+__device__ __forceinline__ void place_long(const uint32_t *lut, uint32_t *ext, uint32_t sym, uint32_t my, uint32_t code)
+{
+    if (my > (uint32_t)ROOT) {
+        const uint32_t rev = __brev(code) >> (32 - my);
+        const uint32_t link = lut[rev & ((1u << ROOT) - 1)];
+        const uint32_t sub = (link >> 8) & 15, at = link >> 16;
+        const uint32_t e = KIND == 0 ? lit_entry2(sym, my) : dist_entry2(sym, my);
+        for (uint32_t j = rev >> ROOT; j < (1u << sub); j += 1u << (my - ROOT)) ext[at + j] = e;
+    }
+}
+// The root table of a COMPLETE code from the first entries place_symbol left in it (zeros elsewhere; entry 0 is always
+// written: the first code is all zeros).  Every lane takes 2^ROOT / 64 neighbouring entries: an empty entry repeats the one
+// in front of it (the codes are canonical: their ranges follow one another); entries that hold a length (ROOT < v <= 15)
+// become links to second-level tables laid out by a prefix sum (`links`: there are such; false: they do not fit);
+// then the table is written back indexed by the next ROOT bits of the stream, which come LSB first.
+template <int ROOT>
+__device__ __forceinline__ bool finish_root(uint32_t *lut, uint32_t &used, uint32_t cap, bool links, int lane)
+{
+    constexpr int PER = (1 << ROOT) / 64;
+    uint32_t v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = lut[lane * PER + k];
+#pragma unroll
+    for (int k = 1; k < PER; ++k) v[k] = v[k] ? v[k] : v[k - 1];
+    const unsigned long long have = __ballot(v[PER - 1] != 0) & ((1ull << lane) - 1);
+    const uint32_t cin = (uint32_t)__shfl((int)v[PER - 1], have ? 63 - __clzll((long long)have) : 0, 64);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) v[k] = v[k] ? v[k] : cin;
+    if (links) {
+        uint32_t need = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) need += (v[k] > (uint32_t)ROOT && v[k] <= 15) ? 1u << (v[k] - ROOT) : 0u;
+        uint32_t tot;
+        uint32_t at = used + wave_excl_scan(need, tot, lane);
+        tot += used;
+#ifdef SPNG_EMU_TRACE
+        if (tot > cap && lane == 0) fprintf(stderr, "finish_root<%d>: need %u > cap %u\n", ROOT, tot, cap);
+#endif
+        if (tot > cap) return false;
+        used = tot;
+#pragma unroll
+        for (int k = 0; k < PER; ++k)
+            if (v[k] > (uint32_t)ROOT && v[k] <= 15) { const uint32_t sub = v[k] - ROOT; v[k] = C_LINK << 5 | sub << 8 | at << 16; at += 1u << sub; }
+    }
+    WSYNC();                                                  // (in place: every read before the first write)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) lut[__brev((uint32_t)(lane * PER + k)) >> (32 - ROOT)] = v[k];
+    return true;
+}
+
 // The code-length code (readBlockTables, InflatorBuffers.Stream.swift:144-190): 19 lengths of <= 7 bits.  Lane
 // i < 19 holds the length of symbol i.  Builds the 2^7-entry LUT (entry = code length | symbol << 16).
 // false: not a complete code (HuffmanTree.swift:80-108).
@@ -223,30 +283,31 @@ __device__ __forceinline__ bool build_clut(DLds &s, uint32_t mylen, int lane)
     if (UNI(wave_sum(scaled)) != 128u) return false;
     const uint32_t first = ((row_scan(scaled) - scaled) >> (7 - (lane & 7))) & 127;      // canonical first code of length `lane`
     if (lane < 16) s.h.cl[lane] = first;
+    s.h.clut[lane] = 0; s.h.clut[64 + lane] = 0;
     WSYNC();
-    if (lane < 19 && mylen) {
-        const uint32_t code = s.h.cl[mylen] + before;
-        const uint32_t rev = __brev(code) >> (32 - mylen);
-        const uint32_t e = mylen | (uint32_t)lane << 16;
-        for (uint32_t j = rev; j < (1u << MB); j += 1u << mylen) s.h.clut[j] = e;
-    }
+    // (built indexed by the code MSB first -- a code's entries are neighbours -- and turned round at the end: finish_root)
+    if (lane < 19 && mylen) s.h.clut[(s.h.cl[mylen] + before) << (MB - mylen)] = mylen | (uint32_t)lane << 16;
+    WSYNC();
+    uint32_t none = 0;
+    finish_root<MB>(s.h.clut, none, 0, false, lane);
     WSYNC();
     return true;
 }
 
-// The run-length coded code lengths (InflatorBuffers.Stream.swift:191-263).  64 bit positions at a time: every
-// lane decodes the symbol that WOULD start at its position, the true chain through the 64 answers is walked
-// on the scalar unit (v_readlane), a prefix sum over the symbols on it gives the write positions, and "the
-// previous length" of a repeat is the nearest lower lane that defines one.  On success lens[0 .. want) are
-// the code lengths and `rel` is the first bit behind them.  false: a sequence the reference rejects (repeat
-// without a previous length, a run past the declared count), or one that does not end inside the input.
+// The run-length coded code lengths (InflatorBuffers.Stream.swift:191-263), in two passes.  Pass 1, 64 bit positions
+// at a time: every lane decodes the symbol that WOULD start at its position, the true chain through the 64 answers is
+// walked on the scalar unit (v_readlane), and the symbols on it go, packed, to a list (in the lit/len table's space, which
+// is not built yet) -- only one position in four or five starts a symbol, so everything else waits for pass 2, which takes
+// the list 64 symbols at a time: a prefix sum over the repeat counts gives the write positions, and "the previous length"
+// of a repeat is the nearest lower symbol that defines one.  On success lens[0 .. want) are the code lengths and `rel`
+// is the first bit behind them.  false: a sequence the reference rejects (repeat without a previous length, a run
+// past the declared count), or one that does not end inside the input.
 __device__ __attribute__((always_inline)) bool decode_lengths2(DLds &s, uint32_t &rel, uint32_t rel_end, uint32_t want, int lane)
 {
     for (int i = lane; i < 128; i += 64) ((uint32_t *)s.h.lens)[i] = 0;
-    WSYNC();
-    uint32_t have = 0, p = rel;
-    uint32_t prev = 0; bool prev_ok = false;
-    for (int window = 0; window < 80; ++window) {           // (a sequence is at most 318 symbols of >= 1 bit)
+    uint32_t *list = s.lit;                                  // symbol | repeat count << 8 | the bit behind it << 16
+    uint32_t ntok = 0, have = 0, p = rel;
+    for (int window = 0; window < 80 && have < want; ++window) {     // (a sequence is at most 318 symbols of >= 1 bit)
         if (p >= rel_end || p + 64 + 16 > 256u * 32) return false;     // (a header parse stages 1 KiB)
         const uint32_t q = p + (uint32_t)lane;
         const uint32_t w = q >> 5;
@@ -256,15 +317,38 @@ __device__ __attribute__((always_inline)) bool decode_lengths2(DLds &s, uint32_t
         const uint32_t extra = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
         const uint32_t rep = sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + ((bits >> len) & ((1u << extra) - 1));
         const uint32_t nb = len + extra;                      // 1 .. 14
-        // the chain through this window
+        // the chain through this window, and how many lengths it stands for.  A dependent scalar step per symbol is what
+        // this loop would cost (~14 per window); three rounds of pointer doubling first, and a step covers eight symbols:
+        // jn = bits from my position to the eighth symbol on (or to the first one past the window), jr = the lengths those
+        // symbols stand for, jm = where they start.
+        uint32_t jn = nb, jr = rep;
+        uint32_t jlo = lane < 32 ? 1u << lane : 0u, jhi = lane < 32 ? 0u : 1u << (lane - 32);
+#pragma unroll
+        for (int round = 0; round < 3; ++round) {
+            const uint32_t tgt = (uint32_t)lane + jn;
+            const uint32_t on = (uint32_t)__shfl((int)(jn | jr << 8), (int)(tgt & 63), 64);
+            const uint32_t olo = (uint32_t)__shfl((int)jlo, (int)(tgt & 63), 64), ohi = (uint32_t)__shfl((int)jhi, (int)(tgt & 63), 64);
+            if (tgt < 64) { jn += on & 0xff; jr += on >> 8; jlo |= olo; jhi |= ohi; }
+        }
         unsigned long long mask = 0;
         uint32_t pp = 0;
         while (pp < 64) {
-            mask |= 1ull << pp;
-            pp += (uint32_t)__builtin_amdgcn_readlane((int)nb, (int)pp);
+            mask |= (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)jhi, (int)pp) << 32 | (uint32_t)__builtin_amdgcn_readlane((int)jlo, (int)pp);
+            have += (uint32_t)__builtin_amdgcn_readlane((int)jr, (int)pp);
+            pp += (uint32_t)__builtin_amdgcn_readlane((int)jn, (int)pp);
         }
-        const bool is = (mask >> lane) & 1;
-        const uint32_t r = is ? rep : 0u;
+        if ((mask >> lane) & 1) list[ntok + (uint32_t)__popcll(mask & ((1ull << lane) - 1))] = sym | rep << 8 | (q + nb) << 16;
+        ntok += (uint32_t)__popcll(mask);
+        p += pp;
+    }
+    if (have < want) return false;
+    WSYNC();
+    uint32_t prev = 0; bool prev_ok = false;
+    have = 0;
+    for (uint32_t b = 0; b < ntok; b += 64) {
+        const bool is = b + (uint32_t)lane < ntok;
+        const uint32_t t = is ? list[b + (uint32_t)lane] : 0u;
+        const uint32_t sym = t & 0xff, r = (t >> 8) & 0xff;
         uint32_t tot;
         const uint32_t idx = have + wave_excl_scan(r, tot, lane);
         // the previous length as seen by a repeat (symbol 16): the nearest lower symbol that is not one
@@ -284,14 +368,12 @@ __device__ __attribute__((always_inline)) bool decode_lengths2(DLds &s, uint32_t
         const unsigned long long endm = __ballot(active && idx + r == want);
         if (__ballot(bad)) return false;
         if (endm) {
-            const int el = __ffsll((long long)endm) - 1;
-            rel = p + (uint32_t)el + (uint32_t)__builtin_amdgcn_readlane((int)nb, el);
+            rel = (uint32_t)__builtin_amdgcn_readlane((int)(t >> 16), __ffsll((long long)endm) - 1);
             WSYNC();
             return rel <= rel_end;
         }
         have += tot;
         if (defm) { prev = (uint32_t)__shfl((int)val, 63 - __clzll((long long)defm), 64); prev_ok = true; }
-        p += pp;
     }
     return false;
 }
@@ -303,57 +385,6 @@ __device__ __attribute__((always_inline)) bool decode_lengths2(DLds &s, uint32_t
 // Restates HuffmanTree.swift:80-174 (validate / size) and the decade tables of LZ77.Composites.swift.  false: a code
 // the reference rejects (or second-level tables that outgrow their space: not this path's case).  minlen = the
 // shortest lit/len code.
-template <int ROOT, int KIND>
-__device__ __forceinline__ void place_symbol(uint32_t *lut, uint32_t sym, uint32_t my, uint32_t code)
-{
-    // short code: every root index that ends in it; long code: its root index learns how long codes behind it get
-    const uint32_t rev = __brev(code) >> (32 - my);
-    if (my <= (uint32_t)ROOT) {
-        const uint32_t e = KIND == 0 ? lit_entry2(sym, my) : dist_entry2(sym, my);
-        for (uint32_t j = rev; j < (1u << ROOT); j += 1u << my) lut[j] = e;
-    } else {
-        atomicMax(&lut[rev & ((1u << ROOT) - 1)], my);
-    }
-}
-template <int ROOT, int KIND>
-__device__ __forceinline__ void place_long(const uint32_t *lut, uint32_t *ext, uint32_t sym, uint32_t my, uint32_t code)
-{
-    if (my > (uint32_t)ROOT) {
-        const uint32_t rev = __brev(code) >> (32 - my);
-        const uint32_t link = lut[rev & ((1u << ROOT) - 1)];
-        const uint32_t sub = (link >> 8) & 15, at = link >> 16;
-        const uint32_t e = KIND == 0 ? lit_entry2(sym, my) : dist_entry2(sym, my);
-        for (uint32_t j = rev >> ROOT; j < (1u << sub); j += 1u << (my - ROOT)) ext[at + j] = e;
-    }
-}
-// root entries that hold a length (ROOT < v <= 15) become links; -> false when the second-level tables do not fit
-template <int ROOT>
-__device__ __forceinline__ bool layout_links(uint32_t *lut, uint32_t &used, uint32_t cap, int lane)
-{
-    constexpr int PER = (1 << ROOT) / 64;
-    uint32_t v[PER], need = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        v[k] = lut[lane * PER + k];
-        const bool link = v[k] > (uint32_t)ROOT && v[k] <= 15;
-        need += link ? 1u << (v[k] - ROOT) : 0u;
-    }
-    uint32_t tot;
-    uint32_t at = used + wave_excl_scan(need, tot, lane);
-    tot += used;
-#ifdef SPNG_EMU_TRACE
-    if (tot > cap && lane == 0) fprintf(stderr, "layout_links<%d>: need %u > cap %u\n", ROOT, tot, cap);
-#endif
-    if (tot > cap) return false;
-    used = tot;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const bool link = v[k] > (uint32_t)ROOT && v[k] <= 15;
-        if (link) { lut[lane * PER + k] = C_LINK << 5 | (v[k] - ROOT) << 8 | at << 16; at += 1u << (v[k] - ROOT); }
-    }
-    return true;
-}
-
 __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t literals, uint32_t distances, uint32_t &minlen, uint32_t &pairs, int lane)
 {
     // (the six code lengths of a lane -- five lit/len symbols, one distance symbol -- travel in one register)
@@ -436,14 +467,15 @@ __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t l
         }
     }
     WSYNC();
-    // ---- second-level tables (only when some code is longer than its root index)
+    // ---- the root tables in their final form, and the second-level tables (only when some code is longer than its
+    // root index)
     const bool longl = __ballot(LL(0) > (uint32_t)LB || LL(1) > (uint32_t)LB || LL(2) > (uint32_t)LB || LL(3) > (uint32_t)LB || LL(4) > (uint32_t)LB) != 0;
     const bool longd = !stub && __ballot(dl > (uint32_t)DB) != 0;
     uint32_t used = 0;
-    if (longl) { if (!UB(layout_links<LB>(s.lit, used, EXT, lane))) return false; }
-    if (longd) { if (!UB(layout_links<DB>(s.dist, used, EXT, lane))) return false; }
+    if (!UB(finish_root<LB>(s.lit, used, EXT, longl, lane))) return false;
+    if (!stub) { if (!UB(finish_root<DB>(s.dist, used, EXT, longd, lane))) return false; }
+    WSYNC();
     if (longl || longd) {
-        WSYNC();
 #pragma unroll
         for (int k = 0; k < 5; ++k) if (LL(k) > (uint32_t)LB) place_long<LB, 0>(s.lit, s.ext, (uint32_t)lane + 64u * k, LL(k), s.h.codes[k][lane]);
         if (!stub && dl > (uint32_t)DB) place_long<DB, 1>(s.dist, s.ext, (uint32_t)lane, dl, s.h.codes[5][lane]);
@@ -454,6 +486,7 @@ __device__ __attribute__((always_inline)) bool build_tables2(DLds &s, uint32_t l
     // ---- pairs of literals: a root index whose bits hold a literal's code and then another one's whole code decodes
     // both in one step.  (An entry rewritten under a reader still shows the same first literal in the same fields.)
     bool made = false;
+    if (2 * minlen <= (uint32_t)LB)                               // (two codes share the root index only when the shortest does twice)
 #pragma unroll
     for (int k = 0; k < (1 << LB) / 64; ++k) {
         const uint32_t idx = (uint32_t)k * 64 + (uint32_t)lane;
@@ -928,6 +961,7 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
     // blocks before it.
     const bool resumable = uni64((uint64_t)st.state) != 0;
     uint64_t hw_block = 0, nbytes = 0, bytes_block = 0;
+    uint32_t nblocks = 0;                                      // (what the planner sizes the next batch's segments by)
 #ifdef SPNG_D_PROF
     uint64_t dp[32];
     for (int i = 0; i < 32; ++i) dp[i] = 0;
@@ -990,8 +1024,10 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
             if (state != 1) break;
             pos = entry;
         }
+        nblocks += 1;
         if (h.bfinal) { status = PSEG_FINAL; break; }
     }
+    if (lane == 0 && nblocks) atomicAdd(pool.next + 1, nblocks);
     uint64_t nhw = cur.nhw;
     // The pool ran dry (a batch unlike the one it was sized by): the stream takes the retry pass, with the pool to itself and
     // its like; dry again there, it stops in front of this block like any other block that cannot be taken.
@@ -1610,11 +1646,12 @@ __global__ void pinf2_verdict_kernel(const PStream *__restrict__ streams, const 
 }
 
 // pages a pass took: its page counter into the batch's totals = {pages, some pass ran dry}
-__global__ void pinf2_account_kernel(const uint32_t *ctr, uint32_t *totals, uint32_t pages)
+__global__ void pinf2_account_kernel(uint32_t *ctr, uint32_t *totals, uint32_t pages)
 {
     const uint32_t used = ctr[0];
     atomicAdd(&totals[0], used < pages ? used : pages);
     if (used >= pages) atomicOr(&totals[1], 1u);
+    totals[2] += ctr[1]; ctr[1] = 0;                            // blocks decoded (ctr[1]: the pass's, counted by the decode waves)
 }
 
 // ---- host ------------------------------------------------------------------------------------------------
@@ -1664,7 +1701,7 @@ hipError_t launch_pinf2_join(PStream *d_streams, uint32_t nstreams, spng_result 
     pinf2_verdict_kernel<<<(nstreams + 63) / 64, 64, 0, stream>>>(d_streams, d_parts, pmax, d_results, d_done, nstreams);
     return hipGetLastError();
 }
-hipError_t launch_pinf2_account(const uint32_t *d_ctr, uint32_t *d_totals, uint32_t pages, hipStream_t stream)
+hipError_t launch_pinf2_account(uint32_t *d_ctr, uint32_t *d_totals, uint32_t pages, hipStream_t stream)
 {
     pinf2_account_kernel<<<1, 1, 0, stream>>>(d_ctr, d_totals, pages);
     return hipGetLastError();

@@ -58,8 +58,9 @@ int main(int argc, char **argv)
     }
     std::vector<uint32_t> pt(pt_total, 0xDEADBEEF);
     std::vector<uint8_t> poolmem((size_t)pages << PAGE_SHIFT, 0xAB);
-    uint32_t next = 0;
-    DPool pool{poolmem.data(), &next, pages, 0};
+    uint32_t nextv[4] = {0, 0, 0, 0};                          // (pages taken, blocks decoded)
+    uint32_t &next = nextv[0];
+    DPool pool{poolmem.data(), nextv, pages, 0};
     spng_result res;
     memset(&res, 0xff, sizeof res);
     int32_t done = 0;
@@ -115,8 +116,9 @@ int main(int argc, char **argv)
         printf("first pass: ok %d pass %u\n", st.ok, st.pass);
         const uint32_t pages2 = (uint32_t)atoi(getenv("EMU_RETRY_PAGES"));
         std::vector<uint8_t> poolmem2((size_t)pages2 << PAGE_SHIFT, 0xAB);
-        uint32_t next2 = 0;
-        DPool pool2{poolmem2.data(), &next2, pages2, 0};
+        uint32_t next2v[4] = {0, 0, 0, 0};
+        uint32_t &next2 = next2v[0];
+        DPool pool2{poolmem2.data(), next2v, pages2, 0};
         emu::launch((unsigned)k, 64, [&] { pinf2_find_kernel<1>(&st, segs.data(), 0); });
         emu::launch((unsigned)k, 64, [&] { pinf2_decode_kernel<1>(&st, segs.data(), pt.data(), pool2, 0); });
         emu::launch(1, 64, [&] { pinf2_scan_kernel<1>(&st, segs.data(), parts.data()); });
