@@ -47,6 +47,7 @@
 // segment that meets a block it cannot take as it stands ends PARTIAL in front of it; resolve begins with
 // the window read back from the output, and the block boundary reached goes to the serial kernel.
 #include "common.hpp"
+#include <type_traits>
 #include "huffman.hpp"
 
 namespace spng {
@@ -1372,6 +1373,10 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                 const bool odd = wave & 1;
                 const uint32_t srclo = odd ? bw[2] : bw[0], srchi = odd ? bw[3] : bw[1], srcbase = odd ? rb + ca : rb;
                 // EB2 rows at a time, so that the record reads and then the ring reads of a batch travel together
+                // (two instances: only in the first 32 KiB can a distance reach in front of the output, or of the part --
+                // everywhere else the test and its bookkeeping are not there)
+                auto expand_rows = [&](auto early_c) {
+                constexpr bool EARLY = decltype(early_c)::value;
 #pragma unroll
                 for (int part = 0; part < (int)(BPT2 / EB2); ++part) {
                     uint32_t r0v[EB2], r1v[EB2];
@@ -1413,9 +1418,9 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                             if (MARK) {
                                 // in front of the tile: the symbol in the ring, or -- in front of the part -- a marker
                                 const uint32_t rel = (uint32_t)(pos - part_pos) + si;             // (from the part's first byte)
-                                v = (int32_t)si >= 0 ? si : (!early || (int32_t)rel >= 0) ? farv[kk] : 0x8000u | (rel + WINDOW2);
+                                v = (int32_t)si >= 0 ? si : (!EARLY || (int32_t)rel >= 0) ? farv[kk] : 0x8000u | (rel + WINDOW2);
                             } else {
-                                if (early && (int32_t)si < 0 && (uint32_t)pos < 0u - si) bad = true;
+                                if (EARLY && (int32_t)si < 0 && (uint32_t)pos < 0u - si) bad = true;
                                 v = (int32_t)si < 0 ? DONE | farv[kk] : si;
                             }
                             sv[k] = v;
@@ -1423,6 +1428,8 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         }
                     }
                 }
+                };
+                if (early) expand_rows(std::true_type{}); else expand_rows(std::false_type{});
             }
             __syncthreads();
             RP2(3);
