@@ -116,6 +116,18 @@ struct Bits {                                    // LSB-first bit writer (LZ77.D
     gbyte *dst; uint64_t cap; bool overflow;
 };
 
+// Arguments of a function that is not inlined travel in vector registers, and whatever is computed from them -- loop counters,
+// masks, branch conditions -- stays there: a single wave then pays a VALU slot and an EXEC detour for what is scalar work
+// (and a wave alone on its SIMD issues one instruction every four cycles, scalar or not: the parse is bound by their number).
+// These put wave-uniform arguments back into scalar registers at the callee's door.
+#define UNIP(T, p) ((T)uni64((uint64_t)(p)))
+__device__ __forceinline__ Bits uni_bits(Bits b)
+{
+    b.acc = uni64(b.acc); b.nacc = UNI(b.nacc); b.total = uni64(b.total); b.flushed = uni64(b.flushed);
+    b.dst = UNIP(gbyte *, b.dst); b.cap = uni64(b.cap); b.overflow = UB(b.overflow);
+    return b;
+}
+
 __device__ __forceinline__ void put(DLds &s, Bits &b, uint32_t bits, uint32_t count, int lane)
 {
     b.acc |= (uint64_t)(bits & ((1u << count) - 1)) << b.nacc;
@@ -167,8 +179,10 @@ __device__ __forceinline__ void bulk_put(DLds &s, Bits &b, uint64_t v, uint32_t 
 // in freq[0..n): code length per symbol into len[].  The heap (LZ77.Heap.swift) is replayed
 // exactly -- which two nodes merge on equal keys depends on its sift order -- but its values are
 // node ids: the reference's per-level leaf-count vectors are the depth histogram of the tree.
-__device__ __attribute__((noinline)) void build_tree(const uint32_t *freq, int n, int limit, uint8_t *len, int lane)
+__device__ __attribute__((noinline)) void build_tree(const uint32_t *freq_, int n_, int limit_, uint8_t *len_, int lane)
 {
+    const uint32_t *freq = UNIP(const uint32_t *, freq_); uint8_t *len = UNIP(uint8_t *, len_);
+    const int n = (int)UNI(n_), limit = (int)UNI(limit_);
     DLds &s = g_lds;
     for (int i = lane; i < n; i += 64) len[i] = 0;
     // rank = position in (descending frequency, ascending symbol) order
@@ -308,8 +322,10 @@ __device__ __attribute__((noinline)) void build_tree(const uint32_t *freq, int n
 }
 
 // canonical codewords, bit-reversed for LSB-first emission (HuffmanTree.codewords :206-230)
-__device__ __attribute__((noinline)) void make_codes(const uint8_t *len, int n, uint16_t *code, int lane)
+__device__ __attribute__((noinline)) void make_codes(const uint8_t *len_, int n_, uint16_t *code_, int lane)
 {
+    const uint8_t *len = UNIP(const uint8_t *, len_); uint16_t *code = UNIP(uint16_t *, code_);
+    const int n = (int)UNI(n_);
     // codes of one length are consecutive in symbol order; the first code of length l is
     // (first of l-1 + count of l-1) << 1
     uint32_t my[5], cw[5];
@@ -338,8 +354,10 @@ __device__ __attribute__((noinline)) void make_codes(const uint8_t *len, int n, 
 
 // The head of a block once the code lengths stand in s.ll / s.dl: code-length RLE, the code-length code,
 // codewords, then writeBlockMetadata + writeBlockTables (DeflatorBuffers.Stream.swift:459-623).
-__device__ __attribute__((noinline)) Bits write_tables(Bits b, bool final, int lane)
+__device__ __attribute__((noinline)) Bits write_tables(Bits b_, bool final_, int lane)
 {
+    Bits b = uni_bits(b_);
+    const bool final = UB(final_);
     DLds &s = g_lds;
     if (lane < 2) { s.ll[286 + lane] = 0; s.dl[30 + lane] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -427,8 +445,11 @@ __device__ __forceinline__ uint64_t match_bits(const DLds &s, uint32_t rd, uint3
 }
 
 // Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), greedy / lazy form
-__device__ __attribute__((noinline)) Bits write_block(Bits b, int count, bool final, int lane)
+__device__ __attribute__((noinline)) Bits write_block(Bits b_, int count_, bool final_, int lane)
 {
+    Bits b = uni_bits(b_);
+    const int count = (int)UNI(count_);
+    const bool final = UB(final_);
     DLds &s = g_lds;
     // DeflatorMatches.trees() (:138-159)
     for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
@@ -443,7 +464,7 @@ __device__ __attribute__((noinline)) Bits write_block(Bits b, int count, bool fi
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     build_tree(s.freq, 286, 15, s.ll, lane);
     build_tree(s.freq + 288, 30, 15, s.dl, lane);
-    b = write_tables(b, final, lane);
+    b = uni_bits(write_tables(b, final, lane));
     // writeBlock(with:) (:626-659), 64 terms at a time
     for (int i0 = 0; i0 < count; i0 += 64) {
         const int i = i0 + lane;
@@ -740,7 +761,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
             uint32_t t = 0;
             bool stop = false;
             while (t < 128 && w + t < last_main && !stop) {
-                if (!(unfilled() > (lazy ? 1 : 0))) { DPROF_END(2); DPROF_BEGIN(); b = write_block(b, count, false, lane); count = 0; DPROF_END(3); DPROF_BEGIN(); }
+                if (!(unfilled() > (lazy ? 1 : 0))) { DPROF_END(2); DPROF_BEGIN(); b = uni_bits(write_block(b, count, false, lane)); count = 0; DPROF_END(3); DPROF_BEGIN(); }
                 const uint32_t run = at(mrunA, mrunB, t);
                 const uint32_t lit = at(litA, litB, t);
                 if (!run) { g_sea.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
@@ -787,12 +808,12 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         insert_upto(n);                                        // Adler-32 over the tail
         // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
         for (uint64_t p = w; p < n; ++p) {
-            if (!(unfilled() > 0)) { b = write_block(b, count, false, lane); count = 0; }
+            if (!(unfilled() > 0)) { b = uni_bits(write_block(b, count, false, lane)); count = 0; }
             g_sea.terms[count] = 0xf8000000u | UNI(in[p]);
             ++count;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        b = write_block(b, count, true, lane);
+        b = uni_bits(write_block(b, count, true, lane));
     }
 
     if (job.format == SPNG_FORMAT_ZLIB) {
@@ -1142,9 +1163,16 @@ __device__ __forceinline__ void full_depths_update(int lane)
 
 // Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), full form: trees(iterations:), header, the path's tokens
 template <int WAVES>
-__device__ __attribute__((noinline)) Bits full_block(Bits b, const FullArrays g, const gbyte *in, uint64_t bbase, uint32_t count,
-                                                     bool final, int iterations, bool generic, int lane)
+__device__ __attribute__((noinline)) Bits full_block(Bits b_, const FullArrays g_, const gbyte *in_, uint64_t bbase_, uint32_t count_,
+                                                     bool final_, int iterations_, bool generic_, int lane)
 {
+    Bits b = uni_bits(b_);
+    FullArrays g; g.base = UNIP(gword *, g_.base); g.vcap = UNI(g_.vcap);
+    const gbyte *in = UNIP(const gbyte *, in_);
+    const uint64_t bbase = uni64(bbase_);
+    const uint32_t count = UNI(count_);
+    const bool final = UB(final_), generic = UB(generic_);
+    const int iterations = (int)UNI(iterations_);
     DLds &s = g_lds;
     for (int i = generic ? -iterations : 0;;) {
         if (count) { FPROF(2); full_forward<WAVES>(g, in, bbase, count, lane); FPROF(4); full_backward(g, in, bbase, count, lane); FPROF(5); }
@@ -1159,7 +1187,7 @@ __device__ __attribute__((noinline)) Bits full_block(Bits b, const FullArrays g,
         if (!(i < iterations)) break;
         full_depths_update(lane);
     }
-    b = write_tables(b, final, lane);
+    b = uni_bits(write_tables(b, final, lane));
     FPROF(7);
     // writeBlock(with:) (:661-707): the path's terms, 64 vertices at a time
     uint32_t pb_next = (uint32_t)lane < count ? g.pathb_()[lane] : 0u, st_next = (uint32_t)lane < count ? g.step_()[lane] : 0u,
@@ -1262,7 +1290,7 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
     auto unfilled = [&]() { return (int)limit - 1 - (int)count; };
     auto close_block = [&](bool final) {
         const uint32_t doubled = 2 * limit < (1u << 21) ? 2 * limit : 1u << 21;     // trees(iterations:) :229
-        b = full_block<WAVES>(b, g, in, bbase, count, final, iterations, generic, lane);
+        b = uni_bits(full_block<WAVES>(b, g, in, bbase, count, final, iterations, generic, lane));
         generic = false; count = 0; limit = doubled < vcap + 1 ? doubled : vcap + 1;
     };
 
@@ -1404,7 +1432,7 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
 // The old kernel stays as the path for streams the pool could not serve (dfl2 marks them; api.hip runs them afterwards).
 static constexpr uint32_t D2_RV = 1u << 21;                     // vertices per stream and round
 static constexpr uint32_t D2_PCOLS = 64, D2_PSTRIDE = 65;       // offer table: lengths 3 .. 66, rows padded against bank conflicts
-__shared__ uint32_t g_ptab[64 * D2_PSTRIDE];                    // (parse kernel only)
+__shared__ uint32_t g_ptab[66 * D2_PSTRIDE];                    // (parse kernel only; two rows of padding: a group of three vertices is read blind)
 #ifndef SPNG_D2_WAVES
 #define SPNG_D2_WAVES 4          // waves of a search workgroup: one of them inserts first.  4 waves = 47 KB of LDS = three per CU
 #endif                           // (2 waves, five per CU, more inserters: measured 30 % slower -- profiles/r04_probe_deflate2d.log)
@@ -1603,6 +1631,15 @@ struct D2Arrays {                                               // (pointers of 
     const uint32_t *pool;
 };
 
+__device__ __forceinline__ D2Arrays uni_arrays(const D2Arrays &a)
+{
+    D2Arrays r;
+    r.vinfo = UNIP(const uint16_t *, a.vinfo); r.bbase = UNIP(const uint64_t *, a.bbase); r.bwords = UNIP(const uint32_t *, a.bwords);
+    r.emask = UNIP(uint64_t *, a.emask); r.up = UNIP(gword *, a.up); r.step = UNIP(gword *, a.step);
+    r.pathb = UNIP(gbyte *, a.pathb); r.litb = UNIP(gbyte *, a.litb); r.pool = UNIP(const uint32_t *, a.pool);
+    return r;
+}
+
 // The parse kernel walks a block in batches of 64 vertices ALIGNED IN ROUND COORDINATES (the first one may start in front of the
 // block: sh = (block's first vertex in the round) mod 64 lanes idle), so that a batch is exactly one batch of the search kernel:
 // one candidate list, the word's position-in-batch is the lane.  Batch j holds the block's vertices 64 j - sh ... 64 j - sh + 63.
@@ -1610,8 +1647,11 @@ struct D2Arrays {                                               // (pointers of 
 // Which vertices of the block keep their edges (Stream.compress full, DeflatorBuffers.Stream.swift:344-400): behind a
 // SEARCHED vertex whose longest run exceeds 100 the next run - 100 vertices -- not beyond the block's capacity -- are not
 // searched.  One 64-bit mask per batch.
-__device__ __attribute__((noinline)) void d2_skip_rule(const D2Arrays g, uint64_t vr0, uint32_t count, uint32_t cap, int lane)
+__device__ __attribute__((noinline)) void d2_skip_rule(const D2Arrays g_, uint64_t vr0_, uint32_t count_, uint32_t cap_, int lane)
 {
+    const D2Arrays g = uni_arrays(g_);
+    const uint64_t vr0 = uni64(vr0_);
+    const uint32_t count = UNI(count_), cap = UNI(cap_);
     const int sh = (int)(vr0 & 63);
     const uint32_t nb = ((uint32_t)sh + count + 64) >> 6;      // (as the forward pass: the batch of the end vertex too)
     int skip_until = 0, base = -sh;
@@ -1742,6 +1782,7 @@ __device__ __forceinline__ void d2_relax_long(const D2Arrays g, uint64_t vr, uin
     }
 }
 
+__device__ __forceinline__ uint32_t d2_smin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 // sum over the wave, in scalar registers (DPP row scans + four v_readlane: no LDS round trips -- __shfl_xor is ds_bpermute)
 __device__ __forceinline__ uint32_t wave_total(uint32_t v)
 {
@@ -1757,8 +1798,12 @@ __device__ __forceinline__ uint32_t wave_total(uint32_t v)
 //   * In a batch with edges the depths are scanned over all 64 lanes only at its start and at its end; between two groups of
 //     vertices (three consecutive ones are final together) only the few lanes up to the next group are recomputed, one DPP
 //     step per lane.
-__device__ __attribute__((noinline)) void d2_forward(const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint32_t count, int lane)
+__device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gbyte *in_, uint64_t bbase_, uint64_t vr0_, uint32_t count_, int lane)
 {
+    const D2Arrays g = uni_arrays(g_);
+    const gbyte *in = UNIP(const gbyte *, in_);
+    const uint64_t bbase = uni64(bbase_), vr0 = uni64(vr0_);
+    const uint32_t count = UNI(count_);
     DLds &s = g_lds;
     uint32_t rc[4];
 #pragma unroll
@@ -1862,25 +1907,87 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g, const gby
         uint32_t D = minplus_scan(cin, Wd, carry, lane);
         uint32_t k = 0;
         bool dirty = false;                                    // keys were written since D was computed
+        // Runs up to 23 -- most batches of image data: the offers of a group's three vertices side by side, 21 lanes each, so
+        // that ONE row read, one key and one ds_min_u64 per lane serve the whole group.  A wave alone on its SIMD issues an
+        // instruction every four cycles, scalar or vector: this loop is bound by their number (~145 per group in its general
+        // form below, a third of that here).  Per batch: which vertices have table edges (okm) / edges beyond the table (lgm) and
+        // room for a match; per lane: its row offset, key constants and whether its column is in use.  Per group: the depths of
+        // its three vertices on the scalar unit -- from the group before when it ends where this one starts (the ring's depths
+        // and the literal costs of three lanes by v_readlane), from a scan over the wave otherwise.
+        if (cols <= 21) {
+            // vertices x (lanes) with 0 <= base + x and base + x + 3 <= count
+            unsigned long long range = ~0ull;
+            if (base < 0) range &= ~0ull << (uint32_t)(-base);
+            {
+                const int top3 = (int)count - 3 - base;                         // last lane with room
+                range = top3 < 0 ? 0ull : top3 >= 63 ? range : range & ((2ull << (uint32_t)top3) - 1);
+            }
+            const unsigned long long gm = em & range, okm = gm & ~longm, lgm = gm & longm;
+            const uint32_t pqbit = (pq < 3 && pl < cols) ? 1u << pq : 0u;
+            const uint32_t rowc = (pq * D2_PSTRIDE + pl) * 4;                  // byte offset of my offer in the group's rows
+            const uint32_t klo_c = (258u - (3u + pl)) << 23 | 1u << 15;
+            const uint32_t ac = pq + 3u + pl;                                   // my target, from the group's first vertex
+            uint32_t prevD = 0, kvs = ~0u;                                      // depth of the vertex at lane kvs - 1 (kvs: none)
+            for (;;) {
+                const unsigned long long rest = k < 64 ? gm >> k : 0ull;
+                if (!rest) break;
+                const uint32_t kk = k + (uint32_t)__builtin_ctzll(rest);
+                const uint32_t m3 = (uint32_t)(okm >> kk) & 7u;
+                uint32_t l3 = (uint32_t)(lgm >> kk) & 7u;
+#ifdef SPNG_DEFLATE_PROF
+                if (threadIdx.x == 0) g_prof[7] += 1ull << 20;
+#endif
+                const uint32_t pk = *(const uint32_t *)((const uint8_t *)g_ptab + kk * (D2_PSTRIDE * 4) + rowc);
+                if (dirty) {
+                    W = act ? s.win[(uint32_t)v & 511] : ~0ull;
+                    Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
+                }
+                const uint32_t k1 = kk + 1 < 63 ? kk + 1 : 63, k2 = kk + 2 < 63 ? kk + 2 : 63;
+                // (the depth in front of the group: the group before left it, or a scan over the wave finds it)
+                if (kk != kvs) {
+                    if (dirty) D = minplus_scan(cin, Wd, carry, lane);
+                    prevD = kk ? (uint32_t)__builtin_amdgcn_readlane((int)D, (int)(kk - 1)) : carry;
+                }
+                const uint32_t D0 = d2_smin(prevD + (uint32_t)__builtin_amdgcn_readlane((int)cin, (int)kk), (uint32_t)__builtin_amdgcn_readlane((int)Wd, (int)kk));
+                const uint32_t D1 = d2_smin(D0 + (uint32_t)__builtin_amdgcn_readlane((int)cin, (int)k1), (uint32_t)__builtin_amdgcn_readlane((int)Wd, (int)k1));
+                const uint32_t D2 = d2_smin(D1 + (uint32_t)__builtin_amdgcn_readlane((int)cin, (int)k2), (uint32_t)__builtin_amdgcn_readlane((int)Wd, (int)k2));
+                prevD = D2; kvs = kk + 3;                                       // (kk + 3 > 63: no group behind this one)
+                if ((m3 & pqbit) && pk != ~0u) {
+                    const uint32_t Dq = pq == 0 ? D0 : pq == 1 ? D1 : D2;
+                    const uint64_t key = (uint64_t)(Dq + (pk >> 20) + rcp) << 32 | ((pk & 0xfffffu) + klo_c);
+                    __hip_atomic_fetch_min(&s.win[((uint32_t)(base + (int)kk) + ac) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                {
+                    const int reach = base + (int)kk + 2 + (int)cols + 2;
+                    pend = reach > pend ? reach : pend;
+                }
+                // (vertices of the group with a run beyond the table)
+                while (l3) {
+                    const uint32_t b3 = (uint32_t)__builtin_ctz(l3);
+                    l3 &= l3 - 1;
+                    const uint32_t vl = (uint32_t)(base + (int)(kk + b3));
+                    d2_relax_long(g, vr0 + vl, vl, count, b3 == 0 ? D0 : b3 == 1 ? D1 : D2, rc, lane);
+                    pend = (int)vl + 258 > pend ? (int)vl + 258 : pend;
+                }
+                dirty = true;
+                k = kk + 3;
+                asm volatile("" ::: "memory");
+            }
+        } else
         for (;;) {
             const unsigned long long rest = k < 64 ? (em >> k) << k : 0ull;
             if (!rest) break;
             const uint32_t kk = (uint32_t)__ffsll((long long)rest) - 1;
             // A match is at least 3 long: the depths of three consecutive vertices are final together.  D is final below lane k;
             // the group needs it through lane kk + 2: a few lanes are recomputed one by one, many by the scan over all of them.
-            // (their offer rows are asked for first: they do not depend on the depths)
-            // Runs up to 23 -- most batches of image data: the offers of the group's three vertices side by side, 21 lanes each,
-            // so that ONE row read, one key and one ds_min_u64 per lane serve the whole group; otherwise vertex by vertex.
-            const bool packed = cols <= 21;
+            // (their offer rows are asked for first: they do not depend on the depths)  Longer runs than the loop above takes:
+            // vertex by vertex, lane = length.
 #ifdef SPNG_DEFLATE_PROF
-            if (threadIdx.x == 0) { g_prof[packed ? 7 : 8] += 1ull << 20; if (dirty && kk + 3 - k > 8) g_prof[9] += 0; }
+            if (threadIdx.x == 0) g_prof[8] += 1ull << 20;
 #endif
             uint32_t row[3];
-            if (packed) row[0] = (pl < cols && kk + pq < 64) ? g_ptab[(kk + pq) * D2_PSTRIDE + pl] : ~0u;
-            else {
 #pragma unroll
-                for (int q = 0; q < 3; ++q) row[q] = ((uint32_t)lane < cols && kk + q < 64) ? g_ptab[(kk + q) * D2_PSTRIDE + lane] : ~0u;
-            }
+            for (int q = 0; q < 3; ++q) row[q] = ((uint32_t)lane < cols && kk + q < 64) ? g_ptab[(kk + q) * D2_PSTRIDE + lane] : ~0u;
             if (dirty) {
                 W = act ? s.win[(uint32_t)v & 511] : ~0ull;
                 Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
@@ -1893,30 +2000,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g, const gby
                     }
                 } else D = minplus_scan(cin, Wd, carry, lane);
             }
-            if (packed) {
-                const uint32_t D0 = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kk);
-                const uint32_t D1 = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)(kk + 1 < 63 ? kk + 1 : 63));
-                const uint32_t D2 = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)(kk + 2 < 63 ? kk + 2 : 63));
-                const uint32_t kq = kk + pq, vv = (uint32_t)(base + (int)kq);
-                const uint32_t pk = row[0];
-                const bool edge = pq < 3 && kq < 64 && ((em >> (kq & 63)) & 1) && count - vv >= 3;
-                if (edge && !((longm >> (kq & 63)) & 1) && pk != ~0u) {
-                    const uint32_t Dq = pq == 0 ? D0 : pq == 1 ? D1 : D2, L = 3u + pl;
-                    const uint64_t key = (uint64_t)(Dq + (pk >> 20) + rcp) << 32 | (258u - L) << 23 | ((pk & 0xfffffu) + (1u << 15));
-                    __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                pend = (int)(base + (int)kk + 2 + (int)cols + 2) > pend ? (int)(base + (int)kk + 2 + (int)cols + 2) : pend;
-                // (vertices of the group with a run beyond the table)
-                unsigned long long lg = (longm >> kk) & 7ull & (em >> kk);
-                while (lg) {
-                    const uint32_t kl = kk + (uint32_t)__ffsll((long long)lg) - 1;
-                    lg &= lg - 1;
-                    const uint32_t vl = (uint32_t)(base + (int)kl);
-                    if (kl >= 64 || count - vl < 3) continue;
-                    d2_relax_long(g, vr0 + vl, vl, count, (uint32_t)__builtin_amdgcn_readlane((int)D, (int)kl), rc, lane);
-                    pend = (int)vl + 258 > pend ? (int)vl + 258 : pend;
-                }
-            } else {
+            {
                 for (uint32_t kq = kk; kq < kk + 3; ++kq) {
                     if (!(kq < 64 && ((em >> kq) & 1))) continue;
                     const uint32_t vv = (uint32_t)(base + (int)kq);
@@ -1959,8 +2043,12 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g, const gby
 }
 
 // minimize() backwards (:282-320), as full_backward with the wider ways-in
-__device__ __attribute__((noinline)) void d2_backward(const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint32_t count, int lane)
+__device__ __attribute__((noinline)) void d2_backward(const D2Arrays g_, const gbyte *in_, uint64_t bbase_, uint64_t vr0_, uint32_t count_, int lane)
 {
+    const D2Arrays g = uni_arrays(g_);
+    const gbyte *in = UNIP(const gbyte *, in_);
+    const uint64_t bbase = uni64(bbase_), vr0 = uni64(vr0_);
+    const uint32_t count = UNI(count_);
     DLds &s = g_lds;
     const uint32_t sh = (uint32_t)(vr0 & 63);
     // (a batch of literals only: the forward pass wrote no ways in for it)
@@ -2015,9 +2103,16 @@ __device__ __attribute__((noinline)) void d2_backward(const D2Arrays g, const gb
 }
 
 // Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), full form, over the records of the search kernel
-__device__ __attribute__((noinline)) Bits d2_block(Bits b, const D2Arrays g, const gbyte *in, uint64_t bbase, uint64_t vr0, uint32_t count, uint32_t cap,
-                                                   bool final, int iterations, bool generic, int lane)
+__device__ __attribute__((noinline)) Bits d2_block(Bits b_, const D2Arrays g_, const gbyte *in_, uint64_t bbase_, uint64_t vr0_, uint32_t count_, uint32_t cap_,
+                                                   bool final_, int iterations_, bool generic_, int lane)
 {
+    Bits b = uni_bits(b_);
+    const D2Arrays g = uni_arrays(g_);
+    const gbyte *in = UNIP(const gbyte *, in_);
+    const uint64_t bbase = uni64(bbase_), vr0 = uni64(vr0_);
+    const uint32_t count = UNI(count_), cap = UNI(cap_);
+    const bool final = UB(final_), generic = UB(generic_);
+    const int iterations = (int)UNI(iterations_);
     DLds &s = g_lds;
     FPROF(0);
     d2_skip_rule(g, vr0, count, cap, lane);
@@ -2034,7 +2129,7 @@ __device__ __attribute__((noinline)) Bits d2_block(Bits b, const D2Arrays g, con
         if (!(i < iterations)) break;
         full_depths_update(lane);
     }
-    b = write_tables(b, final, lane);
+    b = uni_bits(write_tables(b, final, lane));
     FPROF(5);
     // writeBlock(with:) (:661-707): the path's terms, 64 vertices at a time
     uint32_t pb_next = (uint32_t)lane < count ? g.pathb[lane] : 0u, st_next = (uint32_t)lane < count ? g.step[lane] : 0u,
@@ -2135,7 +2230,7 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
             const uint64_t room = n - pos;
             const uint32_t count = (uint64_t)(limit - 1) < room ? limit - 1 : (uint32_t)room;
             const bool final = !more && pos + count == n;
-            b = d2_block(b, g, in, pos, pos - rb, count, limit - 1, final, iterations, generic, lane);
+            b = uni_bits(d2_block(b, g, in, pos, pos - rb, count, limit - 1, final, iterations, generic, lane));
             generic = false;
             pos += count;
             if (!final) limit = 2 * limit < (1u << 21) ? 2 * limit : 1u << 21;     // trees(iterations:) :229
