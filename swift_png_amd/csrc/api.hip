@@ -87,6 +87,7 @@ struct spng_ctx {
     uint64_t pool_pages_planned = 0, pool_src_bytes = 0, pool_src_pending = 0;   // (source bytes of the batch planned / of the one whose counters are on their way)
     double   block_bytes = 0;        // compressed bytes per DEFLATE block in the last batch (0: not known)
     hipEvent_t pool_ev = nullptr; bool pool_pending = false;
+    hipEvent_t ev_dfl[4] = {nullptr, nullptr, nullptr, nullptr};    // level >= 8 rounds: searched[parity], parsed[parity]
     // second stream of the pipeline: the decode of one half of a batch runs beside the resolve of the other
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_mid = nullptr, ev_join = nullptr;
@@ -261,6 +262,7 @@ void spng_destroy(spng_ctx *c)
     if (c->pool_ev) (void)hipEventDestroy(c->pool_ev);
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     for (hipEvent_t e : {c->ev_fork, c->ev_mid, c->ev_join}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_dfl) if (e) (void)hipEventDestroy(e);
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1513,7 +1515,8 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
     const size_t nfull = last - first;
     auto scratch_of = [](uint64_t n) -> uint64_t {
         const uint64_t V = deflate2_vertices(n), B = V / 64 + 2;
-        return ((2 * V + 255) & ~255ull) + ((8 * B + 255) & ~255ull) + ((4 * B + 255) & ~255ull) + ((8 * B + 255) & ~255ull) +
+        // (the candidate records twice: round r + 1 is searched while round r is parsed)
+        return 2 * (((2 * V + 255) & ~255ull) + ((8 * B + 255) & ~255ull) + ((4 * B + 255) & ~255ull)) + ((8 * B + 255) & ~255ull) +
                2 * ((4 * (V + 2) + 255) & ~255ull) + ((V + 2 + 255) & ~255ull) + ((B + 255) & ~255ull);
     };
     size_t free_b = 0, total_b = 0;
@@ -1550,10 +1553,10 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
         l.cps = cps; l.chunk = (((1u << 21) / cps + 63) / 64) * 64;
         l.rings = (uint64_t)cnt * cps * 65536 * 4;
         uint64_t room = budget > l.scratch + l.rings ? budget - l.scratch - l.rings : 0;
-        l.pool = worst_pool < room ? worst_pool : room;
+        l.pool = worst_pool < room / 2 ? worst_pool : room / 2;       // (one pool per round parity)
         if (l.pool < min_pool) l.pool = min_pool;
         l.pool &= ~255ull;
-        const uint64_t tot = l.scratch + l.rings + l.pool + 4096;
+        const uint64_t tot = l.scratch + l.rings + 2 * (l.pool + 256) + 4096;
         slab = tot > slab ? tot : slab;
         lay.push_back(l);
     }
@@ -1586,6 +1589,7 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
             // (spng_deflate_resume_batch: the caller's state, kept from push to push; else the call's own)
             s.state = j.state ? (D2State *)j.state : a.dev<D2State>(tslot) + (i - first);
             s.vinfo = (uint16_t *)take(2 * V); s.bbase = (uint64_t *)take(8 * B); s.bwords = (uint32_t *)take(4 * B); s.emask = (uint64_t *)take(8 * B);
+            s.vinfo2 = (uint16_t *)take(2 * V); s.bbase2 = (uint64_t *)take(8 * B); s.bwords2 = (uint32_t *)take(4 * B);
             s.up = (uint32_t *)take(4 * (V + 2)); s.step = (uint32_t *)take(4 * (V + 2)); s.pathb = (uint8_t *)take(V + 2); s.litb = (uint8_t *)take(B);
             uint64_t pos = j.state ? j.plan_pos : 0;
             uint32_t lim = j.state && j.plan_limit ? j.plan_limit : 2048;
@@ -1598,15 +1602,30 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
         const uint32_t cnt = (uint32_t)(groups[g].second - groups[g].first);
         const Lay &l = lay[g];
         char *rings = (char *)c->d_graph + ((l.scratch + 255) & ~255ull);
-        char *pool = rings + l.rings;
-        unsigned long long *pool_next = (unsigned long long *)(pool + l.pool);
+        char *pools[2] = {rings + l.rings, rings + l.rings + l.pool + 256};       // (each followed by its bump counter)
         uint32_t rounds = 0;
         for (size_t i = groups[g].first; i < groups[g].second; ++i) rounds = rounds_of[i - first] > rounds ? rounds_of[i - first] : rounds;
-        HIP_TRY(launch_deflate2_begin(a.dev<D2Stream>(sslot) + (groups[g].first - first), cnt, c->stream));
+        const D2Stream *ds = a.dev<D2Stream>(sslot) + (groups[g].first - first);
+        HIP_TRY(launch_deflate2_begin(ds, cnt, c->stream));
+        // The search of round r + 1 beside the parse of round r, on a stream of its own (candidates are a function of the input
+        // alone; the parse is one wave per stream and leaves most of the chip idle): two sets of records and pools, by round parity.
+        // searched[p] / parsed[p]: the last search into / parse out of the records of parity p.
+        if (!c->stream2) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+            for (hipEvent_t *e : {&c->ev_fork, &c->ev_mid, &c->ev_join}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+        if (!c->ev_dfl[0]) for (hipEvent_t &e : c->ev_dfl) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         for (uint32_t r = 0; r < rounds; ++r) {
-            { Timed t(c, SPNG_K_DFL_SEARCH); HIP_TRY(launch_deflate2_search(a.dev<D2Stream>(sslot) + (groups[g].first - first), cnt, l.cps, l.chunk, (uint32_t *)pool,
-                                                                            pool_next, l.pool / 4, (uint32_t *)rings, c->stream)); }
-            { Timed t(c, SPNG_K_DFL_PARSE); HIP_TRY(launch_deflate2_parse(a.dev<D2Stream>(sslot) + (groups[g].first - first), cnt, (uint32_t *)pool, dr, c->stream)); }
+            const uint32_t par = r & 1;
+            if (r >= 2) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_dfl[2 + par], 0));     // the parse of round r - 2 is done with these records
+            { Timed t(c, SPNG_K_DFL_SEARCH, c->stream2); HIP_TRY(launch_deflate2_search(ds, cnt, l.cps, l.chunk, (uint32_t *)pools[par],
+                                                                            (unsigned long long *)(pools[par] + l.pool), l.pool / 4, (uint32_t *)rings, par, c->stream2)); }
+            HIP_TRY(hipEventRecord(c->ev_dfl[par], c->stream2));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_dfl[par], 0));
+            { Timed t(c, SPNG_K_DFL_PARSE); HIP_TRY(launch_deflate2_parse(ds, cnt, (uint32_t *)pools[par], dr, par, c->stream)); }
+            HIP_TRY(hipEventRecord(c->ev_dfl[2 + par], c->stream));
         }
     }
     // who is not finished?  (the pool ran dry under them: a batch of very compressible streams on little memory)

@@ -182,6 +182,9 @@ struct D2State {                  // device side, kept from round to round; arri
     uint32_t fail, done;          // the pool ran dry under this stream (the one-kernel search takes it afterwards); finished
     uint8_t  depths[544];         // LZ77.DeflatorMatches.Depths between blocks
     uint32_t started, pad;        // (a state arrives zeroed: the first round of the first call sets the block limit)
+    // the search kernel's own cursor: it runs a round ahead of the parse (block boundaries are a function of the positions alone)
+    uint64_t srb, sre, spos;
+    uint32_t slimit, spad;
 };
 struct D2Stream {
     const uint8_t *src; uint8_t *dst;
@@ -195,6 +198,7 @@ struct D2Stream {
     // word of its list in the pool and words | longest run << 16; block coordinates: which vertices keep their edges, the
     // ways in, the path
     uint16_t *vinfo; uint64_t *bbase; uint32_t *bwords; uint64_t *emask;
+    uint16_t *vinfo2; uint64_t *bbase2; uint32_t *bwords2;   // (the candidate records of the odd rounds: round r + 1 is searched while round r is parsed)
     uint32_t *up, *step; uint8_t *pathb, *litb;   // (litb: per batch of the block, nothing but literal ways in)
 };
 
@@ -241,8 +245,8 @@ uint32_t deflate2_plan(uint64_t n, bool more, uint64_t &pos, uint32_t &lim);
 hipError_t launch_deflate2_begin(const D2Stream *d_streams, uint32_t count, hipStream_t stream);
 uint64_t deflate2_vertices(uint64_t n);
 hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t *d_pool, unsigned long long *d_pool_next,
-                                  uint64_t pool_words, uint32_t *d_rings, hipStream_t stream);
-hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, hipStream_t stream);
+                                  uint64_t pool_words, uint32_t *d_rings, uint32_t parity, hipStream_t stream);
+hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, uint32_t parity, hipStream_t stream);
 hipError_t launch_deflate2_failed(const D2Stream *d_streams, uint32_t count, uint32_t *d_failed, hipStream_t stream);
 uint64_t deflate_graph_vertices(uint64_t n);
 uint64_t deflate_graph_bytes(uint64_t vertices);

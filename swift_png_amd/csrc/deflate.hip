@@ -1520,14 +1520,15 @@ __device__ __forceinline__ void chain_walk1(const gbyte *in, const gword *ring, 
 }
 
 __global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D2Stream *__restrict__ streams, uint32_t cps, uint32_t chunk_len, uint32_t *__restrict__ pool,
-                                                          unsigned long long *__restrict__ pool_next, uint64_t pool_cap, uint32_t *__restrict__ rings)
+                                                          unsigned long long *__restrict__ pool_next, uint64_t pool_cap, uint32_t *__restrict__ rings, uint32_t parity)
 {
     D2ALds &s = g_a;
     const int lane = threadIdx.x & 63, wave = (int)UNI(threadIdx.x >> 6);
     const D2Stream &st = streams[blockIdx.x / cps];
     D2State *state = (D2State *)uni64((uint64_t)st.state);
     if (UNI(state->done) || UNI(state->fail)) return;
-    const uint64_t n = uni64(st.src_len), rb = uni64(state->rb), re = uni64(state->re);
+    // (the search's own cursor: this round may be a round ahead of the one the parse kernel is at)
+    const uint64_t n = uni64(st.src_len), rb = uni64(state->srb), re = uni64(state->sre);
     const uint64_t c0 = rb + (uint64_t)(blockIdx.x % cps) * chunk_len, c1 = c0 + chunk_len < re ? c0 + chunk_len : re;
     if (c0 >= re || n < 3) return;
     const gbyte *in = (const gbyte *)uni64((uint64_t)st.src);
@@ -1612,8 +1613,8 @@ __global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D
         const bool ok = base + T <= pool_cap;
         if (!ok && lane == 0) atomicOr(&state->fail, 1u);
         const uint64_t v = p - rb;
-        if (inchunk) st.vinfo[v] = (uint16_t)(cnt << 9 | ext);
-        if (lane == 0) { st.bbase[v >> 6] = base; st.bwords[v >> 6] = T | mr << 16; }
+        if (inchunk) (parity ? st.vinfo2 : st.vinfo)[v] = (uint16_t)(cnt << 9 | ext);
+        if (lane == 0) { (parity ? st.bbase2 : st.bbase)[v >> 6] = base; (parity ? st.bwords2 : st.bwords)[v >> 6] = T | mr << 16; }
         if (ok) {
             uint32_t k = 0;
             for (uint32_t m = mask; m; m &= m - 1, ++k) {
@@ -2167,7 +2168,7 @@ __device__ __attribute__((noinline)) Bits d2_block(Bits b_, const D2Arrays g_, c
     return b;
 }
 
-__global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restrict__ streams, const uint32_t *__restrict__ pool, spng_result *__restrict__ results)
+__global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restrict__ streams, const uint32_t *__restrict__ pool, spng_result *__restrict__ results, uint32_t parity)
 {
     DLds &s = g_lds;
     const D2Stream *sp = streams + blockIdx.x;
@@ -2178,8 +2179,8 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
     const uint64_t n = uni64(sp->src_len);
     const int32_t format = (int32_t)UNI(sp->format);
     D2Arrays g;
-    g.vinfo = (const uint16_t *)uni64((uint64_t)sp->vinfo); g.bbase = (const uint64_t *)uni64((uint64_t)sp->bbase);
-    g.bwords = (const uint32_t *)uni64((uint64_t)sp->bwords); g.emask = (uint64_t *)uni64((uint64_t)sp->emask);
+    g.vinfo = (const uint16_t *)uni64((uint64_t)(parity ? sp->vinfo2 : sp->vinfo)); g.bbase = (const uint64_t *)uni64((uint64_t)(parity ? sp->bbase2 : sp->bbase));
+    g.bwords = (const uint32_t *)uni64((uint64_t)(parity ? sp->bwords2 : sp->bwords)); g.emask = (uint64_t *)uni64((uint64_t)sp->emask);
     g.up = (gword *)uni64((uint64_t)sp->up); g.step = (gword *)uni64((uint64_t)sp->step); g.pathb = (gbyte *)uni64((uint64_t)sp->pathb);
     g.litb = (gbyte *)uni64((uint64_t)sp->litb);
     g.pool = pool;
@@ -2314,6 +2315,27 @@ __global__ void dfl2_begin_kernel(const D2Stream *__restrict__ streams, uint32_t
     t.fail = 0;
     t.rb = t.pos;
     t.re = st.src_len < 3 ? t.pos : d2_round_end(t.pos, t.limit, st.src_len, st.more != 0);
+    t.spos = t.pos; t.slimit = t.limit; t.srb = t.rb; t.sre = t.re;
+}
+// The search's cursor, from the round it has just searched to the next: the blocks of a round and the limit they leave are a
+// function of the positions alone (deflate2_plan), so the search of round r + 1 does not wait for the parse of round r.
+__global__ void dfl2_advance_kernel(const D2Stream *__restrict__ streams, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const D2Stream &st = streams[i];
+    D2State &t = *st.state;
+    const uint64_t n = st.src_len, end = t.sre;
+    const bool more = st.more != 0;
+    if (n < 3 || end == t.spos) return;
+    uint32_t lim = t.slimit;
+    for (uint64_t at = t.spos; at < end;) {
+        const uint64_t size = (uint64_t)(lim - 1) < end - at ? (uint64_t)(lim - 1) : end - at;
+        at += size;
+        if (more || at < n) lim = 2 * lim < (1u << 21) ? 2 * lim : 1u << 21;
+    }
+    t.spos = end; t.slimit = lim;
+    t.srb = end; t.sre = (!more && end >= n) ? end : d2_round_end(end, lim, n, more);
 }
 hipError_t launch_deflate2_begin(const D2Stream *d_streams, uint32_t count, hipStream_t stream)
 {
@@ -2323,18 +2345,19 @@ hipError_t launch_deflate2_begin(const D2Stream *d_streams, uint32_t count, hipS
 }
 
 hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t *d_pool, unsigned long long *d_pool_next,
-                                  uint64_t pool_words, uint32_t *d_rings, hipStream_t stream)
+                                  uint64_t pool_words, uint32_t *d_rings, uint32_t parity, hipStream_t stream)
 {
     if (!count) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_pool_next, 0, 8, stream);
     if (e != hipSuccess) return e;
-    dfl2_search_kernel<<<count * cps, SPNG_D2_WAVES * 64, 0, stream>>>(d_streams, cps, chunk_len, d_pool, d_pool_next, pool_words, d_rings);
+    dfl2_search_kernel<<<count * cps, SPNG_D2_WAVES * 64, 0, stream>>>(d_streams, cps, chunk_len, d_pool, d_pool_next, pool_words, d_rings, parity);
+    dfl2_advance_kernel<<<(count + 255) / 256, 256, 0, stream>>>(d_streams, count);
     return hipGetLastError();
 }
-hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, hipStream_t stream)
+hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, uint32_t parity, hipStream_t stream)
 {
     if (!count) return hipSuccess;
-    dfl2_parse_kernel<<<count, 64, 0, stream>>>(d_streams, d_pool, d_results);
+    dfl2_parse_kernel<<<count, 64, 0, stream>>>(d_streams, d_pool, d_results, parity);
     return hipGetLastError();
 }
 
