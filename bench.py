@@ -125,7 +125,8 @@ def cpu_baseline(streams, images, rows, cores: int):
 
 
 def pmc_traffic(kind: str, images: int, unique: int):
-    """HBM bytes per launch of each kernel from the committed rocprofv3 PMC passes of this very workload
+    """HBM bytes per decode step of each kernel (summed over its launches of the step: the file's `hbm_bytes_per_launch`
+    dates from one launch per step) from the committed rocprofv3 PMC passes of this very workload
     (profiles/ + PMC_FILE: FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
     MI355X_MICROARCH.md prescribes); None when the file does not describe this configuration."""
     try:
@@ -284,9 +285,12 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
     job.d_rows = job.d_out = job.dres = None                  # (the slabs go back to the allocator before the next workload)
     torch.cuda.empty_cache()
     per_step = {k: prof[k][0] / args.steps for k in STAGES}
+    # launches of a stage per step: the library's event spans, less the retry pass of the pipeline (launched behind every batch,
+    # returns at once when no stream ran out of token pages; in kernel traces it is the <1u> instantiation)
+    launches = {k: max(1, round(prof[k][1] / args.steps) - (1 if k.startswith("pinf_") else 0)) for k in STAGES}
     alg = {"pinf_find": 0, "pinf_decode": total_c, "pinf_resolve": n * U,
            "inflate": 0 if fast == n else total_c + n * U, "unfilter": n * (U + S)}
-    return {"dt": dt, "n": n, "weak": weak, "per_step_ms": per_step, "alg": alg, "total_c": total_c, "U": U, "S": S,
+    return {"dt": dt, "n": n, "weak": weak, "per_step_ms": per_step, "launches": launches, "alg": alg, "total_c": total_c, "U": U, "S": S,
             "fast": fast, "gather": bool(do_gather), "gather_error": gather_error, "hi_lo": hi - lo,
             "ratio": round(U * unique / sum(C), 3), "streams": streams, "images": images, "rows": rows}
 
@@ -298,6 +302,10 @@ def kernel_report(m, traffic):
         if ms <= 0.02:
             continue
         e = {"ms_per_step": round(ms, 3), "algorithmic_bytes": m["alg"][k]}
+        if m.get("launches", {}).get(k, 1) > 1:
+            # (a batch whose tokens do not fit the pool at once goes through in groups of streams: that many launches per step)
+            e["launches_per_step"] = m["launches"][k]
+            e["ms_per_launch"] = round(ms / m["launches"][k], 3)
         if m["alg"][k]:
             e["gbps"] = round(m["alg"][k] / (ms * 1e-3) / 1e9, 2)
             e["frac_of_hbm_peak"] = round(e["gbps"] / HBM_PEAK_GBPS, 4)
@@ -579,7 +587,9 @@ def main():
                                  "gbps": round((m["total_c"] + n * m["U"]) / (infl_ms * 1e-3) / 1e9, 2)},
             "roofline": {"bound": "hbm", "kernel": dominant + "_kernel", "achieved": d.get("gbps"),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d.get("frac_of_hbm_peak"),
-                         "traffic": d.get("traffic"), "ms_per_launch": d["ms_per_step"],
+                         "traffic": (d.get("traffic") // d.get("launches_per_step", 1)) if d.get("traffic") else d.get("traffic"),
+                         "ms_per_launch": d.get("ms_per_launch", d["ms_per_step"]), "launches_per_step": d.get("launches_per_step", 1),
+                         "algorithmic_bytes_per_launch": d["algorithmic_bytes"] // d.get("launches_per_step", 1),
                          **({"traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                                "workload, not measured in this run)"} if d.get("traffic") else {})},
             "kernels": kernels,

@@ -43,7 +43,8 @@ for k in NAMES.values():
     if f is None or w is None:
         continue
     cfg["kernels"][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "launches": fetch[k]["launches"],
-                         "hbm_bytes_raw": int((f + w) * 1024), "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+                         "hbm_bytes_raw": int((f + w) * 1024), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
+                         "hbm_bytes_per_step": int((2 * f + w) * 1024)}        # (per_launch: the older name of the same figure)
 doc["configs"][kind] = cfg
 json.dump(doc, open(dst, "w"), indent=1)
 print(json.dumps(cfg, indent=1))
