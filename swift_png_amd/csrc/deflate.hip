@@ -2061,6 +2061,7 @@ __device__ __attribute__((noinline)) void d2_backward(const D2Arrays g_, const g
     //  leaves this batch exactly at its end, as it does through literals; a longer hop refetches)
     uint32_t u_next = ((uint32_t)lane < hi) ? way_in(hi - (uint32_t)lane) : 0u, hi_next = hi;
     uint32_t l_next = ((uint32_t)lane < hi) ? (uint32_t)in[bbase + hi - (uint32_t)lane - 1] : 0u;
+    uint32_t litrun = 0;                                       // batches of nothing but literal steps in a row
     for (;;) {
         const bool valid = (uint32_t)lane <= hi;
         const uint32_t c = valid ? hi - (uint32_t)lane : 0u;
@@ -2074,8 +2075,9 @@ __device__ __attribute__((noinline)) void d2_backward(const D2Arrays g_, const g
         const uint32_t len = (u >> 16) & 0x1ff;                // 0: vertex 0 (or nothing)
         unsigned long long pm = 0;
         uint32_t pos = 0;
-        if (!__ballot(valid && c > 0 && len != 1)) { pm = __ballot(valid); pos = 64; }
+        if (!__ballot(valid && c > 0 && len != 1)) { pm = __ballot(valid); pos = 64; litrun += 1; }
         else {
+            litrun = 0;
             while (pos < 64) {
                 pm |= 1ull << pos;
                 const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)pos);
@@ -2097,6 +2099,34 @@ __device__ __attribute__((noinline)) void d2_backward(const D2Arrays g_, const g
         // vertices the leaving hop jumped over are not on the path
         for (uint32_t cc = nhi + 1 + (uint32_t)lane; cc + 64 <= hi; cc += 64) g.pathb[cc] = 0;
         hi = nhi;
+        // Two batches of literals in a row -- incompressible data: the batches below that the forward pass marked "literal ways
+        // in only" (litb) are walked without looking at their ways in at all: every vertex is on the path, its step is the
+        // literal in front of it.  (A load per batch cannot hide behind the few instructions a batch of literals takes; here
+        // the bytes travel three batches ahead.)
+        if (litrun >= 2 && hi >= 128) {
+            const uint32_t q_hi = (sh + hi) >> 6;
+            const uint32_t lbv = (uint32_t)lane <= q_hi ? (uint32_t)g.litb[q_hi - (uint32_t)lane] : 0u;
+            const unsigned long long nz = __ballot(lbv == 0);
+            const uint32_t z = nz ? (uint32_t)__ffsll((long long)nz) - 1 : 64u;     // aligned batches q_hi .. q_hi - z + 1
+            if (z >= 2) {
+                int c_lo = (int)(64 * (q_hi - z + 1)) - (int)sh;                 // their lowest vertex (vertex 0 has no way in)
+                c_lo = c_lo < 1 ? 1 : c_lo;
+                auto lit_at = [&](int top) -> uint32_t { const int cc = top - lane; return cc >= c_lo ? (uint32_t)in[bbase + (uint32_t)cc - 1] : 0u; };
+                uint32_t l0 = lit_at((int)hi), l1 = lit_at((int)hi - 64), l2 = lit_at((int)hi - 128);
+                for (int top = (int)hi; top >= c_lo; top -= 64) {
+                    const uint32_t lt = l0;
+                    l0 = l1; l1 = l2; l2 = lit_at(top - 192);
+                    const int cc = top - lane;
+                    if (cc >= c_lo) {
+                        if ((uint32_t)cc < count) g.pathb[cc] = 1;
+                        g.step[cc - 1] = 0x0001ff00u;
+                        atomicAdd(&s.freq[lt], 1u);
+                    }
+                }
+                hi = (uint32_t)(c_lo - 1);
+                litrun = 0;
+            }
+        }
     }
     if (lane == 0) s.freq[256] = 1;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
