@@ -1657,12 +1657,12 @@ __device__ __attribute__((noinline)) void d2_skip_rule(const D2Arrays g_, uint64
     const uint32_t nb = ((uint32_t)sh + count + 64) >> 6;      // (as the forward pass: the batch of the end vertex too)
     int skip_until = 0, base = -sh;
     auto info_of = [&](int v) -> uint32_t { return (v >= 0 && (uint32_t)v < count) ? (uint32_t)g.vinfo[vr0 + v] : 1u; };
-    uint32_t info_next = info_of(base + lane);
+    uint32_t iq0 = info_of(base + lane), iq1 = info_of(base + 64 + lane), iq2 = info_of(base + 128 + lane);   // (three batches ahead)
     for (uint32_t j = 0; j < nb; ++j, base += 64) {
         const int v = base + lane;
         const bool valid = v >= 0 && (uint32_t)v < count;
-        const uint32_t info = info_next;
-        info_next = info_of(v + 64);
+        const uint32_t info = iq0;
+        iq0 = iq1; iq1 = iq2; iq2 = info_of(v + 192);
         const uint32_t ext = info & 0x1ff;
         unsigned long long em = __ballot(valid && (info >> 9) != 0), xm = __ballot(valid && ext > 100);
         if (xm || skip_until > base) {
@@ -1862,10 +1862,11 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
             z = z < most ? z : most;
             uint32_t acc = cin;
             {
-                uint32_t lbq = lit_of(v + 64);                               // (batch j + 1; fetched once more below when z == 0: harmless)
+                // (batches j + 1 ..: four loads in flight -- a batch is a load, a look-up and an add)
+                uint32_t q0 = lit_of(v + 64), q1 = lit_of(v + 128), q2 = lit_of(v + 192), q3 = lit_of(v + 256);
                 for (uint32_t i = 1; i <= z; ++i) {
-                    const uint32_t lbc = lbq;
-                    lbq = lit_of(v + 64 * (int)(i + 1));
+                    const uint32_t lbc = q0;
+                    q0 = q1; q1 = q2; q2 = q3; q3 = lit_of(v + 64 * (int)(i + 4));
                     acc += s.depths[lbc];
                 }
             }
@@ -2163,17 +2164,21 @@ __device__ __attribute__((noinline)) Bits d2_block(Bits b_, const D2Arrays g_, c
     b = uni_bits(write_tables(b, final, lane));
     FPROF(5);
     // writeBlock(with:) (:661-707): the path's terms, 64 vertices at a time
-    uint32_t pb_next = (uint32_t)lane < count ? g.pathb[lane] : 0u, st_next = (uint32_t)lane < count ? g.step[lane] : 0u,
-             lt_next = (uint32_t)lane < count ? in[bbase + lane] : 0u;
+    // (what a batch needs travels three batches ahead: a batch of literals is a few hundred cycles of work, a load two thousand)
+    uint32_t pbq[3], stq[3], ltq[3];
+    auto ask = [&](uint32_t vn, uint32_t &pbv, uint32_t &stv, uint32_t &ltv) {
+        const bool inn = vn < count;
+        pbv = inn ? g.pathb[vn] : 0u; stv = inn ? g.step[vn] : 0u; ltv = inn ? in[bbase + vn] : 0u;
+    };
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ask(64u * q + (uint32_t)lane, pbq[q], stq[q], ltq[q]);
     for (uint32_t b0 = 0; b0 < count; b0 += 64) {
         const uint32_t v = b0 + lane;
-        const bool on = v < count && pb_next != 0;
-        const uint32_t st = st_next, lt = lt_next;
-        {
-            const uint32_t vn = v + 64;
-            const bool inn = vn < count;
-            pb_next = inn ? g.pathb[vn] : 0u; st_next = inn ? g.step[vn] : 0u; lt_next = inn ? in[bbase + vn] : 0u;
-        }
+        const bool on = v < count && pbq[0] != 0;
+        const uint32_t st = stq[0], lt = ltq[0];
+        pbq[0] = pbq[1]; stq[0] = stq[1]; ltq[0] = ltq[1];
+        pbq[1] = pbq[2]; stq[1] = stq[2]; ltq[1] = ltq[2];
+        ask(v + 192, pbq[2], stq[2], ltq[2]);
         uint64_t bits = 0; uint32_t nb = 0;
         if (on) {
             const uint32_t cnt = (st >> 16) & 0x1ff, dd = (st >> 8) & 0xff;
