@@ -26,6 +26,8 @@ def main():
     s = spng.load(0)
     images, rows, streams = bench.build_inputs(s, args.unique, 32, args.kind)
     d_streams = [s.to_device(z) for z in streams]
+    s.trim()
+    torch.cuda.empty_cache()
     out = {}
     for n, groups in ((128, 1), (128, 2), (128, 4), (32, 1), (8, 1)):
         job = bench.DecodeJob(spng, s, torch, d_streams, n, 0, args.unique, groups)
