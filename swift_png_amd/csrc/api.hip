@@ -79,6 +79,7 @@ struct spng_ctx {
     void *d_log = nullptr;  size_t log_cap = 0;
     void *d_tok = nullptr;  size_t tok_cap = 0;      // bytes
     void *d_sym = nullptr;  size_t sym_cap = 0;      // several workgroups per stream: 16-bit symbols, windows (bytes)
+    uint64_t sym_failed = 0;                        // a symbol scratch of this size could not be had (forgotten by spng_trim)
     void *d_win = nullptr;  size_t win_cap = 0;
     // token pool of the pipeline (pinflate2.hip): halfwords a compressed byte turned into in the last batch (learned,
     // so that the next batch of the same kind takes one pass), and the pinned word the page counter is read back into
@@ -665,13 +666,21 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
             syms += (p.jobs[i].dst_cap + 15) & ~(uint64_t)7;
         }
         const uint64_t win = (uint64_t)p.jobs.size() * pm * 32768;
-        if (pm >= 2) {
+        // (the symbol scratch is two bytes per output byte: only when it fits a quarter of what is free, and not again after an
+        // allocation of that size has failed -- a failed hipMalloc of gigabytes per call costs more than the parts save)
+        bool afford = syms * 2 <= c->sym_cap;
+        if (!afford && !(c->sym_failed && syms * 2 >= c->sym_failed)) {
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            afford = syms * 2 + win <= (uint64_t)(free_b + c->sym_cap + c->win_cap) / 4;
+        }
+        if (pm >= 2 && afford) {
             bool room = true;
             if (syms * 2 > c->sym_cap) {
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 if (c->d_sym) { HIP_TRY(hipFree(c->d_sym)); c->d_sym = nullptr; c->sym_cap = 0; }
-                if (hipMalloc(&c->d_sym, syms * 2) != hipSuccess) { (void)hipGetLastError(); room = false; }
-                else c->sym_cap = syms * 2;
+                if (hipMalloc(&c->d_sym, syms * 2) != hipSuccess) { (void)hipGetLastError(); room = false; c->sym_failed = syms * 2; }
+                else { c->sym_cap = syms * 2; c->sym_failed = 0; }
             }
             if (room && win > c->win_cap) {
                 HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1830,7 +1839,7 @@ int32_t spng_trim(spng_ctx *c)
         if (*bufs[i]) HIP_TRY(hipFree(*bufs[i]));
         *bufs[i] = nullptr; *caps[i] = 0;
     }
-    c->pool_ratio = 0; c->block_bytes = 0;                     // (what the token pool had learned went with it)
+    c->pool_ratio = 0; c->block_bytes = 0; c->sym_failed = 0;  // (what the token pool had learned went with it)
     return SPNG_DONE;
 }
 
