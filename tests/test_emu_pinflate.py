@@ -57,6 +57,33 @@ def cases():
     yield "text3", deflate(t3, 6, 15, zlib.Z_HUFFMAN_ONLY), t3, 0     # 1- and 2-bit codes: pairs in short subsequences
     yield "zeros", deflate(bytes(200000), 6), bytes(200000), 0     # one-bit codes: short subsequences
     yield "period4", deflate(bytes([1, 2, 3, 255]) * 20000, 9), bytes([1, 2, 3, 255]) * 20000, 0
+    # Fibonacci-like byte frequencies: zlib's length-limited trees reach 15 bits, codes longer than the 9-bit root index share
+    # root prefixes (second-level tables of several depths; round 4 builds the root table in code order and transposes it)
+    deep = []
+    a, b = 1, 1
+    for sym in range(24):
+        deep.append(bytes([sym * 7 % 256]) * a)
+        a, b = b, a + b
+    deep = b"".join(deep)[:200000]
+    deep = bytes(np.random.default_rng(5).permutation(np.frombuffer(deep, dtype=np.uint8)))
+    yield "deeptree", deflate(deep, 6, 15, zlib.Z_HUFFMAN_ONLY), deep, 0
+    # the same for the distance code: matches at Fibonacci-weighted distance decades over a literal background
+    rng2 = np.random.default_rng(6)
+    buf = bytearray(rng2.integers(0, 256, 70000, dtype=np.uint8).tobytes())
+    dists = [1, 2, 3, 4, 6, 9, 14, 22, 35, 55, 90, 140, 230, 370, 600, 960, 1500, 2500, 4000, 6500, 10000, 16000, 26000, 32000]
+    w = [max(1, int(1.6 ** k)) for k in range(len(dists))][::-1]
+    pick = rng2.choice(len(dists), 6000, p=np.array(w) / sum(w))
+    at = 33000
+    for k in pick:
+        d = dists[k]
+        n = int(rng2.integers(4, 12))
+        if at + n >= len(buf):
+            break
+        for i in range(n):
+            buf[at + i] = buf[at + i - d]
+        at += n + int(rng2.integers(0, 3))
+    deepd = bytes(buf[:at])
+    yield "deepdist", deflate(deepd, 9), deepd, 0
     co = zlib.compressobj(6)
     parts = []
     for i in range(0, len(rows), 9000):
