@@ -1,0 +1,77 @@
+"""The level >= 8 deflate kernels of csrc/deflate.hip (dfl2_begin -> dfl2_search -> dfl2_advance -> dfl2_parse, round by round), run
+on the CPU by the wave emulator of tools/emu and compared with the oracle's stream bit for bit.  The build container has no GPU:
+this is how the LOGIC of the device deflater -- hash chains and candidate records, the skip rule, offer tables, the shortest-path
+passes, trees, the bit writer -- is checked before a GPU minute is spent.  The emulator compiles a COPY of the source prepared by
+tools/emu/prep_deflate.py (launches blanked, a few meetings of the wave where the source relies on lock-step execution); timing
+and memory ordering are not modelled, the `-m gpu` tests remain the parity tests proper."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
+
+import pnghelp as ph  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    import prep_deflate
+    d = tmp_path_factory.mktemp("emu_deflate")
+    inc = d / "deflate_emu.inc"
+    inc.write_text(prep_deflate.prepare(open(os.path.join(ROOT, "swift_png_amd", "csrc", "deflate.hip")).read()))
+    out = d / "emu_deflate2"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DSPNG_EMU", f'-DEMU_DEFLATE_SRC="{inc}"', "-I" + os.path.join(ROOT, "tools", "emu"),
+                    "-I" + os.path.join(ROOT, "swift_png_amd", "csrc"), "-x", "c++", "-fpermissive", "-Wno-attributes", "-w", "-o", str(out),
+                    os.path.join(ROOT, "tools", "emu", "emu_deflate2.cpp")], check=True, capture_output=True, timeout=600)
+    return out
+
+
+def inputs():
+    rng = np.random.default_rng(2)
+    walk = bytes((np.cumsum(rng.integers(-2, 3, 20000)) % 256).astype(np.uint8))       # four blocks (2047, 4095, 8191, the rest)
+    runs = b"".join(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 400)) for _ in range(60))   # runs > 100: the skip rule; > 66: beyond the offer table
+    text = (b"It was the best of times, it was the worst of times, it was the age of wisdom, it was the age of foolishness, " * 60)[:6000]
+    noise = rng.integers(0, 256, 3000, dtype=np.uint8).tobytes()
+    mixed = noise[:2500] + bytes(3000) + text[:2000] + rng.integers(0, 4, 3000, dtype=np.uint8).tobytes()
+    y, x = np.mgrid[0:40, 0:96]
+    img = np.stack([(x * 2 + y) % 256, (x + y * 3) % 256, (x * y) % 256, np.full_like(x, 255)], axis=-1).astype(np.uint8)
+    rows = ph.orc_filter(img.reshape(-1), 96, 40, 8, 4, False)                          # filtered scanlines of a smooth RGBA image
+    return {"walk": walk, "runs": runs, "text": text, "noise": noise, "mixed": mixed, "rows": rows,
+            "zeros": bytes(3000), "two": b"ab", "three": b"abc", "empty": b""}
+
+
+INPUTS = inputs()
+CASES = [("walk", 9, 3), ("runs", 8, 3), ("runs", 9, 2), ("text", 9, 1), ("text", 10, 5), ("noise", 9, 3), ("mixed", 9, 3), ("mixed", 13, 3),
+         ("rows", 9, 3), ("rows", 12, 4), ("zeros", 9, 3), ("two", 9, 3), ("three", 9, 3), ("empty", 9, 3)]
+
+
+@pytest.mark.parametrize("name,level,chunks", CASES)
+def test_emulated_level8_rounds_match_the_oracle(emu, tmp_path, name, level, chunks):
+    """chunks: search workgroups per stream and round (the chunk boundaries re-warm the hash window: any number gives the same records)"""
+    data = INPUTS[name]
+    want = ph.orc_deflate(data, level)
+    (tmp_path / "in").write_bytes(data)
+    (tmp_path / "want").write_bytes(want)
+    r = subprocess.run([str(emu), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0", str(chunks)], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (name, level, r.stdout[-300:], r.stderr[-300:])
+    assert r.stdout.startswith("ok:")
+
+
+def test_prepared_copy_only_differs_where_it_says(tmp_path):
+    """the copy the emulator compiles = the product source but for the documented replacements"""
+    import difflib
+    import prep_deflate
+    src = open(os.path.join(ROOT, "swift_png_amd", "csrc", "deflate.hip")).read()
+    out = prep_deflate.prepare(src)
+    changed = [l for l in difflib.unified_diff(src.splitlines(), out.splitlines(), lineterm="", n=0) if l[:1] in "+-" and l[:3] not in ("+++", "---")]
+    assert 0 < len(changed) < 80, len(changed)
+    for l in changed:
+        assert any(k in l for k in ("<<<", "(void)0", "s_waitcnt", "__builtin_amdgcn_fence", 'asm volatile("" ::: "memory")', "emu_bb", "g.bbase[q]", "b.nacc", "hipMemsetAsync", "dfl2_", "deflate_")), l

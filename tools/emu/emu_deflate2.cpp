@@ -1,0 +1,79 @@
+// emu_deflate2.cpp -- TEST INFRASTRUCTURE: runs the level >= 8 kernels of csrc/deflate.hip (dfl2_begin / dfl2_search /
+// dfl2_advance / dfl2_parse) on the CPU (tools/emu/hip/hip_runtime.h) over one stream, round by round and with the two sets
+// of candidate records alternating the way api.hip drives them, and compares the bytes with the expected stream (the oracle's).
+// Built and used by tests/test_emu_deflate.py from a copy of deflate.hip whose launchers and `s_waitcnt` lines are blanked
+// (EMU_DEFLATE_SRC); never part of the product.
+//
+//   emu_deflate2 <input file> <expected stream file> <level> <format 0 zlib | 1 raw (ios)> [chunks per stream]
+//   exit code 0: SPNG_DONE and identical bytes; 1: anything else (printed)
+#include EMU_DEFLATE_SRC
+
+#include <fstream>
+#include <iostream>
+
+using namespace spng;
+
+static std::vector<uint8_t> slurp(const char *path)
+{
+    std::ifstream f(path, std::ios::binary);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) { fprintf(stderr, "usage\n"); return 2; }
+    std::vector<uint8_t> src = slurp(argv[1]), want = slurp(argv[2]);
+    const int level = atoi(argv[3]), format = atoi(argv[4]);
+    const uint32_t cps = argc > 5 ? (uint32_t)atoi(argv[5]) : 3;
+    const uint64_t n = src.size();
+    std::vector<uint8_t> dst(want.size() + 4096, 0xEE);
+    src.resize(n + 64);                                          // (the kernels read keys a few bytes past positions they search)
+
+    const uint64_t V = deflate2_vertices(n), B = V / 64 + 2;
+    std::vector<uint16_t> vinfo[2] = {std::vector<uint16_t>(V, 0xDEAD), std::vector<uint16_t>(V, 0xBEEF)};
+    std::vector<uint64_t> bbase[2] = {std::vector<uint64_t>(B, 0), std::vector<uint64_t>(B, 0)};
+    std::vector<uint32_t> bwords[2] = {std::vector<uint32_t>(B, 0), std::vector<uint32_t>(B, 0)};
+    std::vector<uint64_t> emask(B, 0);
+    std::vector<uint32_t> up(V + 2, 0), step(V + 2, 0);
+    std::vector<uint8_t> pathb(V + 2, 0), litb(B, 0);
+    const uint64_t pool_words = (n < (1u << 21) ? n : (1u << 21)) * 30 + 4096;
+    std::vector<uint32_t> pool[2] = {std::vector<uint32_t>(pool_words, 0), std::vector<uint32_t>(pool_words, 0)};
+    unsigned long long pool_next[2] = {0, 0};
+    std::vector<uint32_t> rings((size_t)cps * 65536, 0);
+    D2State state;
+    memset(&state, 0, sizeof state);
+    D2Stream st;
+    memset(&st, 0, sizeof st);
+    st.src = src.data(); st.dst = dst.data(); st.src_len = n; st.dst_cap = dst.size();
+    st.format = format == 1 ? SPNG_FORMAT_IOS : SPNG_FORMAT_ZLIB; st.level = level; st.image = 0; st.exponent = 15; st.more = 0;
+    st.state = &state;
+    st.vinfo = vinfo[0].data(); st.bbase = bbase[0].data(); st.bwords = bwords[0].data(); st.emask = emask.data();
+    st.vinfo2 = vinfo[1].data(); st.bbase2 = bbase[1].data(); st.bwords2 = bwords[1].data();
+    st.up = up.data(); st.step = step.data(); st.pathb = pathb.data(); st.litb = litb.data();
+    spng_result res;
+    memset(&res, 0xff, sizeof res);
+
+    uint64_t pos = 0; uint32_t lim = 2048;
+    const uint32_t rounds = deflate2_plan(n, false, pos, lim);
+    const uint32_t chunk = (((1u << 21) / cps + 63) / 64) * 64;
+    emu::launch(1, 256, [&] { dfl2_begin_kernel(&st, 1); });
+    for (uint32_t r = 0; r < rounds; ++r) {
+        const uint32_t par = r & 1;
+        pool_next[par] = 0;
+        emu::launch(cps, SPNG_D2_WAVES * 64, [&] { dfl2_search_kernel(&st, cps, chunk, pool[par].data(), &pool_next[par], pool_words, rings.data(), par); });
+        emu::launch(1, 256, [&] { dfl2_advance_kernel(&st, 1); });
+        emu::launch(1, 64, [&] { dfl2_parse_kernel(&st, pool[par].data(), &res, par); });
+        if (getenv("EMU_VERBOSE")) fprintf(stderr, "round %u: pos %llu limit %u total %llu fail %u done %u\n", r, (unsigned long long)state.pos, state.limit,
+                                           (unsigned long long)state.total, state.fail, state.done);
+    }
+    if (getenv("EMU_DUMP")) { std::ofstream o(getenv("EMU_DUMP"), std::ios::binary); o.write((const char *)dst.data(), (std::streamsize)res.written); }
+    if (res.status != SPNG_DONE || !state.done || state.fail) { printf("status %d done %u fail %u after %u rounds\n", res.status, state.done, state.fail, rounds); return 1; }
+    if (res.written != want.size() || memcmp(dst.data(), want.data(), want.size())) {
+        size_t k = 0;
+        while (k < want.size() && k < res.written && dst[k] == want[k]) ++k;
+        printf("stream differs: %llu bytes against %zu expected, first difference at %zu\n", (unsigned long long)res.written, want.size(), k);
+        return 1;
+    }
+    printf("ok: %llu -> %llu bytes in %u rounds\n", (unsigned long long)n, (unsigned long long)res.written, rounds);
+    return 0;
+}

@@ -52,6 +52,7 @@ struct Fiber {
     int op = 0;
     uint64_t in0 = 0, in1 = 0, out = 0;
     int src_lane = 0;
+    int line = 0;                                       // source line of the wave builtin the fiber waits at (EMU_WHERE)
     const std::function<void()> *body = nullptr;
 };
 
@@ -84,7 +85,12 @@ inline void resolve_wave(std::vector<Fiber> &fb, size_t base, size_t n)
         Fiber &f = fb[base + l];
         if (f.state == DONE) continue;
         if (!op) op = f.op;
-        if (f.op != op) { fprintf(stderr, "emu: wave diverged at a wave builtin (ops %d vs %d, block %u wave %zu)\n", op, f.op, f.bid.x, base / 64); abort(); }
+        if (f.op != op) {
+            fprintf(stderr, "emu: wave diverged at a wave builtin (ops %d vs %d, block %u wave %zu)\n", op, f.op, f.bid.x, base / 64);
+            for (size_t k = 0; k < n; ++k) if (fb[base + k].state != DONE) fprintf(stderr, " l%zu:op%d@%d", k, fb[base + k].op, fb[base + k].line);
+            fprintf(stderr, "\n");
+            abort();
+        }
     }
     uint64_t ballot = 0;
     for (size_t l = 0; l < n; ++l) if (fb[base + l].state != DONE && fb[base + l].in0) ballot |= 1ull << l;
@@ -262,3 +268,18 @@ inline void __threadfence() {}
 inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
+inline unsigned atomicMin(unsigned *p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T __hip_atomic_fetch_min(T *p, T v, int, int) { T o = *p; if (v < o) *p = v; return o; }
+// s_sleep inside a wave-uniform spin loop: the wave meets and the scheduler turns to the other waves of the workgroup
+inline void __builtin_amdgcn_s_sleep(int) { emu::wave_op(emu::OP_FENCE, 0); }
+inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+
+// ---- diagnostics: remember the source line of every wave builtin a fiber waits at (printed when a wave diverges) -----------
+#define __builtin_amdgcn_readfirstlane(v) (emu::cur()->line = __LINE__, __builtin_amdgcn_readfirstlane(v))
+#define __builtin_amdgcn_readlane(v, l) (emu::cur()->line = __LINE__, __builtin_amdgcn_readlane(v, l))
+#define __ballot(p) (emu::cur()->line = __LINE__, __ballot(p))
+#define __shfl(...) (emu::cur()->line = __LINE__, __shfl(__VA_ARGS__))
+#define __shfl_xor(...) (emu::cur()->line = __LINE__, __shfl_xor(__VA_ARGS__))
+#define __builtin_amdgcn_fence(...) (emu::cur()->line = __LINE__, __builtin_amdgcn_fence(__VA_ARGS__))
+#define __builtin_amdgcn_update_dpp(...) (emu::cur()->line = __LINE__, __builtin_amdgcn_update_dpp(__VA_ARGS__))
+#define __builtin_amdgcn_s_sleep(n) (emu::cur()->line = __LINE__, __builtin_amdgcn_s_sleep(n))

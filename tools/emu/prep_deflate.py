@@ -1,0 +1,41 @@
+"""TEST INFRASTRUCTURE: a copy of csrc/deflate.hip that the CPU wave emulator (tools/emu) can compile -- the product source is
+not touched.  What is changed in the copy, each by an exact-text replacement that fails loudly when the source moves on:
+
+  * kernel launches (`kernel<<<grid, block, 0, stream>>>(...)`) are blanked: the emulator's driver launches the kernels itself;
+  * `s_waitcnt` inline assembly is dropped (memory is sequentially consistent in the emulator);
+  * lock-step assumptions the fiber emulator does not keep (a wave's lanes run one after another between two wave builtins):
+    a meeting of the wave is put where the source relies on "every lane stores, then every lane ORs", and a wave-uniform load
+    that sits inside a lane-dependent `?:` is hoisted in front of it.
+
+    python tools/emu/prep_deflate.py <csrc/deflate.hip> <out file>
+"""
+import re
+import sys
+
+MEET = '__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");'
+PATCHES = [
+    # bulk_put: the serial writer's pending byte is stored by every lane before any lane ORs its bits into the ring
+    ("    if (b.nacc) s.out[b.total & (OUTB - 1)] = (uint8_t)b.acc;  // the pending bits of the serial writer join the ring\n",
+     "    if (b.nacc) s.out[b.total & (OUTB - 1)] = (uint8_t)b.acc;\n    " + MEET + "\n"),
+    # d2_relax_long: uni64 under a lane-dependent condition
+    ("    const uint32_t w = (uint32_t)lane < cnt ? g.pool[uni64(g.bbase[q]) + pre + lane] : 0u;\n",
+     "    const uint64_t emu_bb = uni64(g.bbase[q]);\n    const uint32_t w = (uint32_t)lane < cnt ? g.pool[emu_bb + pre + lane] : 0u;\n"),
+]
+
+
+def prepare(text: str) -> str:
+    out = text.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "((void)0)")
+    # "LDS serves a wave's operations in order": where the source only tells the COMPILER to keep an order (the keys of a group
+    # of vertices before the next group's reads of the ring), the emulator's lanes have to meet
+    assert out.count('asm volatile("" ::: "memory");') >= 2
+    out = out.replace('asm volatile("" ::: "memory");', MEET)
+    out, n = re.subn(r"\b[A-Za-z_][A-Za-z_0-9]*(?:<[A-Za-z_0-9, ]*>)?<<<[^;]*?>>>\([^;]*?\);", "(void)0;", out, flags=re.S)
+    assert n >= 8, f"only {n} kernel launches found"
+    for old, new in PATCHES:
+        assert old in out, "deflate.hip moved on: " + old.strip()[:80]
+        out = out.replace(old, new)
+    return out
+
+
+if __name__ == "__main__":
+    open(sys.argv[2], "w").write(prepare(open(sys.argv[1]).read()))
