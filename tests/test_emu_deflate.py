@@ -18,19 +18,28 @@ sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
 import pnghelp as ph  # noqa: E402
 
 
-@pytest.fixture(scope="module")
-def emu(tmp_path_factory):
+def build(d, round_vertices=0):
     if not shutil.which("g++"):
         pytest.skip("g++ not available")
     import prep_deflate
-    d = tmp_path_factory.mktemp("emu_deflate")
     inc = d / "deflate_emu.inc"
-    inc.write_text(prep_deflate.prepare(open(os.path.join(ROOT, "swift_png_amd", "csrc", "deflate.hip")).read()))
+    inc.write_text(prep_deflate.prepare(open(os.path.join(ROOT, "swift_png_amd", "csrc", "deflate.hip")).read(), round_vertices))
     out = d / "emu_deflate2"
     subprocess.run(["g++", "-O1", "-std=c++17", "-DSPNG_EMU", f'-DEMU_DEFLATE_SRC="{inc}"', "-I" + os.path.join(ROOT, "tools", "emu"),
                     "-I" + os.path.join(ROOT, "swift_png_amd", "csrc"), "-x", "c++", "-fpermissive", "-Wno-attributes", "-w", "-o", str(out),
                     os.path.join(ROOT, "tools", "emu", "emu_deflate2.cpp")], check=True, capture_output=True, timeout=600)
     return out
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    return build(tmp_path_factory.mktemp("emu_deflate"))
+
+
+@pytest.fixture(scope="module")
+def emu_small_rounds(tmp_path_factory):
+    """rounds of 2^14 vertices: blocks of 2047 + 4095 + 8191 terms fill the first round, the block of 16383 the second"""
+    return build(tmp_path_factory.mktemp("emu_deflate_rv"), 1 << 14)
 
 
 def inputs():
@@ -63,6 +72,22 @@ def test_emulated_level8_rounds_match_the_oracle(emu, tmp_path, name, level, chu
                        timeout=900)
     assert r.returncode == 0, (name, level, r.stdout[-300:], r.stderr[-300:])
     assert r.stdout.startswith("ok:")
+
+
+@pytest.mark.parametrize("name,level", [("walk30k", 9), ("mixed30k", 9), ("walk30k", 8)])
+def test_emulated_rounds_carry_their_state(emu_small_rounds, tmp_path, name, level):
+    """two rounds (the product needs > 2 MiB for that): bit writer, depths, block limit and the search's own cursor carried from
+    round to round, the second round's candidates in the second set of records"""
+    rng = np.random.default_rng(11)
+    data = {"walk30k": bytes((np.cumsum(rng.integers(-2, 3, 30000)) % 256).astype(np.uint8)),
+            "mixed30k": (INPUTS["mixed"] * 3)[:30000]}[name]
+    want = ph.orc_deflate(data, level)
+    (tmp_path / "in").write_bytes(data)
+    (tmp_path / "want").write_bytes(want)
+    r = subprocess.run([str(emu_small_rounds), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0", "2"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (name, level, r.stdout[-300:], r.stderr[-300:])
+    assert r.stdout.strip().endswith("in 2 rounds"), r.stdout
 
 
 def test_prepared_copy_only_differs_where_it_says(tmp_path):

@@ -55,7 +55,7 @@ int main(int argc, char **argv)
 
     uint64_t pos = 0; uint32_t lim = 2048;
     const uint32_t rounds = deflate2_plan(n, false, pos, lim);
-    const uint32_t chunk = (((1u << 21) / cps + 63) / 64) * 64;
+    const uint32_t chunk = ((D2_RV / cps + 63) / 64) * 64;
     emu::launch(1, 256, [&] { dfl2_begin_kernel(&st, 1); });
     for (uint32_t r = 0; r < rounds; ++r) {
         const uint32_t par = r & 1;

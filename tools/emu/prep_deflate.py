@@ -23,7 +23,13 @@ PATCHES = [
 ]
 
 
-def prepare(text: str) -> str:
+def prepare(text: str, round_vertices: int = 0) -> str:
+    """round_vertices: vertices per stream and round in the copy (a power of two; 0: the product's 2^21) -- small rounds let a
+    20 KB input go through several rounds (state carried from round to round, the search a round ahead, both sets of records)"""
+    if round_vertices:
+        old = "static constexpr uint32_t D2_RV = 1u << 21;"
+        assert old in text
+        text = text.replace(old, f"static constexpr uint32_t D2_RV = {round_vertices}u;")
     out = text.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "((void)0)")
     # "LDS serves a wave's operations in order": where the source only tells the COMPILER to keep an order (the keys of a group
     # of vertices before the next group's reads of the ring), the emulator's lanes have to meet
