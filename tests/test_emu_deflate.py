@@ -90,6 +90,19 @@ def test_emulated_rounds_carry_their_state(emu_small_rounds, tmp_path, name, lev
     assert r.stdout.strip().endswith("in 2 rounds"), r.stdout
 
 
+@pytest.mark.parametrize("cuts", [(100, 5000, 5001, 12000), (1, 2, 3, 300, 19999), (7000,)])
+def test_emulated_pushes_give_the_one_shot_stream(emu, tmp_path, cuts):
+    """spng_deflate_resume_batch as LZ77.Deflator.push(_:last:) drives it: a call per piece with `more` set (only blocks whose every
+    vertex sees its whole look-ahead are taken), the state kept between calls -- the bytes are those of one call over everything"""
+    data = INPUTS["walk"]
+    want = ph.orc_deflate(data, 9)
+    (tmp_path / "in").write_bytes(data)
+    (tmp_path / "want").write_bytes(want)
+    r = subprocess.run([str(emu), str(tmp_path / "in"), str(tmp_path / "want"), "9", "0", "3"] + [str(c) for c in cuts], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (cuts, r.stdout[-300:], r.stderr[-300:])
+
+
 def test_prepared_copy_only_differs_where_it_says(tmp_path):
     """the copy the emulator compiles = the product source but for the documented replacements"""
     import difflib

@@ -4,7 +4,8 @@
 // Built and used by tests/test_emu_deflate.py from a copy of deflate.hip whose launchers and `s_waitcnt` lines are blanked
 // (EMU_DEFLATE_SRC); never part of the product.
 //
-//   emu_deflate2 <input file> <expected stream file> <level> <format 0 zlib | 1 raw (ios)> [chunks per stream]
+//   emu_deflate2 <input file> <expected stream file> <level> <format 0 zlib | 1 raw (ios)> [chunks per stream] [cut ...]
+//   cut ...: the input arrives in pieces (spng_deflate_resume_batch): a call per cut with `more` set, the state kept, then the rest
 //   exit code 0: SPNG_DONE and identical bytes; 1: anything else (printed)
 #include EMU_DEFLATE_SRC
 
@@ -54,17 +55,27 @@ int main(int argc, char **argv)
     memset(&res, 0xff, sizeof res);
 
     uint64_t pos = 0; uint32_t lim = 2048;
-    const uint32_t rounds = deflate2_plan(n, false, pos, lim);
     const uint32_t chunk = ((D2_RV / cps + 63) / 64) * 64;
-    emu::launch(1, 256, [&] { dfl2_begin_kernel(&st, 1); });
-    for (uint32_t r = 0; r < rounds; ++r) {
-        const uint32_t par = r & 1;
-        pool_next[par] = 0;
-        emu::launch(cps, SPNG_D2_WAVES * 64, [&] { dfl2_search_kernel(&st, cps, chunk, pool[par].data(), &pool_next[par], pool_words, rings.data(), par); });
-        emu::launch(1, 256, [&] { dfl2_advance_kernel(&st, 1); });
-        emu::launch(1, 64, [&] { dfl2_parse_kernel(&st, pool[par].data(), &res, par); });
-        if (getenv("EMU_VERBOSE")) fprintf(stderr, "round %u: pos %llu limit %u total %llu fail %u done %u\n", r, (unsigned long long)state.pos, state.limit,
-                                           (unsigned long long)state.total, state.fail, state.done);
+    std::vector<uint64_t> cuts;
+    for (int a = 6; a < argc; ++a) cuts.push_back(strtoull(argv[a], nullptr, 10));
+    cuts.push_back(n);
+    uint32_t rounds = 0;
+    for (size_t call = 0; call < cuts.size(); ++call) {
+        // one call of spng_deflate_resume_batch: the bytes so far, `more` unless they are all
+        st.src_len = cuts[call] < n ? cuts[call] : n;
+        st.more = call + 1 < cuts.size() ? 1 : 0;
+        const uint32_t calls_rounds = deflate2_plan(st.src_len, st.more != 0, pos, lim);
+        emu::launch(1, 256, [&] { dfl2_begin_kernel(&st, 1); });
+        for (uint32_t r = 0; r < calls_rounds; ++r, ++rounds) {
+            const uint32_t par = r & 1;
+            pool_next[par] = 0;
+            emu::launch(cps, SPNG_D2_WAVES * 64, [&] { dfl2_search_kernel(&st, cps, chunk, pool[par].data(), &pool_next[par], pool_words, rings.data(), par); });
+            emu::launch(1, 256, [&] { dfl2_advance_kernel(&st, 1); });
+            emu::launch(1, 64, [&] { dfl2_parse_kernel(&st, pool[par].data(), &res, par); });
+            if (getenv("EMU_VERBOSE")) fprintf(stderr, "call %zu round %u: pos %llu limit %u total %llu fail %u done %u status %d\n", call, r, (unsigned long long)state.pos,
+                                               state.limit, (unsigned long long)state.total, state.fail, state.done, res.status);
+        }
+        if (st.more && res.status != SPNG_NEED_MORE_INPUT) { printf("call %zu (more): status %d\n", call, res.status); return 1; }
     }
     if (getenv("EMU_DUMP")) { std::ofstream o(getenv("EMU_DUMP"), std::ios::binary); o.write((const char *)dst.data(), (std::streamsize)res.written); }
     if (res.status != SPNG_DONE || !state.done || state.fail) { printf("status %d done %u fail %u after %u rounds\n", res.status, state.done, state.fail, rounds); return 1; }
