@@ -1,5 +1,5 @@
-"""The level >= 8 deflate kernels of csrc/deflate.hip (dfl2_begin -> dfl2_search -> dfl2_advance -> dfl2_parse, round by round), run
-on the CPU by the wave emulator of tools/emu and compared with the oracle's stream bit for bit.  The build container has no GPU:
+"""The deflate kernels of csrc/deflate.hip -- levels >= 8: dfl2_begin -> dfl2_search -> dfl2_advance -> dfl2_parse, round by round;
+levels 0-7: deflate_kernel -- run on the CPU by the wave emulator of tools/emu and compared with the oracle's stream bit for bit.  The build container has no GPU:
 this is how the LOGIC of the device deflater -- hash chains and candidate records, the skip rule, offer tables, the shortest-path
 passes, trees, the bit writer -- is checked before a GPU minute is spent.  The emulator compiles a COPY of the source prepared by
 tools/emu/prep_deflate.py (launches blanked, a few meetings of the wave where the source relies on lock-step execution); timing
@@ -88,6 +88,31 @@ def test_emulated_rounds_carry_their_state(emu_small_rounds, tmp_path, name, lev
                        timeout=900)
     assert r.returncode == 0, (name, level, r.stdout[-300:], r.stderr[-300:])
     assert r.stdout.strip().endswith("in 2 rounds"), r.stdout
+
+
+@pytest.mark.parametrize("level", [0, 1, 4, 6, 7])
+@pytest.mark.parametrize("name", ["walk", "text", "zeros", "noise", "rows", "mixed", "empty", "two"])
+def test_emulated_greedy_lazy_kernel_matches_the_oracle(emu, tmp_path, name, level):
+    """levels 0-7 (`deflate_kernel`, one wave per stream; level 6 is what the bench's swift-png-made inputs are made with)"""
+    data = INPUTS[name]
+    want = ph.orc_deflate(data, level)
+    (tmp_path / "in").write_bytes(data)
+    (tmp_path / "want").write_bytes(want)
+    r = subprocess.run([str(emu), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (name, level, r.stdout[-300:], r.stderr[-300:])
+
+
+def test_emulated_level6_over_many_blocks(emu, tmp_path):
+    """96 KiB of scanline-like bytes: some twenty blocks of 2047 terms, as PNG.Image.compress makes them"""
+    rng = np.random.default_rng(12)
+    a = rng.integers(-3, 4, 96 * 1024).astype(np.int16)
+    a[rng.random(len(a)) < 0.6] = 0
+    data = a.astype(np.uint8).tobytes()
+    want = ph.orc_deflate(data, 6)
+    (tmp_path / "in").write_bytes(data)
+    (tmp_path / "want").write_bytes(want)
+    r = subprocess.run([str(emu), str(tmp_path / "in"), str(tmp_path / "want"), "6", "0"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-300:])
 
 
 @pytest.mark.parametrize("cuts", [(100, 5000, 5001, 12000), (1, 2, 3, 300, 19999), (7000,)])
