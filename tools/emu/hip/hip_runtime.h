@@ -27,7 +27,8 @@
 
 typedef int hipError_t;
 typedef void *hipStream_t;
-static const hipError_t hipSuccess = 0;
+static const hipError_t hipSuccess = 0, hipErrorInvalidValue = 1;
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 inline hipError_t hipGetLastError() { return hipSuccess; }
 
 #define __device__
@@ -257,19 +258,56 @@ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
 inline unsigned long long __builtin_readcyclecounter_emu() { return 0; }
+#ifdef __clang__
+// (clang -- the host compiler for kernels written with its vector extensions -- has the __hip_atomic builtins itself)
+#ifndef __HIP_MEMORY_SCOPE_WORKGROUP
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#endif
+#else
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
 #define __HIP_MEMORY_SCOPE_AGENT 1
 template <class T> inline T __hip_atomic_fetch_add(T *p, T v, int, int) { T o = *p; *p = o + v; return o; }
 template <class T> inline T __hip_atomic_fetch_or(T *p, T v, int, int) { T o = *p; *p = o | v; return o; }
 template <class T> inline T __hip_atomic_load(const T *p, int, int) { return *p; }
 template <class T> inline void __hip_atomic_store(T *p, T v, int, int) { *p = v; }
+#endif
 inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 inline void __threadfence() {}
 inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline unsigned atomicMax(unsigned *p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 inline unsigned atomicMin(unsigned *p, unsigned v) { unsigned o = *p; if (v < o) *p = v; return o; }
+#ifndef __clang__
 template <class T> inline T __hip_atomic_fetch_min(T *p, T v, int, int) { T o = *p; if (v < o) *p = v; return o; }
+#endif
+inline int __any(int p) { return emu::wave_op(emu::OP_BALLOT, p ? 1 : 0) != 0; }
+// v_perm_b32: byte k of the result = byte sel[k] of {hi, lo} (0-3: lo, 4-7: hi); 0x0c: 0x00 (the other special selectors are not used)
+inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel)
+{
+    const uint64_t both = (uint64_t)hi << 32 | lo;
+    unsigned r = 0;
+    for (int k = 0; k < 4; ++k) {
+        const unsigned c = (sel >> (8 * k)) & 0xff;
+        unsigned b;
+        if (c <= 7) b = (unsigned)(both >> (8 * c)) & 0xff;
+        else if (c == 0x0c) b = 0;
+        else if (c >= 0x0d) b = 0xff;
+        else { fprintf(stderr, "emu: v_perm selector 0x%02x not modelled\n", c); abort(); }
+        r |= b << (8 * k);
+    }
+    return r;
+}
+// v_lerp_u8: per byte (a + b + (c & 1)) >> 1
+inline unsigned __builtin_amdgcn_lerp(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r = 0;
+    for (int k = 0; k < 4; ++k) r |= ((((a >> (8 * k)) & 255) + ((b >> (8 * k)) & 255) + ((c >> (8 * k)) & 1)) >> 1) << (8 * k);
+    return r;
+}
 // s_sleep inside a wave-uniform spin loop: the wave meets and the scheduler turns to the other waves of the workgroup
 inline void __builtin_amdgcn_s_sleep(int) { emu::wave_op(emu::OP_FENCE, 0); }
 inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }

@@ -43,5 +43,18 @@ def prepare(text: str, round_vertices: int = 0) -> str:
     return out
 
 
+def prepare_plain(text: str, patches=()) -> str:
+    """the same for a source without lock-step patches of its own (csrc/unfilter.hip): launches blanked, `s_waitcnt` dropped,
+    compiler-only barriers turned into meetings of the wave, plus the exact-text `patches` given"""
+    out = text.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "((void)0)")
+    out = out.replace('asm volatile("" ::: "memory");', MEET)
+    out, n = re.subn(r"\b[A-Za-z_][A-Za-z_0-9]*(?:<[A-Za-z_0-9, ]*>)?<<<[^;]*?>>>\([^;]*?\);", "(void)0;", out, flags=re.S)
+    assert n >= 1
+    for old, new in patches:
+        assert old in out, "the source moved on: " + old.strip()[:80]
+        out = out.replace(old, new)
+    return out
+
+
 if __name__ == "__main__":
     open(sys.argv[2], "w").write(prepare(open(sys.argv[1]).read()))
