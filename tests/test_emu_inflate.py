@@ -1,0 +1,119 @@
+"""inflate_kernel of csrc/inflate.hip -- the serial three-wave kernel (scout / decoder-walker / resolver) that gives the reference's
+exact answer wherever the parallel pipeline stops: errors with their payloads, truncation, capacity -- run on the CPU by the wave
+emulator of tools/emu (host compiler: the ROCm clang++) and compared with the oracle: status, bytes, error payload.  The source is
+a prepared copy (tools/emu/prep_deflate.py: compiler-only barriers become meetings of the wave, the eight-token chain walk in GCN
+assembly is restated in C).  Timing and memory ordering are not modelled; the `-m gpu` tests remain the parity tests proper."""
+import os
+import shutil
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
+
+import pnghelp as ph  # noqa: E402
+from test_oracle_decode import _dynamic_header  # noqa: E402
+
+CLANG = os.environ.get("SPNG_HOST_CLANG", "/opt/rocm/lib/llvm/bin/clang++")
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    if not (os.path.exists(CLANG) or shutil.which(CLANG)):
+        pytest.skip("clang++ not available")
+    import prep_deflate
+    d = tmp_path_factory.mktemp("emu_inflate")
+    csrc = os.path.join(ROOT, "swift_png_amd", "csrc")
+    inc, hh = prep_deflate.prepare_inflate(open(os.path.join(csrc, "inflate.hip")).read(), open(os.path.join(csrc, "huffman.hpp")).read(),
+                                           str(d / "huffman_emu.hpp"), os.path.join(csrc, "common.hpp"))
+    (d / "inflate_emu.inc").write_text(inc)
+    (d / "huffman_emu.hpp").write_text(hh)
+    out = d / "emu_inflate"
+    subprocess.run([CLANG, "-O1", "-std=c++17", "-DSPNG_EMU", f'-DEMU_INFLATE_SRC="{d / "inflate_emu.inc"}"', "-I" + os.path.join(ROOT, "tools", "emu"),
+                    "-I" + csrc, "-x", "c++", "-w", "-o", str(out), os.path.join(ROOT, "tools", "emu", "emu_inflate.cpp")],
+                   check=True, capture_output=True, timeout=600)
+    return out
+
+
+def check(emu, tmp_path, z, fmt, cap):
+    """the emulated kernel against the oracle: status, bytes written and their values, the error's payload"""
+    (tmp_path / "z").write_bytes(z)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(fmt), str(cap), str(tmp_path / "out")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-200:], r.stderr[-400:])
+    status, written, consumed, aux0, aux1 = (int(x) for x in r.stdout.split())
+    st, out, used, aux = ph.orc_inflate(z, fmt, cap=cap)
+    assert status == st, (status, st, aux)
+    assert written == len(out) and (tmp_path / "out").read_bytes() == bytes(out)
+    if st >= 16:
+        assert (aux0, aux1) == tuple(aux[:2]), ((aux0, aux1), aux)
+    if st == 0:
+        assert consumed == used
+    return status
+
+
+def payload():
+    rng = np.random.default_rng(1)
+    return bytes((np.cumsum(rng.integers(-2, 3, 30000)) % 256).astype(np.uint8))
+
+
+def test_emulated_serial_kernel_good_streams(emu, tmp_path):
+    data = payload()
+    rng = np.random.default_rng(2)
+    assert check(emu, tmp_path, zlib.compress(data, 6), 0, len(data)) == 0
+    assert check(emu, tmp_path, zlib.compress(data, 1), 0, len(data)) == 0
+    co = zlib.compressobj(9, zlib.DEFLATED, -15)
+    assert check(emu, tmp_path, co.compress(data) + co.flush(), 1, len(data)) == 0                     # raw (CgBI)
+    noise = rng.integers(0, 256, 5000, dtype=np.uint8).tobytes()
+    assert check(emu, tmp_path, zlib.compress(noise, 0), 0, len(noise)) == 0                           # stored blocks
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+    assert check(emu, tmp_path, co.compress(data[:8000]) + co.flush(), 0, 8000) == 0                   # fixed blocks
+    assert check(emu, tmp_path, ph.orc_deflate(data[:12000], 6), 0, 12000) == 0                        # swift-png's own blocks
+    assert check(emu, tmp_path, zlib.compress(bytes(70000), 9), 0, 70000) == 0                         # runs of 258, distance 1
+
+
+def test_emulated_serial_kernel_truncation_and_capacity(emu, tmp_path):
+    data = payload()
+    z = zlib.compress(data, 6)
+    for cut in (0, 1, 2, 3, 100, 5000, len(z) - 4, len(z) - 1):
+        assert check(emu, tmp_path, z[:cut], 0, len(data)) == 1                                        # NEED_MORE_INPUT with the bytes so far
+    assert check(emu, tmp_path, z, 0, 1000) == 64                                                      # output capacity
+    assert check(emu, tmp_path, z, 0, len(data) - 1) == 64
+
+
+def test_emulated_serial_kernel_error_vocabulary(emu, tmp_path):
+    """the vectors of tests/test_oracle_decode.py::test_error_vocabulary / test_codelength_sequence_errors, on the device kernel"""
+    good = zlib.compress(b"hello hello hello hello", 9)
+    assert check(emu, tmp_path, b"\x77\x01" + good[2:], 0, 4096) == 16                                # invalidCompressionMethod(7)
+    assert check(emu, tmp_path, b"\x88\x01" + good[2:], 0, 4096) == 17                                # invalidWindowSize(exponent: 16)
+    assert check(emu, tmp_path, b"\x78\x02" + good[2:], 0, 4096) == 18                                # invalidCheckBits
+    assert check(emu, tmp_path, b"\x78\x20" + good[2:], 0, 4096) == 19                                # unexpectedDictionary
+    bad = bytearray(good)
+    bad[-1] ^= 1
+    assert check(emu, tmp_path, bytes(bad), 0, 4096) == 32                                            # invalidStreamChecksum(declared:computed:)
+    assert check(emu, tmp_path, b"\x78\x01\x07", 0, 4096) == 33                                       # invalidBlockTypeCode(3)
+    assert check(emu, tmp_path, b"\x78\x01\x01\x03\x00\xfc\xfe\x00\x00\x00", 0, 4096) == 34          # LEN / NLEN parity
+    assert check(emu, tmp_path, bytes([0x05 | (31 << 3) & 0xff, (31 >> 5) | 0, 0, 0, 0, 0, 0, 0]), 1, 4096) == 35   # 288 literals
+    assert check(emu, tmp_path, bytes([0x05, 0, 0, 0, 0, 0, 0, 0, 0, 0]), 1, 4096) == 36              # empty code-length code
+    assert check(emu, tmp_path, _dynamic_header(257, 1, [1, 0, 0, 1], "1" + "00"), 1, 64) == 37       # repeat without a previous length
+    clens = [0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1]
+    assert check(emu, tmp_path, _dynamic_header(257, 1, clens, "1" + "1111111" + "1" + "1111111"), 1, 64) == 37     # run past the count
+    assert check(emu, tmp_path, _dynamic_header(257, 1, clens, "1" + "1111111" + "1" + format(120 - 11, "07b")[::-1]), 1, 64) == 38
+    bits = "1" + "10" + "0000001" + "00000"
+    by = bytes(int("".join(reversed(bits[i:i + 8].ljust(8, "0"))), 2) for i in range(0, len(bits), 8)) + b"\0\0"
+    assert check(emu, tmp_path, by, 1, 4096) == 39                                                    # reference in front of the output
+
+
+def test_emulated_serial_kernel_bit_flips(emu, tmp_path):
+    """whatever a damaged stream makes the reference say, the kernel says it too"""
+    data = payload()[:12000]
+    z = zlib.compress(data, 6)
+    rng = np.random.default_rng(7)
+    for _ in range(12):
+        b = bytearray(z)
+        at = int(rng.integers(2, len(b)))
+        b[at] ^= 1 << int(rng.integers(0, 8))
+        check(emu, tmp_path, bytes(b), 0, len(data) + 300)

@@ -56,5 +56,28 @@ def prepare_plain(text: str, patches=()) -> str:
     return out
 
 
+def prepare_inflate(text: str, huffman_text: str, huffman_path: str, common_path: str):
+    """csrc/inflate.hip (the serial three-wave kernel) and the copy of huffman.hpp it is to include: `COMPILER_ORDER()` -- a barrier for
+    the compiler only, where the hardware keeps a wave's LDS operations in order -- becomes a meeting of the wave; the eight-token
+    chain walk written in GCN assembly (v_readlane pairs + s_bitset1) is restated in C; `s_endpgm` aborts.  -> (source, header)"""
+    hh = huffman_text.replace('#define COMPILER_ORDER() asm volatile("" ::: "memory")', "#define COMPILER_ORDER() " + MEET.rstrip(";"))
+    assert hh != huffman_text
+    hh = hh.replace('#include "common.hpp"', f'#include "{common_path}"')
+    a = text.index('                            asm volatile(\n                                "v_readlane_b32 %3, %10, %11')
+    tail = ': "v"(nxt), "v"(nxt2), "s"(ent));'
+    b = text.index(tail, a) + len(tail)
+    walk = """                            {
+                                auto RL = [&](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(l & 63)); };
+                                t2 = RL(nxt2, ent); t1 = RL(nxt, ent); t4 = RL(nxt2, t2); t3 = RL(nxt, t2);
+                                t6 = RL(nxt2, t4); t5 = RL(nxt, t4); p = RL(nxt2, t6); t7 = RL(nxt, t6);
+                                chain = 1ull << (ent & 63) | 1ull << (t1 & 63) | 1ull << (t2 & 63) | 1ull << (t3 & 63) | 1ull << (t4 & 63) |
+                                        1ull << (t5 & 63) | 1ull << (t6 & 63) | 1ull << (t7 & 63);
+                            }"""
+    patches = [('asm volatile("s_endpgm")', "abort()"), (text[a:b], walk),
+               ('asm("s_bitset1_b64 %0, %1" : "+s"(chain) : "s"(p));', "chain |= 1ull << (p & 63);"),
+               ('#include "huffman.hpp"', f'#include "{huffman_path}"')]
+    return prepare_plain(text, patches=patches), hh
+
+
 if __name__ == "__main__":
     open(sys.argv[2], "w").write(prepare(open(sys.argv[1]).read()))
