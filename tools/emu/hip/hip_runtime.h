@@ -285,6 +285,8 @@ inline unsigned atomicMin(unsigned *p, unsigned v) { unsigned o = *p; if (v < o)
 template <class T> inline T __hip_atomic_fetch_min(T *p, T v, int, int) { T o = *p; if (v < o) *p = v; return o; }
 #endif
 inline void __builtin_amdgcn_s_setprio(int) {}
+// v_alignbyte_b32: ({hi, lo} >> 8 * (sh & 3)) & 0xffffffff
+inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3))); }
 inline int __any(int p) { return emu::wave_op(emu::OP_BALLOT, p ? 1 : 0) != 0; }
 // v_perm_b32: byte k of the result = byte sel[k] of {hi, lo} (0-3: lo, 4-7: hi); 0x0c: 0x00 (the other special selectors are not used)
 inline unsigned __builtin_amdgcn_perm(unsigned hi, unsigned lo, unsigned sel)
