@@ -175,9 +175,10 @@ int32_t spng_inflate_batch(spng_ctx *ctx, const spng_stream_desc *descs, uint32_
  * stream, {first bit of the first block that was not complete yet, inflated bytes in front of it}, as the previous call
  * returned them in spng_result.aux of a SPNG_NEED_MORE_INPUT result ({0, 0} or a NULL array: nothing seen yet).
  * Blocks the input now holds completely are decoded by the parallel pipeline exactly once; only the block the input
- * ends in is decoded again by the next call.  (The resume point advances with the pipeline only: blocks it leaves to the
- * serial kernel -- a stream of nothing but stored or fixed blocks behind the point, with no dynamic header for the search to
- * find -- are decoded again from the last point by every call until a call holds the stream's end.)  Results as
+ * ends in is decoded again by the next call.  (Whatever the blocks are: the pipeline's first segment starts at the resume
+ * point and takes stored and fixed blocks like dynamic ones, so a stream without a single dynamic header for the search to
+ * find advances from push to push too -- on one wave.  Only what the pipeline declines altogether -- a pool or page table
+ * that is exhausted -- is left to the serial kernel and decoded again from the last point by the next call.)  Results as
  * spng_inflate_batch (written / consumed count from the start of the stream; the zlib checksum -- the CRC-32 of a gzip
  * member -- is verified over the whole output by the call that reports SPNG_DONE); formats SPNG_FORMAT_ZLIB, SPNG_FORMAT_IOS
  * and SPNG_FORMAT_GZIP (state = bits and bytes of the member's DEFLATE payload; the header is parsed again per call). */

@@ -133,6 +133,42 @@ def test_emulated_pipeline_with_a_small_page_table(emu, tmp_path):
     assert r.returncode == 0, (r.stdout[-300:], r.stderr[-300:])
 
 
+@pytest.mark.parametrize("kind", ["stored", "fixed"])
+def test_emulated_resume_point_moves_past_stored_and_fixed_blocks(emu, tmp_path, kind):
+    """a stream of nothing but stored (or fixed) blocks, cut inside a block: no dynamic header for the search to find, yet the first
+    segment's wave takes every complete block and the serial kernel is told to start at the LAST block boundary (exit 4) -- pushes
+    of such a stream are linear too.  Then the push that brings the rest goes on from that point."""
+    import re
+    rng = np.random.default_rng(21)
+    if kind == "stored":
+        data = rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()
+        z = zlib.compress(data, 0)
+        least = 65535                                        # (one whole stored block at least lies in front of the cut)
+    else:
+        data = bytes((np.cumsum(rng.integers(-2, 3, 120000)) % 256).astype(np.uint8))
+        co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
+        parts = []
+        for i in range(0, len(data), 20000):
+            parts.append(co.compress(data[i:i + 20000]))
+            parts.append(co.flush(zlib.Z_FULL_FLUSH))
+        z = b"".join(parts) + co.flush()
+        least = 60000
+    assert zlib.decompress(z) == data
+    cut = len(z) * 2 // 3
+    (tmp_path / "z").write_bytes(z[:cut])
+    (tmp_path / "raw").write_bytes(data)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", "65536"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 4, (r.stdout[-300:], r.stderr[-300:])
+    m = re.search(r"starts at bit (\d+) with (\d+) bytes in front", r.stdout)
+    bit, pos = int(m.group(1)), int(m.group(2))
+    assert pos >= least and bit > 8 * 1000, (bit, pos)
+    # the next push: the whole stream, resumed at that point with the bytes so far in place
+    (tmp_path / "z").write_bytes(z)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", "65536", "4096", str(bit), str(pos)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-300:], r.stderr[-300:])
+
+
 def test_emulated_pipeline_keeps_the_prefix_of_a_truncated_stream(emu, tmp_path):
     """the input ends in the middle of a block: everything in front of that block is decoded by the pipeline, and the
     serial kernel is told to start at the block boundary (exit 4), not at byte 0"""
