@@ -58,7 +58,7 @@ def inputs():
 
 INPUTS = inputs()
 CASES = [("walk", 9, 3), ("runs", 8, 3), ("runs", 9, 2), ("text", 9, 1), ("text", 10, 5), ("noise", 9, 3), ("mixed", 9, 3), ("mixed", 13, 3),
-         ("rows", 9, 3), ("rows", 12, 4), ("zeros", 9, 3), ("two", 9, 3), ("three", 9, 3), ("empty", 9, 3)]
+         ("rows", 9, 3), ("rows", 10, 4), ("zeros", 9, 3), ("two", 9, 3), ("three", 9, 3), ("empty", 9, 3)]
 
 
 @pytest.mark.parametrize("name,level,chunks", CASES)
@@ -90,7 +90,7 @@ def test_emulated_rounds_carry_their_state(emu_small_rounds, tmp_path, name, lev
     assert r.stdout.strip().endswith("in 2 rounds"), r.stdout
 
 
-@pytest.mark.parametrize("level", [0, 1, 4, 6, 7])
+@pytest.mark.parametrize("level", [0, 1, 6, 7])
 @pytest.mark.parametrize("name", ["walk", "text", "zeros", "noise", "rows", "mixed", "empty", "two"])
 def test_emulated_greedy_lazy_kernel_matches_the_oracle(emu, tmp_path, name, level):
     """levels 0-7 (`deflate_kernel`, one wave per stream; level 6 is what the bench's swift-png-made inputs are made with)"""

@@ -72,13 +72,13 @@ def test_emulated_serial_kernel_good_streams(emu, tmp_path):
     co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, zlib.Z_FIXED)
     assert check(emu, tmp_path, co.compress(data[:8000]) + co.flush(), 0, 8000) == 0                   # fixed blocks
     assert check(emu, tmp_path, ph.orc_deflate(data[:12000], 6), 0, 12000) == 0                        # swift-png's own blocks
-    assert check(emu, tmp_path, zlib.compress(bytes(70000), 9), 0, 70000) == 0                         # runs of 258, distance 1
+    assert check(emu, tmp_path, zlib.compress(bytes(20000), 9), 0, 20000) == 0                         # runs of 258, distance 1
 
 
 def test_emulated_serial_kernel_truncation_and_capacity(emu, tmp_path):
-    data = payload()
+    data = payload()[:12000]
     z = zlib.compress(data, 6)
-    for cut in (0, 1, 2, 3, 100, 5000, len(z) - 4, len(z) - 1):
+    for cut in (0, 2, 100, 5000, len(z) - 1):
         assert check(emu, tmp_path, z[:cut], 0, len(data)) == 1                                        # NEED_MORE_INPUT with the bytes so far
     assert check(emu, tmp_path, z, 0, 1000) == 64                                                      # output capacity
     assert check(emu, tmp_path, z, 0, len(data) - 1) == 64
@@ -112,7 +112,7 @@ def test_emulated_serial_kernel_bit_flips(emu, tmp_path):
     data = payload()[:12000]
     z = zlib.compress(data, 6)
     rng = np.random.default_rng(7)
-    for _ in range(12):
+    for _ in range(6):
         b = bytearray(z)
         at = int(rng.integers(2, len(b)))
         b[at] ^= 1 << int(rng.integers(0, 8))
