@@ -104,8 +104,13 @@ typedef struct spng_image_desc {
     uint8_t     channels;                       /* 1 (v / indexed), 2 (va), 3 (rgb), 4 (rgba)  */
     uint8_t     interlaced;                     /* Adam7                                       */
     uint8_t     format;                         /* SPNG_FORMAT_*                               */
-    uint32_t    reserved;
+    uint32_t    reserved;                       /* flags: SPNG_IMAGE_OVERDRAW (spng_unfilter_resume_batch) */
 } spng_image_desc;
+/* PNG.Context.push(data:overdraw: true) (PNG.Context.swift:88-102, PNG.Image.overdraw, PNG.Image.swift:134-183): while an
+ * interlaced image is incomplete, every assigned pixel is replicated over the cell of storage the later passes will refine,
+ * for progressive display.  Honoured by spng_unfilter_resume_batch: after every call d_storage equals the reference's
+ * image.storage after the same scanlines (pixels no scanline has reached yet keep what the caller put there). */
+enum { SPNG_IMAGE_OVERDRAW = 1 };
 
 /* ---- utilities ----------------------------------------------------------------------------- */
 int32_t     spng_version(void);
@@ -141,7 +146,9 @@ enum { SPNG_CFG_INFLATE_MODE = 0,   /* SPNG_INFLATE_AUTO: parallel pipeline, ser
        SPNG_CFG_DEFLATE_BYTES = 7,         /* levels >= 8: size limit of the context's scratch slab (per-stream vertex arrays, candidate
                                               pool, link rings) in bytes; 0 = half of the free device memory.  Streams that do not
                                               fit side by side go in groups */
-       SPNG_CFG_COUNT = 8 };
+       SPNG_CFG_MULTI_GROUPS = 8,          /* spng_decode_batch_multi: calls a context's shard is cut into when its rasters leave for another
+                                              device (a group's copies run beside the next group's decode); 0 = 2, at most 2 */
+       SPNG_CFG_COUNT = 9 };
 enum { SPNG_INFLATE_AUTO = 0, SPNG_INFLATE_SERIAL = 1 };
 enum { SPNG_DEFLATE_AUTO = 0, SPNG_DEFLATE_ONE_KERNEL = 1 };
 enum { SPNG_OVERLAP_AUTO = 0, SPNG_OVERLAP_ALWAYS = 1, SPNG_OVERLAP_NEVER = 2 };
@@ -153,6 +160,7 @@ enum { SPNG_K_INFLATE = 0,          /* the serial inflate kernel (streams the pa
        SPNG_K_DEFLATE = 4, SPNG_K_ADLER = 5,
        SPNG_K_PINFLATE = 6,         /* the parallel inflate pipeline as a whole: find + decode + scan + resolve */
        SPNG_K_UNPACK = 7,
+       SPNG_K_PACK = 10,            /* spng_pack_batch */
        SPNG_K_LEX = 12,             /* chunk lexing + CRC-32 / IDAT chunk emission */
        SPNG_K_PINF_FIND = 8, SPNG_K_PINF_DECODE = 9, SPNG_K_PINF_RESOLVE = 11,   /* its stages */
        SPNG_K_DFL_SEARCH = 13, SPNG_K_DFL_PARSE = 14,   /* levels >= 8: the two kernels of a round (inside SPNG_K_DEFLATE) */
@@ -251,7 +259,8 @@ int32_t spng_crc32(spng_ctx *ctx, const void *data, uint64_t n, uint32_t *out);
  * track of (Sources/PNG/Decoding/PNG.Decoder.swift:20-21, 88-94, 121-135) -- each row once, with the defiltered row above it
  * as an earlier call left it (in d_storage for 8 / 16-bit non-interlaced images; in d_work[i], a buffer of the size and layout
  * of d_rows, for interlaced and sub-byte ones: d_rows itself stays as inflated, it is the LZ77 window of the next push).
- * results: written = scanline bytes defiltered by this call, consumed = inflated bytes that are whole rows by now. */
+ * results: written = scanline bytes defiltered by this call, consumed = inflated bytes that are whole rows by now.
+ * descs[i].reserved & SPNG_IMAGE_OVERDRAW: push(data:overdraw: true) -- see SPNG_IMAGE_OVERDRAW. */
 int32_t spng_unfilter_resume_batch(spng_ctx *ctx, const spng_image_desc *descs, void *const *d_work,
                                    const uint64_t *h_prev_len, const uint64_t *h_now_len, uint32_t count,
                                    spng_result *d_results, spng_result *h_results);
@@ -272,14 +281,16 @@ typedef struct spng_unpack_desc {
     uint8_t     has_key;
     uint8_t     target;                         /* 8 or 16: T = UInt8 / UInt16                        */
     uint8_t     layout;                         /* SPNG_TARGET_RGBA: PNG.RGBA<T>, SPNG_TARGET_VA: PNG.VA<T> (v = the grey value or
-                                                   the red channel, a) -- d_out holds width * height (v, a) pairs then */
+                                                   the red channel, a) -- d_out holds width * height (v, a) pairs then;
+                                                   SPNG_TARGET_SCALAR: T, the scalar unpack of PNG.Image.swift:682-760, 1030-1040
+                                                   (grey value / red channel / palette[i].r; keys ignored, no premultiply) */
     uint8_t     premultiply;                    /* 0: straight;  SPNG_PREMULTIPLY: .premultiplied (PNG.RGBA.swift:121-127,
                                                    PNG.VA.swift:57-60);  SPNG_PREMULTIPLY_AS_U8 (target 16 only):
                                                    .premultiplied(as: UInt8.self) (PNG.RGBA.swift:146-158), the form the
                                                    reference's iOS goldens are compared in (Roundtripping.swift:206-215) */
     uint8_t     reserved[6];
 } spng_unpack_desc;
-enum { SPNG_TARGET_RGBA = 0, SPNG_TARGET_VA = 1 };
+enum { SPNG_TARGET_RGBA = 0, SPNG_TARGET_VA = 1, SPNG_TARGET_SCALAR = 2 };
 enum { SPNG_PREMULTIPLY = 1, SPNG_PREMULTIPLY_AS_U8 = 2 };
 /* replaces PNG.RGBA<T>.unpack(_:of:deindexer:) / PNG.VA<T>.unpack(_:of:deindexer:) with the default deindexers, T = UInt8 / UInt16
  * (Sources/PNG/ColorTargets/PNG.RGBA.swift:259-365, depth rescaling Sources/PNG/PNG.swift:255-312,
@@ -293,6 +304,34 @@ int32_t spng_unpack(spng_ctx *ctx, const void *storage, uint32_t w, uint32_t h, 
 int32_t spng_unpack_as(spng_ctx *ctx, const void *storage, uint32_t w, uint32_t h, int depth, int channels,
                        int indexed, int bgr, int target, int layout, int premultiply, const void *palette,
                        uint32_t palette_count, const uint16_t *key, void *out);
+
+/* ---- pixels: the step in front of the encode path ------------------------------------------------ */
+/* One image to pack: the inverse of spng_unpack_desc.  d_pixels: width * height RGBA<T> quadruplets (r, g, b, a), VA<T> pairs
+ * (v, a) or scalars T in host byte order, T = UInt8 / UInt16 (`source` bits); d_storage: PNG.Image.storage, S bytes. */
+typedef struct spng_pack_desc {
+    const void *d_pixels;
+    void       *d_storage;
+    const void *d_palette;                      /* indexed formats: palette_count x (r, g, b, a), as in spng_unpack_desc */
+    uint32_t    width, height;
+    uint32_t    palette_count;
+    uint8_t     depth, channels;                /* as in spng_image_desc                             */
+    uint8_t     indexed;                        /* PNG.Format.indexed1/2/4/8                         */
+    uint8_t     bgr;                            /* PNG.Format.bgr8 / bgra8 (CgBI)                    */
+    uint8_t     source;                         /* 8 or 16: T = UInt8 / UInt16                        */
+    uint8_t     layout;                         /* SPNG_TARGET_RGBA / _VA / _SCALAR                   */
+    uint8_t     reserved[6];
+} spng_pack_desc;
+/* replaces PNG.RGBA<T>.pack(_:as:indexer:) / PNG.VA<T>.pack(_:as:indexer:) / the scalar PNG.Image.pack<T> with the default
+ * indexers, T = UInt8 / UInt16 -- what PNG.Image.init(packing:size:layout:) stores (Sources/PNG/ColorTargets/PNG.RGBA.swift:409-478,
+ * PNG.VA.swift:334-403, PNG.Image.swift:767-834, 935-1010, 1043-1062; depth rescaling PNG.deconvolve, Sources/PNG/PNG.swift:699-1285;
+ * default indexers PNG.Color.swift:158-226).  Components of T are narrowed to the format's depth by a right shift or widened by
+ * the quantum, stored big-endian; colour formats without alpha drop it; chroma keys play no part.  Indexed formats: the palette
+ * entry equal to the pixel reduced to 8 bits, entry 0 when there is none (the reference traps on a palette that holds a colour
+ * twice; here the lowest index wins).  All descs of a call share `source`.  The storage can go straight to spng_encode_batch. */
+int32_t spng_pack_batch(spng_ctx *ctx, const spng_pack_desc *descs, uint32_t count);
+/* host-pointer convenience (copies in / out, synchronous) */
+int32_t spng_pack_as(spng_ctx *ctx, const void *pixels, uint32_t w, uint32_t h, int depth, int channels,
+                     int indexed, int bgr, int source, int layout, const void *palette, uint32_t palette_count, void *storage);
 
 /* ---- encode -------------------------------------------------------------------------------- */
 /* replaces PNG.Encoder.filter (PNG.Encoder.swift:132-204) + PNG.Image.collect
@@ -347,9 +386,12 @@ int32_t spng_shard(uint32_t count, uint32_t parts, uint32_t index, uint32_t *fir
 /* spng_decode_batch (PNG.Context.push end to end) over n_ctx contexts, one per device of the node: descs[i]'s device
  * pointers live on the device of the context its block belongs to (spng_shard); every context decodes its block without
  * talking to the others.  d_gather (NULL: leave the rasters where they are): per image, where on the FIRST context's device its
- * raster is wanted -- the one exchange step of the path; each goes as a peer-to-peer copy behind its context's decode (xGMI is
- * point to point: the seven peers' copies ride their own links at once).  Returns when everything has arrived; results in
- * h_results. */
+ * raster is wanted -- the one exchange step of the path; each goes as a peer-to-peer copy on the context's own copy stream behind
+ * the decode of its group (a shard goes in SPNG_CFG_MULTI_GROUPS groups, so a group's rasters travel while the next decodes;
+ * xGMI is point to point: the seven peers' copies ride their own links at once).  Peer access to the first context's device is
+ * switched on once per pair (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess); where the devices refuse, the copies are staged
+ * by the runtime and spng_last_error_string says so.  The caller's current device is left as it was.  Returns when everything
+ * has arrived; results in h_results. */
 int32_t spng_decode_batch_multi(spng_ctx *const *ctxs, uint32_t n_ctx, const spng_image_desc *descs, uint32_t count,
                                 void *const *d_gather, spng_result *h_results);
 

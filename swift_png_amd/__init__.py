@@ -34,7 +34,9 @@ E_OUTPUT_CAPACITY, E_ARGUMENT, E_DEVICE, E_REFERENCE_UNDEFINED = 64, 65, 66, 67
 FORMAT_ZLIB, FORMAT_IOS, FORMAT_GZIP = 0, 1, 2
 K_INFLATE, K_UNFILTER, K_SCATTER, K_FILTER, K_DEFLATE, K_ADLER, K_PINFLATE = 0, 1, 2, 3, 4, 5, 6
 K_UNPACK = 7
-TARGET_RGBA, TARGET_VA = 0, 1
+K_PACK = 10
+IMAGE_OVERDRAW = 1
+TARGET_RGBA, TARGET_VA, TARGET_SCALAR = 0, 1, 2
 PREMULTIPLY, PREMULTIPLY_AS_U8 = 1, 2
 K_LEX = 12
 K_PINF_FIND, K_PINF_DECODE, K_PINF_RESOLVE = 8, 9, 11
@@ -51,7 +53,7 @@ EXPORTS = [
     "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_inflate_resume_batch", "spng_unfilter_batch",
     "spng_unfilter_resume_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
-    "spng_lex_batch", "spng_write_idat_batch", "spng_crc32", "spng_unpack_batch", "spng_unpack", "spng_unpack_as", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
+    "spng_lex_batch", "spng_write_idat_batch", "spng_crc32", "spng_unpack_batch", "spng_unpack", "spng_unpack_as", "spng_pack_batch", "spng_pack_as", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
     "spng_shard", "spng_decode_batch_multi", "spng_copy_ceiling", "spng_trim", "spng_deflate_state_bytes", "spng_deflate_resume_batch",
 ]
 
@@ -92,6 +94,13 @@ class UnpackDesc(ctypes.Structure):
                 ("key", ctypes.c_uint16 * 3), ("depth", ctypes.c_uint8), ("channels", ctypes.c_uint8), ("indexed", ctypes.c_uint8),
                 ("bgr", ctypes.c_uint8), ("has_key", ctypes.c_uint8), ("target", ctypes.c_uint8), ("layout", ctypes.c_uint8),
                 ("premultiply", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 6)]
+
+
+class PackDesc(ctypes.Structure):
+    _fields_ = [("d_pixels", ctypes.c_void_p), ("d_storage", ctypes.c_void_p), ("d_palette", ctypes.c_void_p),
+                ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("palette_count", ctypes.c_uint32),
+                ("depth", ctypes.c_uint8), ("channels", ctypes.c_uint8), ("indexed", ctypes.c_uint8), ("bgr", ctypes.c_uint8),
+                ("source", ctypes.c_uint8), ("layout", ctypes.c_uint8), ("reserved", ctypes.c_uint8 * 6)]
 
 
 class ChunkingDesc(ctypes.Structure):
@@ -217,6 +226,9 @@ def load_library():
                                 vp, u32, vp, vp]
     lib.spng_unpack_as.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_int, vp, u32, vp, vp]
+    lib.spng_pack_batch.argtypes = [vp, vp, u32]
+    lib.spng_pack_as.argtypes = [vp, vp, u32, u32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_int, vp, u32, vp]
     lib.spng_deflate_bound.restype = u64
     lib.spng_deflate_bound.argtypes = [u64]
     lib.spng_deflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), ctypes.POINTER(i32), u32, vp, rp]
@@ -508,13 +520,27 @@ class Session:
         """PNG.Image.unpack(as: PNG.RGBA<UInt8 / UInt16>.self) (layout = TARGET_VA: PNG.VA<T>): -> bytes of r, g, b, a
         (v, a) per pixel (host order).  palette: bytes of (r, g, b, a) quadruplets (PLTE with the tRNS alphas folded in);
         key: tRNS chroma key; premultiply: 0, PREMULTIPLY (.premultiplied) or PREMULTIPLY_AS_U8 (.premultiplied(as: UInt8.self))."""
-        n = w * h * (2 if layout else 4) * (target // 8)
+        n = w * h * (4, 2, 1)[layout] * (target // 8)
         src = (ctypes.c_uint8 * max(len(storage), 1)).from_buffer_copy(bytes(storage) or b"\0")
         out = (ctypes.c_uint8 * max(n, 1))()
         pal = (ctypes.c_uint8 * max(len(palette or b""), 1)).from_buffer_copy(bytes(palette or b"\0"))
         k = (ctypes.c_uint16 * 3)(*(list(key) + [0, 0, 0])[:3]) if key is not None else None
         _check(self.lib, self.lib.spng_unpack_as(self.ctx, src, w, h, depth, channels, int(bool(indexed)), int(bool(bgr)), target,
                                                  int(layout), int(premultiply), pal if palette else None, len(palette or b"") // 4, k, out))
+        return bytes(out[:n])
+
+    def pack(self, pixels: bytes, w, h, depth, channels, indexed=False, bgr=False, source=16, palette=None, layout=0) -> bytes:
+        """PNG.Image(packing:size:layout:).storage for [PNG.RGBA<T>] (layout TARGET_RGBA), [PNG.VA<T>] (TARGET_VA) or [T]
+        (TARGET_SCALAR), T = UInt8 / UInt16 (`source` bits), with the default indexer: pixels = bytes of r, g, b, a | v, a | v per
+        pixel (host order) -> storage bytes.  palette: bytes of (r, g, b, a) quadruplets."""
+        px = (ctypes.c_uint8 * max(len(pixels), 1)).from_buffer_copy(bytes(pixels) or b"\0")
+        if len(pixels) != w * h * (4, 2, 1)[layout] * (source // 8):
+            raise ValueError("pixel array `count` must be equal to `size.x * size.y`")
+        n = self.lib.spng_storage_size(w, h, depth, channels)
+        out = (ctypes.c_uint8 * max(n, 1))()
+        pal = (ctypes.c_uint8 * max(len(palette or b""), 1)).from_buffer_copy(bytes(palette or b"\0"))
+        _check(self.lib, self.lib.spng_pack_as(self.ctx, px, w, h, depth, channels, int(bool(indexed)), int(bool(bgr)), source,
+                                               int(layout), pal if palette else None, len(palette or b"") // 4, out))
         return bytes(out[:n])
 
     def deflate(self, data: bytes, level: int, fmt=FORMAT_ZLIB, exponent: int = 15) -> bytes:

@@ -20,6 +20,25 @@ typedef uint8_t __attribute__((address_space(1))) gbyte;      // a byte in globa
 typedef uint8_t gbyte;
 #endif
 
+// A bound on the spin waits of the wave-to-wave protocols (unfilter bands, the search kernel's inserter and searchers): a
+// protocol bug must fault, not hang the GPU -- but a wave held up from outside (a profiler serialising the kernel, a debugger)
+// is not a bug, so the bound is wall time (s_memrealtime, 100 MHz), looked at every 4096 spins: 20 s.
+struct SpinGuard {
+    uint32_t spins = 0;
+    uint64_t t0 = 0;
+    __device__ __forceinline__ void tick()
+    {
+        if ((++spins & 0xfffu) != 0) return;
+#ifndef SPNG_EMU
+        const uint64_t now = __builtin_amdgcn_s_memrealtime();
+        if (!t0) t0 = now;
+        else if (now - t0 > 2000000000ull) __builtin_trap();
+#else
+        if (spins > (1u << 28)) __builtin_trap();
+#endif
+    }
+};
+
 // One unfilter job = one dependency chain of scanlines: a whole non-interlaced image or one
 // Adam7 sub-image (PNG.Decoder.swift:59-140).  Rows are `in_stride` apart starting at `in`
 // (which points at the first row's filter byte); defiltered bytes of row y go to
@@ -54,6 +73,16 @@ struct ScatterJob {
     uint32_t       depth, channels;
 };
 
+// One image whose unfinished Adam7 cells are filled in for progressive display (PNG.Image.overdraw, PNG.Image.swift:134-183, as
+// PNG.Context.push(data:overdraw: true) calls it after every scanline, PNG.Context.swift:88-102).
+struct OverdrawJob {
+    uint8_t *storage;
+    uint32_t width, height;
+    uint32_t elem;                // storage bytes per pixel (1, 2, 3, 4, 6, 8)
+    uint32_t y0, y1;              // storage rows this call may have changed
+    uint32_t done[7];             // scanlines of each Adam7 pass assigned so far
+};
+
 // One filter job (encode): storage -> filtered rows of one (sub-)image
 // (PNG.Encoder.pull + PNG.Image.collect + PNG.Encoder.filter).
 struct FilterJob {
@@ -77,6 +106,17 @@ struct UnpackJob {
     uint16_t       key[3];        // tRNS chroma key, at the source depth
     uint8_t        depth, channels, indexed, bgr, has_key, pad;
     uint8_t        layout, premultiply;      // spng_unpack_desc.layout / .premultiply
+};
+
+// One image to pack: RGBA<T> / VA<T> / T pixels -> PNG.Image.storage (unpack.hip, pack_kernel)
+struct PackJob {
+    const void    *pixels;
+    uint8_t       *storage;
+    const uint8_t *palette;       // indexed formats: palette_count x (r, g, b, a)
+    uint32_t       width, height;
+    uint32_t       palette_count;
+    uint8_t        depth, channels, indexed, bgr;
+    uint8_t        layout, pad[3];           // spng_pack_desc.layout
 };
 
 struct InflateJob {
@@ -212,6 +252,7 @@ hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, s
 hipError_t launch_copy_probe(const void *d_src, void *d_dst, uint64_t bytes, int pattern, hipStream_t stream);
 hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32_t *d_job_image,
                           const spng_result *d_results, uint32_t blocks_x, hipStream_t stream);
+hipError_t launch_overdraw(const OverdrawJob *d_jobs, uint32_t count, uint32_t blocks_x, hipStream_t stream);
 hipError_t launch_inflate(const InflateJob *d_jobs, uint32_t count, spng_result *d_results,
                           hipStream_t stream);
 // pinflate2.hip: the parallel inflate pipeline
@@ -251,6 +292,7 @@ hipError_t launch_deflate2_failed(const D2Stream *d_streams, uint32_t count, uin
 uint64_t deflate_graph_vertices(uint64_t n);
 uint64_t deflate_graph_bytes(uint64_t vertices);
 hipError_t launch_unpack(const UnpackJob *d_jobs, uint32_t count, uint32_t blocks_x, int target, hipStream_t stream);
+hipError_t launch_pack(const PackJob *d_jobs, uint32_t count, uint32_t blocks_x, int source, hipStream_t stream);
 size_t lex_chunk_bytes();
 size_t lex_walk_bytes();
 hipError_t launch_lex(const spng_file_desc *d_files, uint32_t count, spng_lexed *d_out, void *d_table, const uint64_t *d_table_at,

@@ -1456,7 +1456,8 @@ __host__ __device__ inline uint64_t d2_round_end(uint64_t pos, uint32_t limit, u
         if (more && size < (uint64_t)(lim - 1)) break;
         if (end > pos && end - pos + size > D2_RV) break;
         end += size;
-        if (!more && end == n) break;
+        if (!more && end >= n) break;                           // (>=, and no room at all: a position behind the input -- a state
+        if (!room) break;                                       //  that does not belong to this input -- must not spin here)
         lim = 2 * lim < (1u << 21) ? 2 * lim : 1u << 21;
     }
     return end;
@@ -1553,10 +1554,10 @@ __global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D
         uint32_t key_next = load_key(in, n, inserted + lane);
         uint32_t since = 0;
         while (inserted < c1) {
-            uint32_t spins = 0;
+            SpinGuard guard;
             while (inserted >= c0 + 64ull * __hip_atomic_load(&s.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 16384) {
                 __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 28)) __builtin_trap();
+                guard.tick();
             }
             const uint32_t key = key_next;
             key_next = load_key(in, n, inserted + 64 + lane);
@@ -1583,10 +1584,10 @@ __global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D
         if (b >= nbatches) break;
         const uint64_t p0 = c0 + 64ull * b, upto = p0 + 64 < c1 ? p0 + 64 : c1;
         {
-            uint32_t spins = 0;
+            SpinGuard guard;
             while (__hip_atomic_load(&s.inserted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < upto) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 28)) __builtin_trap();
+                guard.tick();
             }
         }
         const uint64_t p = p0 + lane;

@@ -1658,7 +1658,8 @@ __global__ void pinf2_account_kernel(uint32_t *ctr, uint32_t *totals, uint32_t p
     const uint32_t used = ctr[0];
     atomicAdd(&totals[0], used < pages ? used : pages);
     if (used >= pages) atomicOr(&totals[1], 1u);
-    totals[2] += ctr[1]; ctr[1] = 0;                            // blocks decoded (ctr[1]: the pass's, counted by the decode waves)
+    atomicAdd(&totals[2], ctr[1]); ctr[1] = 0;                  // blocks decoded (ctr[1]: the pass's, counted by the decode waves;
+                                                                // atomic: in overlap mode two groups' accounts run side by side)
 }
 
 // ---- host ------------------------------------------------------------------------------------------------

@@ -266,10 +266,10 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         return __hip_atomic_load(&done[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
     };
     auto wait_ready = [&](uint32_t band, uint32_t T) {
-        uint32_t spins = 0;
+        SpinGuard guard;
         while (!ready(band, T)) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 26)) __builtin_trap();  // a protocol bug must fault, not hang the GPU
+            guard.tick();
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
@@ -531,10 +531,10 @@ __global__ __launch_bounds__(SPNG_UNF_PK_NW * 64) void unfilter_pk_kernel(const 
         return __hip_atomic_load(&done[pw], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need;
     };
     auto wait_ready = [&](uint32_t band, uint32_t T) {
-        uint32_t spins = 0;
+        SpinGuard guard;
         while (!ready(band, T)) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 26)) __builtin_trap();  // a protocol bug must fault, not hang the GPU
+            guard.tick();
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
@@ -741,6 +741,54 @@ __global__ __launch_bounds__(256) void scatter_kernel(const ScatterJob *__restri
             else for (uint32_t k = 0; k < bpp; ++k) to[k] = from[k];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PNG.Image.overdraw (Sources/PNG/PNG.Image.swift:134-183) as PNG.Context.push(data:overdraw: true) applies it
+// (PNG.Context.swift:88-102): after the scanline of pass z at `base` is assigned, with stride (sx, sy),
+//     s = (base.x == 0 ? 0 : 1, base.y & 7 == 0 ? 0 : 1),  brush = (sx >> s.x, sy >> s.y),
+// every pixel of rows [base.y, base.y + brush.y) and columns [x, x + brush.x), x = base.x, base.x + brush.x, ... takes the value
+// storage holds at (x, base.y) -- brushes of one pixel do nothing.  (So pass 3 paints 2 x 4 cells from rows 0 mod 8 and
+// 2 x 2 cells from rows 4 mod 8, and pass 5 1 x 2 cells from rows 0 mod 8 only: the reference's `base.y & 0b111` test is taken
+// as it stands.)  The reference does this scanline by scanline; what storage holds after any prefix of the scanlines has a
+// closed form, which is what lets every pixel be done on its own: the cells of a pass never reach an assigned pixel other
+// than their own source (the rows and columns strictly inside a cell belong to later passes), every source (x, base.y) is an
+// assigned pixel of a pass <= z, scanlines of one pass paint disjoint rows, and passes come in order -- so an unassigned
+// pixel shows the source of the LAST pass that has an assigned scanline whose cell covers it, and an assigned pixel itself.
+// One thread per pixel of the rows the call may have changed: reads assigned pixels only, writes unassigned ones only.
+__global__ __launch_bounds__(256) void overdraw_kernel(const OverdrawJob *__restrict__ jobs)
+{
+    const OverdrawJob job = jobs[blockIdx.y];
+    const uint32_t BX[7] = {0, 4, 0, 2, 0, 1, 0}, BY[7] = {0, 0, 4, 0, 2, 0, 1};
+    const uint32_t EX[7] = {3, 3, 2, 2, 1, 1, 0}, EY[7] = {3, 3, 3, 2, 2, 1, 1};
+    const uint64_t total = (uint64_t)(job.y1 - job.y0) * job.width;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t Y = job.y0 + (uint32_t)(idx / job.width), X = (uint32_t)(idx % job.width);
+        // the pixel's own pass and scanline (PNG.adam7, PNG.Decoder.swift:6-15)
+        const uint32_t own = (Y & 1) ? 6 : (X & 1) ? 5 : (Y & 2) ? 4 : (X & 2) ? 3 : (Y & 4) ? 2 : (X & 4) ? 1 : 0;
+        if (((Y - BY[own]) >> EY[own]) < job.done[own]) continue;          // assigned: final
+        for (int q = 6; q >= 0; --q) {
+            if (!job.done[q] || X < BX[q] || Y < BY[q]) continue;
+            const uint32_t yq = (Y - BY[q]) >> EY[q];
+            if (yq >= job.done[q]) continue;                               // that scanline has not come yet
+            const uint32_t B = BY[q] + (yq << EY[q]);
+            const uint32_t bx = (1u << EX[q]) >> (BX[q] ? 1 : 0), by = (1u << EY[q]) >> ((B & 7) ? 1 : 0);
+            if (bx * by <= 1 || Y >= B + by) continue;
+            const uint32_t x = BX[q] + (X - BX[q]) / bx * bx;
+            const uint8_t *from = job.storage + ((uint64_t)B * job.width + x) * job.elem;
+            uint8_t *to = job.storage + ((uint64_t)Y * job.width + X) * job.elem;
+            for (uint32_t k = 0; k < job.elem; ++k) to[k] = from[k];
+            break;
+        }
+    }
+}
+
+hipError_t launch_overdraw(const OverdrawJob *d_jobs, uint32_t count, uint32_t blocks_x, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u)
+        overdraw_kernel<<<dim3(blocks_x ? blocks_x : 1, count - y0 < 65535u ? count - y0 : 65535u), 256, 0, stream>>>(d_jobs + y0);
+    return hipGetLastError();
 }
 
 hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32_t *d_job_image,

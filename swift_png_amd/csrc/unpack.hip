@@ -107,14 +107,139 @@ __global__ __launch_bounds__(256) void unpack_kernel(const UnpackJob *__restrict
                     else { uint2 w; w.x = v[0]; w.y = v[1]; ((uint2 *)out)[i0 + k] = w; }
                 }
             }
-        } else {
+        } else if (job.layout == 1) {
             // PNG.VA<T>: (v, a)
             for (uint32_t k = 0; k < m; ++k) {
                 if (TB == 8) ((uint16_t *)out)[i0 + k] = (uint16_t)(px[k][0] | px[k][3] << 8);
                 else ((uint32_t *)out)[i0 + k] = px[k][0] | px[k][3] << 16;
             }
+        } else {
+            // scalar T (PNG.Image.unpack<T>(as:), PNG.Image.swift:682-760): the grey value / the red channel / palette[i].r
+            if (TB == 8) {
+                if (m == 4) ((uint32_t *)out)[q] = px[0][0] | px[1][0] << 8 | px[2][0] << 16 | px[3][0] << 24;
+                else for (uint32_t k = 0; k < m; ++k) ((uint8_t *)out)[i0 + k] = (uint8_t)px[k][0];
+            } else {
+                if (m == 4) { uint2 w; w.x = px[0][0] | px[1][0] << 16; w.y = px[2][0] | px[3][0] << 16; ((uint2 *)out)[q] = w; }
+                else for (uint32_t k = 0; k < m; ++k) ((uint16_t *)out)[i0 + k] = (uint16_t)px[k][0];
+            }
         }
     }
+}
+
+// ---- pack: colour-target pixels -> PNG.Image.storage, the step in front of the encode path ------------------------------
+// Replaces PNG.RGBA<T>.pack(_:as:indexer:) (PNG.RGBA.swift:409-478), PNG.VA<T>.pack (PNG.VA.swift:334-403) and the scalar
+// PNG.Image.pack<T> (PNG.Image.swift:767-834) for T = UInt8 / UInt16 with the default indexers (PNG.Color.swift:158-226,
+// PNG.Image.swift:1043-1062): what PNG.Image.init(packing:size:layout:) stores.
+//   depth rescaling     Sources/PNG/PNG.swift:1064-1285 (deconvolve): T.bitWidth == depth: as is; < depth: times
+//                       quantum(source: T.bitWidth, destination: depth) (:255-261); > depth: shifted right by the difference;
+//                       samples stored big-endian (:699-745), sub-byte depths one unscaled byte per sample
+//   component choice    v formats take r (v), va (r | v, a | T.max), rgb (r, g, b | v, v, v), bgr / bgra swizzled; a colour
+//                       format without alpha drops it, chroma keys play no part (they are metadata of the format)
+//   indexed formats     components reduced to UInt8 (T == UInt16: >> 8, PNG.swift:819-878), then the default indexer: the entry
+//                       equal to (r, g, b, a) | (v, v, v, a) | (v, v, v, 255), entry 0 when there is none.  The reference builds a
+//                       Dictionary(uniqueKeysWithValues:) and traps on a palette that holds a colour twice; here the lowest index
+//                       of a repeated colour wins (the mirror refuses such palettes like the reference).
+// HBM-bound: reads the pixels, writes S.  Four pixels per thread; RGBA<UInt8> -> rgba8 moves 16 bytes per lane each way.
+static constexpr uint32_t PACK_SLOTS = 1024;                    // open addressing, <= 256 entries: load factor <= 1/4
+__device__ __forceinline__ uint32_t pack_hash(uint32_t c) { return (c * 0x9E3779B1u) >> 22; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(const PackJob *__restrict__ jobs)
+{
+    const PackJob job = jobs[blockIdx.y];
+    const uint64_t n = (uint64_t)job.width * job.height;
+    constexpr uint32_t TB = sizeof(T) * 8;
+    const uint32_t depth = job.depth;
+    const uint32_t bps = depth == 16 ? 2 : 1;                  // storage bytes per sample
+    const uint32_t ch = job.channels;
+    // transform(T) -> A: quantum(source: TB, destination: depth) = (2^depth - 1) / (2^TB - 1) when TB < depth (8 -> 16: 257)
+    const uint32_t mul = TB < depth ? 257u : 1u;
+    const uint32_t shr = TB > depth ? TB - depth : 0u;
+    constexpr uint32_t TMAX = TB == 8 ? 0xffu : 0xffffu;
+    __shared__ unsigned long long table[PACK_SLOTS];            // indexed formats: colour << 32 | index, ~0 = empty
+    if (job.indexed) {
+        for (uint32_t i = threadIdx.x; i < PACK_SLOTS; i += blockDim.x) table[i] = ~0ull;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < job.palette_count && i < 256; i += blockDim.x) {
+            const uint8_t *p = job.palette + 4 * i;
+            const uint32_t c = p[0] | p[1] << 8 | p[2] << 16 | (uint32_t)p[3] << 24;
+            const unsigned long long mine = (unsigned long long)c << 32 | i;
+            for (uint32_t h = pack_hash(c);; h = (h + 1) & (PACK_SLOTS - 1)) {
+                const unsigned long long old = atomicCAS(&table[h], ~0ull, mine);
+                if (old == ~0ull) break;
+                if ((uint32_t)(old >> 32) == c) { atomicMin(&table[h], mine); break; }     // a repeated colour: lowest index
+            }
+        }
+        __syncthreads();
+    }
+    const bool fast = TB == 8 && depth == 8 && ch == 4 && !job.indexed && job.layout == 0 &&
+                      (((uintptr_t)job.storage | (uintptr_t)job.pixels) & 3) == 0;
+    const bool words = ((uintptr_t)job.storage & 3) == 0;
+    const T *in = (const T *)job.pixels;
+    const uint64_t quads = (n + 3) / 4;
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i0 = q * 4;
+        const uint32_t m = n - i0 < 4 ? (uint32_t)(n - i0) : 4u;
+        if (fast && m == 4) {
+            v4u v = ((const PV4 *)((const uint32_t *)in + i0))->v;
+            if (job.bgr) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (v[k] & 0xff00ff00u) | (v[k] >> 16 & 0xff) | (v[k] & 0xff) << 16;
+            }
+            ((PV4 *)(job.storage + i0 * 4))->v = v;
+            continue;
+        }
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // the storage bytes of up to four pixels (<= 32), in memory order
+        uint32_t at = 0;
+        for (uint32_t k = 0; k < m; ++k) {
+            const uint64_t i = i0 + k;
+            uint32_t r, g, b, a = TMAX;
+            if (job.layout == 0) { const T *p = in + i * 4; r = p[0]; g = p[1]; b = p[2]; a = p[3]; }
+            else if (job.layout == 1) { const T *p = in + i * 2; r = g = b = p[0]; a = p[1]; }
+            else { r = g = b = in[i]; }
+            if (job.indexed) {
+                const uint32_t s8 = TB - 8;
+                const uint32_t c = (r >> s8) | (g >> s8) << 8 | (b >> s8) << 16 | (a >> s8) << 24;
+                uint32_t idx = 0;
+                for (uint32_t h = pack_hash(c);; h = (h + 1) & (PACK_SLOTS - 1)) {
+                    const unsigned long long e = table[h];
+                    if (e == ~0ull) break;
+                    if ((uint32_t)(e >> 32) == c) { idx = (uint32_t)e; break; }
+                }
+                w[at >> 2] |= idx << 8 * (at & 3); ++at;
+                continue;
+            }
+            uint32_t c[4];
+            if (ch <= 2) { c[0] = r; c[1] = a; }
+            else { c[0] = job.bgr ? b : r; c[1] = g; c[2] = job.bgr ? r : b; c[3] = a; }
+            for (uint32_t z = 0; z < ch; ++z) {
+                const uint32_t v = (c[z] * mul) >> shr;
+                if (bps == 2) { w[at >> 2] |= (v >> 8) << 8 * (at & 3); ++at; w[at >> 2] |= (v & 0xff) << 8 * (at & 3); ++at; }
+                else { w[at >> 2] |= v << 8 * (at & 3); ++at; }
+            }
+        }
+        const uint32_t per = job.indexed ? 1 : ch * bps;        // storage bytes per pixel
+        uint8_t *dst = job.storage + i0 * per;
+        if (m == 4 && words) {
+            const uint32_t nw = per;                            // 4 pixels x per bytes = per dwords
+            if (nw == 4) { v4u v = {w[0], w[1], w[2], w[3]}; ((PV4 *)dst)->v = v; }
+            else if (nw == 8) { v4u v = {w[0], w[1], w[2], w[3]}, u = {w[4], w[5], w[6], w[7]}; ((PV4 *)dst)->v = v; ((PV4 *)dst + 1)->v = u; }
+            else for (uint32_t z = 0; z < nw; ++z) ((uint32_t *)dst)[z] = w[z];
+        } else {
+            for (uint32_t z = 0; z < m * per; ++z) dst[z] = (uint8_t)(w[z >> 2] >> 8 * (z & 3));
+        }
+    }
+}
+
+hipError_t launch_pack(const PackJob *d_jobs, uint32_t count, uint32_t blocks_x, int source, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u) {           // (grid y stops at 65535)
+        const dim3 grid(blocks_x ? blocks_x : 1, count - y0 < 65535u ? count - y0 : 65535u);
+        if (source == 8) pack_kernel<uint8_t><<<grid, 256, 0, stream>>>(d_jobs + y0);
+        else pack_kernel<uint16_t><<<grid, 256, 0, stream>>>(d_jobs + y0);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_unpack(const UnpackJob *d_jobs, uint32_t count, uint32_t blocks_x, int target, hipStream_t stream)

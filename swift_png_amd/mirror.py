@@ -9,7 +9,7 @@ inflated bytes so far, and the point (a block boundary) from which the next push
 from __future__ import annotations
 
 from . import (DONE, FORMAT_GZIP, FORMAT_IOS, FORMAT_ZLIB, NEED_MORE_INPUT, DecodingError, SpngError,
-               E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM, E_OUTPUT_CAPACITY)
+               E_EXTRANEOUS_COMPRESSED_DATA, E_INCOMPLETE_DATASTREAM, E_OUTPUT_CAPACITY, IMAGE_OVERDRAW)
 
 _DELAY_FORMATS = {1: (8, 1), 2: (8, 2), 3: (8, 3), 4: (8, 4), 6: (16, 3), 8: (16, 4)}
 
@@ -302,8 +302,10 @@ class PNG:
                 self._stale = False
             return self._storage
 
-        def push(self, data: bytes):
-            """push(data:) (:88-102): one call per IDAT chunk.  The inflate goes on where the previous chunk stopped
+        def push(self, data: bytes, overdraw: bool = False):
+            """push(data:overdraw:) (:88-102): one call per IDAT chunk.  overdraw: the assigned pixels of an unfinished interlaced
+            image are replicated over the cells the later passes refine (PNG.Image.overdraw, PNG.Image.swift:134-183), on the
+            device (SPNG_IMAGE_OVERDRAW).  The inflate goes on where the previous chunk stopped
             (spng_inflate_resume_batch); the scanlines that became complete with this chunk -- and only those -- are defiltered
             and assigned (spng_unfilter_resume_batch, PNG.Decoder.swift:88-94, 121-135)."""
             from . import raise_for, E_EXTRANEOUS_IMAGE_DATA
@@ -331,6 +333,7 @@ class PNG:
             if now > self._defiltered:
                 desc = s.image_desc(None, self._d_rows, self._d_storage, w, h, self.depth, self.channels, self.interlaced,
                                     self.standard, rows_cap=self._d_rows.numel())
+                desc.reserved = IMAGE_OVERDRAW if overdraw else 0
                 ures = s.unfilter_resume(desc, self._d_work, self._defiltered, now)
                 raise_for(ures.status, (ures.aux[0], ures.aux[1]))
                 self.defiltered_total += ures.written

@@ -182,6 +182,55 @@ def test_context_push_is_incremental_on_the_image_side(gpu, name):
     assert ctx.defiltered_total == U, (ctx.defiltered_total, U)
 
 
+@pytest.mark.parametrize("name", ["common/basi3p04.png", "common/basi6a16.png", "common/basi2c08.png", "common/basi0g01.png",
+                                  "common/s05i3p02.png", "common/s09i3p02.png", "common/s33i3p04.png"])
+def test_context_push_with_overdraw_equals_the_reference_procedure(gpu, name):
+    """PNG.Context.push(data:overdraw: true) (PNG.Context.swift:88-102; PNG.Image.overdraw, PNG.Image.swift:134-183) on the
+    device: an interlaced image pushed a few bytes at a time -- after EVERY push the raster equals what the reference's
+    scanline-by-scanline procedure leaves (oracle/pixels.py `overdrawn`, with the reference's `base.y & 7` brush rule), for every
+    element size 1, 2, 3, 8 and for images smaller than a cell; at the end it is the image."""
+    import sys
+    import pnghelp as ph
+    sys.path.insert(0, str(ph.ROOT / "oracle"))
+    import pixels as orc_pixels
+    png = ph.parse_png((ph.GOLDEN / "pngsuite" / name).read_bytes())
+    assert png.interlaced
+    st, final, _ = ph.orc_decode(png)
+    assert st == 0
+    w, h = png.width, png.height
+    elem = len(final) // (w * h)
+    final = final.reshape(h, w, elem)
+    # scanlines complete after `n` inflated bytes, in the order of PNG.Decoder.push
+    ends = []
+    off = 0
+    volume = png.depth * png.channels
+    for (bx, by), (ex, ey) in orc_pixels.ADAM7:
+        sw, sh = (w + (1 << ex) - bx - 1) >> ex, (h + (1 << ey) - by - 1) >> ey
+        if sw <= 0 or sh <= 0:
+            continue
+        pitch = (sw * volume + 7) >> 3
+        for _ in range(sh):
+            off += pitch + 1
+            ends.append(off)
+    ctx = gpu.PNG.Context((w, h), png.depth, png.channels, True, png.fmt)
+    step = max(1, len(png.idat) // 40)
+    seen = set()
+    for i in range(0, len(png.idat), step):
+        ctx.push(png.idat[i:i + step], overdraw=True)
+        k = sum(1 for e in ends if e <= ctx._defiltered)
+        seen.add(k)
+        got = np.frombuffer(ctx.storage, dtype=np.uint8).reshape(h, w, elem)
+        assert (got == orc_pixels.overdrawn(final, k)).all(), (name, i, k)
+    assert len(seen) > 3 or len(ends) < 8
+    ctx.push_ancillary_iend()
+    assert ctx.storage == final.tobytes()
+    # the flag off: untouched pixels stay as they were (zero)
+    plain = gpu.PNG.Context((w, h), png.depth, png.channels, True, png.fmt)
+    plain.push(png.idat[:len(png.idat) // 2])
+    st, want, _ = ph.orc_decode(png, png.idat[:len(png.idat) // 2])
+    assert plain.storage == want.tobytes()
+
+
 def test_gzip_member_arrives_in_pieces(gpu):
     """Gzip.Inflator.push by pieces (LZ77.InflatorBuffers.swift:139-230): the member's DEFLATE payload goes on from the block
     boundary the previous push stopped at; after every push the available bytes are a prefix of the plain data, and the CRC-32
