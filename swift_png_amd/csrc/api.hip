@@ -1668,10 +1668,10 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
         Lay l;
         l.scratch = 0;
         for (size_t i = gr.first; i < gr.second; ++i) l.scratch += scratch_of(sorted[i].src_len);
-        uint32_t cps = (1536 + cnt - 1) / cnt;                // (two rounds of resident workgroups: three per CU)
-        cps = cps < 1 ? 1 : cps > 64 ? 64 : cps;
+        uint32_t cps = (256 + cnt - 1) / cnt;                 // (a search workgroup is a CU: one round of them where the streams are few,
+        cps = cps < 2 ? 2 : cps > 64 ? 64 : cps;              //  chunks of 2^20 positions -- 3 % of warm-up -- where they are many)
         l.cps = cps; l.chunk = (((1u << 21) / cps + 63) / 64) * 64;
-        l.rings = (uint64_t)cnt * cps * 65536 * 4;
+        l.rings = deflate2_temp_bytes(cnt * cps);             // (the searchers' word scratch; round 4: a 256 KiB link ring per workgroup)
         uint64_t room = budget > l.scratch + l.rings ? budget - l.scratch - l.rings : 0;
         l.pool = worst_pool < room / 2 ? worst_pool : room / 2;       // (one pool per round parity)
         if (l.pool < min_pool) l.pool = min_pool;

@@ -286,7 +286,8 @@ uint32_t deflate2_plan(uint64_t n, bool more, uint64_t &pos, uint32_t &lim);
 hipError_t launch_deflate2_begin(const D2Stream *d_streams, uint32_t count, hipStream_t stream);
 uint64_t deflate2_vertices(uint64_t n);
 hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t *d_pool, unsigned long long *d_pool_next,
-                                  uint64_t pool_words, uint32_t *d_rings, uint32_t parity, hipStream_t stream);
+                                  uint64_t pool_words, uint32_t *d_temp, uint32_t parity, hipStream_t stream);
+uint64_t deflate2_temp_bytes(uint32_t workgroups);
 hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, uint32_t parity, hipStream_t stream);
 hipError_t launch_deflate2_failed(const D2Stream *d_streams, uint32_t count, uint32_t *d_failed, hipStream_t stream);
 uint64_t deflate_graph_vertices(uint64_t n);

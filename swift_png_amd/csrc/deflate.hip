@@ -1626,6 +1626,303 @@ __global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D
     }
 }
 
+// =====================================================================================================================
+// round 5: the search with its window in LDS (every level)
+// =====================================================================================================================
+// dfl2_search_kernel above hops through HBM: a link is a 4-byte word in a 256 KiB ring per workgroup, a hop two dependent loads
+// of a microsecond each, and with 13-bit bucket heads over a 32 K window a position of incompressible input walks ~4 foreign
+// bucket members to find nothing (10 GB/s with the whole chip on it).  Here a workgroup is a whole CU -- sixteen waves, 141 KB
+// of LDS -- and everything a hop touches lives in LDS:
+//   * `in`:   the input bytes of the last D3_R = 36864 positions (the 32 K window + 4 K of lead), a ring with its first 320
+//             bytes mirrored behind its end so that a compare never wraps;
+//   * `link`: per position the distance to the previous position of its bucket (16 bits, 0 = none): no tags -- a candidate is
+//             verified against the input itself, four bytes at its ring slot;
+//   * `head`: 2^14 bucket heads (16 bits, positions mod 2^16; a head nobody touched for 2^16 positions aliases a young one and
+//             sends a walk into another bucket's chain -- positions only ever decrease along a walk and every candidate is
+//             verified, so that costs hops, never a candidate: the note at d3_insert).
+// Wave 0 stages the bytes (global -> LDS, three 256-byte steps in flight) and inserts, 64 positions at a time: when the 64
+// buckets are all different -- what a read-back of the heads tells -- a batch costs three LDS round trips; the radix match over
+// the hash bits is the slow path.  The other fifteen waves (and wave 0 once it is done) claim batches of 64 positions behind
+// it and walk the chains (LZ77.DeflatorWindow.match, :132-212: attempts / goal / window of the level).  Distances only grow
+// along a chain, so the candidates of one distance decade are neighbours: the "longest run per decade, closest first"
+// (DeflatorMatches.set(edge:), :183-194) is a running maximum in registers and a word whenever the decade changes -- no table
+// of thirty slots per lane (round 4: 7.7 KB of LDS per wave, the reason for three workgroups per CU).  Words go to a small
+// per-wave area in global memory and from there, when the batch's total is known, to the pool in the same lane-major order as
+// before.  Levels 0-7 (FULL = false) leave one word per position instead: the first strictly longest run > 5 and its distance
+// (DeflatorWindow.match :145-208 as Stream.compress greedy / lazy asks it), for dfl3_parse_kernel.
+static constexpr uint32_t D3_R = 36864, D3_MIR = 320;           // ring positions (a multiple of 256), mirrored bytes
+#ifndef SPNG_D3_WAVES
+#define SPNG_D3_WAVES 16
+#endif
+#ifndef SPNG_D3_HBITS
+#define SPNG_D3_HBITS 14
+#endif
+struct D3Lds {
+    union { uint8_t in[D3_R + D3_MIR]; uint32_t in32[(D3_R + D3_MIR) / 4]; };
+    uint16_t link[D3_R];
+    uint16_t head[(1u << SPNG_D3_HBITS) + 64];                  // (+ a spare slot for idle lanes)
+    uint32_t cur[SPNG_D3_WAVES];                                // the batch each wave is at (~0: none any more)
+    uint32_t staged, inserted, next, pad;                       // positions (relative to the warm-up's first) below which bytes / links stand; batches claimed
+};
+__shared__ __attribute__((aligned(16))) D3Lds g_d3;
+
+// four / eight input bytes at ring offset `off` (any alignment; the mirror makes them contiguous)
+__device__ __forceinline__ uint32_t d3_u32(const D3Lds &s, uint32_t off)
+{
+    const uint32_t w = off >> 2;
+    return __builtin_amdgcn_alignbyte(s.in32[w + 1], s.in32[w], off & 3);
+}
+__device__ __forceinline__ uint64_t d3_u64(const D3Lds &s, uint32_t off)
+{
+    const uint32_t w = off >> 2, a = s.in32[w], b = s.in32[w + 1], c = s.in32[w + 2];
+    return (uint64_t)__builtin_amdgcn_alignbyte(c, b, off & 3) << 32 | __builtin_amdgcn_alignbyte(b, a, off & 3);
+}
+__device__ __forceinline__ uint32_t d3_common_prefix(const D3Lds &s, uint32_t q, uint32_t p, uint32_t limit)
+{
+    uint32_t i = 0;
+    while (i + 8 <= limit) {
+        const uint64_t x = d3_u64(s, q + i) ^ d3_u64(s, p + i);
+        if (x) return i + ((uint32_t)__builtin_ctzll(x) >> 3);
+        i += 8;
+    }
+    if (i + 4 <= limit) {
+        const uint32_t x = d3_u32(s, q + i) ^ d3_u32(s, p + i);
+        if (x) return i + ((uint32_t)__builtin_ctz(x) >> 3);
+        i += 4;
+    }
+    while (i < limit && s.in[q + i] == s.in[p + i]) ++i;
+    return i;
+}
+
+// Hash insertion of 64 positions (LZ77.DeflatorWindow.update, :78-128) with heads and links in LDS.  rel: the batch's first
+// position relative to the warm-up's first, idx: its ring slot.  A position's link is the distance to the previous position of
+// its bucket, 0 when that is 32768 or more away.  Heads are positions mod 2^16: a head older than 2^16 positions reads as a
+// young one and its link leads into another bucket's chain.  Harmless: along a walk positions only decrease, every candidate is
+// compared with the key itself, and had the bucket a member inside the window the head would be that member -- a stray link
+// can only stand where the true chain has ended.
+__device__ __forceinline__ void d3_insert(D3Lds &s, uint32_t rel, uint32_t idx, uint64_t p0, uint32_t p0m, uint64_t n, bool sum, uint32_t &accS, uint32_t &accI, int lane)
+{
+    const uint64_t p = p0 + lane;
+    const bool live = p + 4 <= n;                              // the last three positions never start a match
+    const uint32_t key = d3_u32(s, idx + lane);
+    if (p < n && sum) {                                        // Adler-32 accumulators (p0m: p0 mod 65521 + a multiple of it, < 2^24)
+        const uint32_t byte = key & 0xff;
+        accS += byte;
+        accI = (accI + (p0m + (uint32_t)lane) % 65521 * byte) % 65521;
+    }
+    const uint32_t h = (key * 0x9E3779B1u) >> (32 - SPNG_D3_HBITS);
+    const uint32_t mine = (rel + (uint32_t)lane) & 0xffffu, spare = (1u << SPNG_D3_HBITS) + (uint32_t)lane;
+    const uint32_t slot = live ? h : spare;
+    const uint32_t old = s.head[slot];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    s.head[slot] = (uint16_t)mine;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    const uint32_t back = s.head[slot];
+    uint32_t d = (mine - old) & 0xffffu;
+    if (__ballot(back != mine)) {
+        // two positions of one bucket in the batch: the nearest lower lane of the same bucket is the previous position, the
+        // highest lane of a bucket its new head (radix match over the hash bits: one ballot per bit)
+        unsigned long long same = __ballot(live);
+#pragma unroll
+        for (int k = 0; k < SPNG_D3_HBITS; ++k) {
+            const unsigned long long bk = __ballot((h >> k) & 1);
+            same &= (h >> k) & 1 ? bk : ~bk;
+        }
+        const unsigned long long lower = (1ull << lane) - 1;
+        const unsigned long long below = same & lower, above = same & ~lower & ~(1ull << lane);
+        if (live && below) d = (uint32_t)lane - (uint32_t)(63 - __clzll((long long)below));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        s.head[live && !above ? h : spare] = (uint16_t)mine;
+    }
+    s.link[idx + lane] = (uint16_t)(live && d <= 32767u ? d : 0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+}
+
+// One chunk [c0, c1) of a stream's positions on one workgroup.  rb: the round's first position (records are kept in round
+// coordinates).  FULL: vinfo / bbase / bwords / pool as dfl2_search_kernel; else match[position - rb] = run << 16 | distance
+// (0: no run > 5).  temp: SPNG_D3_WAVES x 30 x 64 words of global scratch of this workgroup (FULL).
+template <bool FULL>
+__device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uint64_t rb, uint64_t c0, uint64_t c1, int attempts, int goal, uint32_t wmask,
+                                                uint32_t *adlerS, uint32_t *adlerI, uint32_t *fail,
+                                                uint16_t *vinfo, uint64_t *bbase, uint32_t *bwords, uint32_t *pool, unsigned long long *pool_next, uint64_t pool_cap,
+                                                uint32_t *temp, uint32_t *match)
+{
+    D3Lds &s = g_d3;
+    const int lane = threadIdx.x & 63, wave = (int)UNI(threadIdx.x >> 6);
+    const uint64_t warm = (c0 >= 32768 ? c0 - 32768 : 0) & ~(uint64_t)255;       // first position entered into the window
+    const uint32_t c0r = (uint32_t)(c0 - warm), c1r = (uint32_t)(c1 - warm);
+    const uint32_t nr = n - warm < (1u << 30) ? (uint32_t)(n - warm) : 1u << 30;  // the input's end, relative (bytes behind it read as zero)
+    const uint32_t stage_end = (c1r + 336 + 255) & ~255u;      // bytes staged in all (a batch looks 258 + 8 bytes ahead, + a dword of slack)
+    const uint64_t last_main = n - 4 + 1;                      // positions 0 .. n-4 are searched
+    const uint32_t nbatches = (c1r - c0r + 63) / 64;
+    for (uint32_t i = threadIdx.x; i < (1u << SPNG_D3_HBITS) + 64; i += SPNG_D3_WAVES * 64) s.head[i] = 32768;   // (2^15 behind position 0: no link)
+    if (threadIdx.x < SPNG_D3_WAVES) s.cur[threadIdx.x] = threadIdx.x == 0 ? ~0u : 0u;
+    if (threadIdx.x == 0) { s.staged = 0; s.inserted = 0; s.next = 0; }
+    __syncthreads();
+
+    if (wave == 0) {
+        // ---- the stager and inserter
+        __builtin_amdgcn_s_setprio(3);                         // (fifteen waves wait on this one)
+        uint32_t accS = 0, accI = 0;
+        auto fetch = [&](uint32_t at) -> uint32_t {            // the four bytes at relative offset at + 4 lane
+            const uint32_t off = at + 4u * (uint32_t)lane;
+            if (off + 4 <= nr) return load32(in + warm + off);
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < 4; ++k) if (off + k < nr) v |= (uint32_t)in[warm + off + k] << (8 * k);
+            return v;
+        };
+        auto put_step = [&](uint32_t sidx, uint32_t v) {       // 256 bytes into ring slot sidx (a multiple of 256)
+            const uint32_t o = sidx + 4u * (uint32_t)lane;
+            s.in32[o >> 2] = v;
+            if (o < D3_MIR) s.in32[(D3_R + o) >> 2] = v;
+        };
+        uint32_t staged = 0, sidx = 0;                         // bytes in the ring; the ring slot of the next step
+        uint32_t q0 = fetch(0), q1 = fetch(256), q2 = fetch(512), q3 = fetch(768);
+        put_step(0, q0); staged = 256; sidx = 256;
+        q0 = q1; q1 = q2; q2 = q3; q3 = fetch(1024);
+        uint32_t fetched = 1280;                               // next offset to ask for
+        uint32_t smin = 0;                                     // lowest batch some wave may still be at (as last looked up)
+        uint32_t iidx = 0;
+        const uint32_t warm_m = (uint32_t)(warm % 65521);
+        // one more step of 256 bytes into the ring -- never beyond what the slowest searcher still needs: the slot of position x
+        // is x + D3_R's, and a batch looks back 32767 positions
+        auto stage_step = [&]() {
+            {
+                SpinGuard guard;
+                while (staged + 256 > c0r + 64u * smin + (D3_R - 32768)) {
+                    uint32_t v = (uint32_t)lane < SPNG_D3_WAVES ? __hip_atomic_load(&s.cur[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                               : lane == SPNG_D3_WAVES ? __hip_atomic_load(&s.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0u;
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o < v ? o : v; }
+                    smin = UNI(v);
+                    if (staged + 256 <= c0r + 64u * smin + (D3_R - 32768)) break;
+                    __builtin_amdgcn_s_sleep(4);
+                    guard.tick();
+                }
+                put_step(sidx, q0);
+                staged += 256; sidx = sidx + 256 >= D3_R ? 0 : sidx + 256;
+                q0 = q1; q1 = q2; q2 = q3; q3 = fetch(fetched); fetched += 256;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+                if (lane == 0) __hip_atomic_store(&s.staged, staged, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
+        for (uint32_t i = 0; i < c1r; i += 256) {
+            if (staged < stage_end) stage_step();              // the step behind this quad's positions: their keys reach three bytes into it
+#pragma unroll 1
+            for (uint32_t k = 0; k < 256 && i + k < c1r; k += 64) {
+                const uint32_t rel = i + k;
+                d3_insert(s, rel, iidx, warm + rel, warm_m + rel, n, rel + (uint32_t)lane >= c0r && rel + (uint32_t)lane < c1r, accS, accI, lane);
+                iidx = iidx + 64 >= D3_R ? 0 : iidx + 64;
+            }
+            const uint32_t done = i + 256 < c1r ? i + 256 : c1r;
+            if (lane == 0) __hip_atomic_store(&s.inserted, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        while (staged < stage_end) stage_step();               // what the last batches look ahead at
+        // Adler-32 sums of the chunk (MRC32.swift:26-50 in the closed form of inflate.hip), added to the stream's
+        uint32_t S = accS % 65521, I = accI % 65521;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { S += __shfl_xor(S, m, 64); I += __shfl_xor(I, m, 64); }
+        if (lane == 0) { atomicAdd(adlerS, S % 65521); atomicAdd(adlerI, I % 65521); }
+        __builtin_amdgcn_s_setprio(0);
+    }
+    // ---- the searchers: 64 positions at a time
+    uint32_t *tw = FULL ? temp + (uint64_t)wave * (30 * 64) : nullptr;
+    for (;;) {
+        uint32_t b = 0;
+        if (lane == 0) b = atomicAdd(&s.next, 1u);
+        b = UNI(b);
+        if (b >= nbatches) break;
+        if (lane == 0) __hip_atomic_store(&s.cur[wave], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t p0r = c0r + 64u * b, upto = p0r + 64 < c1r ? p0r + 64 : c1r;
+        const uint32_t ahead = p0r + 336 < stage_end ? p0r + 336 : stage_end;
+        {
+            SpinGuard guard;
+            while (__hip_atomic_load(&s.inserted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < upto ||
+                   __hip_atomic_load(&s.staged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < ahead) {
+                __builtin_amdgcn_s_sleep(2);
+                guard.tick();
+            }
+        }
+        const uint32_t rel = p0r + (uint32_t)lane, idx0 = UNI(p0r % D3_R) + (uint32_t)lane, idx = idx0 >= D3_R ? idx0 - D3_R : idx0;
+        const uint64_t p = warm + rel;
+        const bool inchunk = rel < c1r, live = inchunk && p < last_main;
+        const uint32_t key = d3_u32(s, idx);
+        const uint32_t lim = n - p < 258 ? (uint32_t)(n - p) : 258u;
+        // LZ77.DeflatorWindow.match (:132-212): the candidates of the key, most recent first
+        uint32_t d = live ? s.link[idx] : 0u, acc = 0;
+        int rem = attempts;
+        bool first = true;
+        uint32_t ext = FULL ? 1u : 5u, bestd = 1;              // longest run seen (levels 0-7: it must exceed 5, and its distance)
+        uint32_t cdec = 0xff, crun = 0, cdist = 0, cnt = 0;    // FULL: the decade at hand, its longest run and that run's distance; words so far
+        while (d) {
+            acc += d;
+            if (acc > wmask || (!first && acc >= wmask)) break;
+            const uint32_t cidx = idx >= acc ? idx - acc : idx + D3_R - acc;
+            const uint32_t e = s.link[cidx];
+            if (d3_u32(s, cidx) == key) {
+                const uint32_t run = d3_common_prefix(s, cidx, idx, lim);
+                if (FULL) {
+                    ext = run > ext ? run : ext;
+                    const uint32_t dec = dist_decade(acc);
+                    if (dec != cdec) {
+                        if (cdec != 0xff) { tw[cnt * 64 + (uint32_t)lane] = (uint32_t)lane << 24 | cdist << 9 | crun; ++cnt; }
+                        cdec = dec; crun = run; cdist = acc;
+                    } else if (run > crun) { crun = run; cdist = acc; }    // (strict: the closest candidate of a decade stays)
+                } else if (ext < run) { ext = run; bestd = acc; }          // (the first strictly longest run wins, :145-208)
+                first = false; rem -= 1;
+                if (!(rem > 0 && goal > (int)run)) break;
+            }
+            d = e;
+        }
+        const uint64_t v = (warm + p0r - rb) + (uint32_t)lane;  // round coordinates
+        if (!FULL) {
+            if (inchunk) match[v] = ext > 5 ? ext << 16 | bestd : 0u;
+            continue;
+        }
+        if (cdec != 0xff) { tw[cnt * 64 + (uint32_t)lane] = (uint32_t)lane << 24 | cdist << 9 | crun; ++cnt; }
+        // ---- the batch's record: per position candidates << 9 | longest run; the words where the pool has room
+        uint32_t T;
+        const uint32_t pre = wave_excl_scan(cnt, T, lane);
+        uint32_t mr = ext;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mr, m, 64); mr = o > mr ? o : mr; }
+        unsigned long long base = 0;
+        if (T && lane == 0) base = atomicAdd(pool_next, (unsigned long long)T);
+        base = uni64(base);
+        const bool ok = base + T <= pool_cap;
+        if (!ok && lane == 0) atomicOr(fail, 1u);
+        if (inchunk) vinfo[v] = (uint16_t)(cnt << 9 | ext);
+        if (lane == 0) { bbase[v >> 6] = base; bwords[v >> 6] = T | mr << 16; }
+        if (ok && T) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's own words, back from the scratch (L1 is write-through: read past it)
+            for (uint32_t k = 0; k < cnt; ++k)
+                pool[base + pre + k] = __hip_atomic_load(&tw[k * 64 + (uint32_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (lane == 0) __hip_atomic_store(&s.cur[wave], ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(SPNG_D3_WAVES * 64) void dfl3_search_kernel(const D2Stream *__restrict__ streams, uint32_t cps, uint32_t chunk_len, uint32_t *__restrict__ pool,
+                                                          unsigned long long *__restrict__ pool_next, uint64_t pool_cap, uint32_t *__restrict__ temp, uint32_t parity)
+{
+    const D2Stream &st = streams[blockIdx.x / cps];
+    D2State *state = (D2State *)uni64((uint64_t)st.state);
+    if (UNI(state->done) || UNI(state->fail)) return;
+    // (the search's own cursor: this round may be a round ahead of the one the parse kernel is at)
+    const uint64_t n = uni64(st.src_len), rb = uni64(state->srb), re = uni64(state->sre);
+    const uint64_t c0 = rb + (uint64_t)(blockIdx.x % cps) * chunk_len, c1 = c0 + chunk_len < re ? c0 + chunk_len : re;
+    if (c0 >= re || n < 3) return;
+    const int lv = (int)UNI(st.level) > 13 ? 13 : (int)UNI(st.level);
+    // DeflatorSearch.init(level:) (:13-35), full rows
+    const int attempts = lv == 8 ? 14 : lv == 9 ? 20 : lv == 10 ? 30 : lv == 11 ? 60 : lv == 12 ? 100 : 0x7fffffff;
+    const int goal = lv == 8 ? 20 : lv == 9 ? 32 : lv == 10 ? 50 : lv == 11 ? 80 : lv == 12 ? 133 : 258;
+    d3_search_chunk<true>((const gbyte *)uni64((uint64_t)st.src), n, rb, c0, c1, attempts, goal, (1u << UNI(st.exponent)) - 1,
+                          &state->adlerS, &state->adlerI, &state->fail,
+                          (uint16_t *)uni64((uint64_t)(parity ? st.vinfo2 : st.vinfo)), (uint64_t *)uni64((uint64_t)(parity ? st.bbase2 : st.bbase)),
+                          (uint32_t *)uni64((uint64_t)(parity ? st.bwords2 : st.bwords)), pool, pool_next, pool_cap,
+                          temp + (uint64_t)blockIdx.x * (SPNG_D3_WAVES * 30 * 64), nullptr);
+}
+
 // ---- the parse kernel -------------------------------------------------------------------------------------------
 struct D2Arrays {                                               // (pointers of one stream, wave-uniform)
     const uint16_t *vinfo; const uint64_t *bbase; const uint32_t *bwords; uint64_t *emask;
@@ -2380,13 +2677,14 @@ hipError_t launch_deflate2_begin(const D2Stream *d_streams, uint32_t count, hipS
     return hipGetLastError();
 }
 
+uint64_t deflate2_temp_bytes(uint32_t workgroups) { return (uint64_t)workgroups * (SPNG_D3_WAVES * 30 * 64 * 4); }
 hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t *d_pool, unsigned long long *d_pool_next,
-                                  uint64_t pool_words, uint32_t *d_rings, uint32_t parity, hipStream_t stream)
+                                  uint64_t pool_words, uint32_t *d_temp, uint32_t parity, hipStream_t stream)
 {
     if (!count) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_pool_next, 0, 8, stream);
     if (e != hipSuccess) return e;
-    dfl2_search_kernel<<<count * cps, SPNG_D2_WAVES * 64, 0, stream>>>(d_streams, cps, chunk_len, d_pool, d_pool_next, pool_words, d_rings, parity);
+    dfl3_search_kernel<<<count * cps, SPNG_D3_WAVES * 64, 0, stream>>>(d_streams, cps, chunk_len, d_pool, d_pool_next, pool_words, d_temp, parity);
     dfl2_advance_kernel<<<(count + 255) / 256, 256, 0, stream>>>(d_streams, count);
     return hipGetLastError();
 }

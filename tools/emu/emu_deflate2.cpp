@@ -60,7 +60,7 @@ int main(int argc, char **argv)
     const uint64_t pool_words = (n < (1u << 21) ? n : (1u << 21)) * 30 + 4096;
     std::vector<uint32_t> pool[2] = {std::vector<uint32_t>(pool_words, 0), std::vector<uint32_t>(pool_words, 0)};
     unsigned long long pool_next[2] = {0, 0};
-    std::vector<uint32_t> rings((size_t)cps * 65536, 0);
+    std::vector<uint32_t> rings((size_t)cps * SPNG_D3_WAVES * 30 * 64, 0);    // (the search workgroups' word scratch)
     D2State state;
     memset(&state, 0, sizeof state);
     D2Stream st;
@@ -89,7 +89,7 @@ int main(int argc, char **argv)
         for (uint32_t r = 0; r < calls_rounds; ++r, ++rounds) {
             const uint32_t par = r & 1;
             pool_next[par] = 0;
-            emu::launch(cps, SPNG_D2_WAVES * 64, [&] { dfl2_search_kernel(&st, cps, chunk, pool[par].data(), &pool_next[par], pool_words, rings.data(), par); });
+            emu::launch(cps, SPNG_D3_WAVES * 64, [&] { dfl3_search_kernel(&st, cps, chunk, pool[par].data(), &pool_next[par], pool_words, rings.data(), par); });
             emu::launch(1, 256, [&] { dfl2_advance_kernel(&st, 1); });
             emu::launch(1, 64, [&] { dfl2_parse_kernel(&st, pool[par].data(), &res, par); });
             if (getenv("EMU_VERBOSE")) fprintf(stderr, "call %zu round %u: pos %llu limit %u total %llu fail %u done %u status %d\n", call, r, (unsigned long long)state.pos,
