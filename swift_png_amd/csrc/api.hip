@@ -1778,6 +1778,108 @@ static int32_t deflate_full_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
     return SPNG_DONE;
 }
 
+// Levels 0-7 in rounds (deflate.hip, "round 5"): the chip-wide search leaves one word per position, a parse wave per stream walks
+// them.  Per stream two sets of 4 bytes per position of a round (<= 2^21 positions; the search of round r + 1 beside the parse of
+// round r) from the context's slab, streams that do not fit side by side in groups.  No room at all: the one-kernel form for
+// streams that keep no state, an error for pushed ones.
+static int32_t deflate_fast_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted, size_t first, size_t last, spng_result *dr, Arena &a, size_t jslot, bool &fell_back)
+{
+    fell_back = false;
+    if (first >= last) return SPNG_DONE;
+    const size_t nfast = last - first;
+    const uint64_t RV = deflate3_round_positions();
+    // what a call searches: from where the previous push left the search (plan_aux) to the end the input allows
+    auto span_of = [&](const DeflateJob &j) -> uint64_t {
+        const uint64_t from = j.state ? j.plan_aux : 0, E = deflate3_end(j.src_len, j.more != 0);
+        return E > from ? E - from : 0;
+    };
+    auto scratch_of = [&](const DeflateJob &j) -> uint64_t {
+        const uint64_t sp = span_of(j), V = (sp < RV ? sp : RV) + 64;
+        return 2 * ((4 * V + 255) & ~255ull);
+    };
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = c->cfg[SPNG_CFG_DEFLATE_BYTES] ? (uint64_t)c->cfg[SPNG_CFG_DEFLATE_BYTES] : (uint64_t)(free_b + c->graph_cap + c->ring_cap) / 2;
+    std::vector<std::pair<size_t, size_t>> groups;
+    uint64_t slab = 0;
+    for (size_t i = first; i < last;) {
+        uint64_t used = 0;
+        size_t k = i;
+        while (k < last) {
+            const uint64_t sc = scratch_of(sorted[k]);
+            if (used + sc > budget && k > i) break;
+            used += sc; ++k;
+        }
+        slab = used > slab ? used : slab;
+        groups.push_back({i, k});
+        i = k;
+    }
+    slab += 4096;
+    if (slab > c->graph_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_graph) HIP_TRY(hipFree(c->d_graph));
+        c->d_graph = nullptr; c->graph_cap = 0;
+        if (hipMalloc(&c->d_graph, slab) != hipSuccess) {
+            (void)hipGetLastError();
+            for (size_t i = first; i < last; ++i)
+                if (sorted[i].state || sorted[i].more) return fail_text("spng_deflate_resume_batch: no device memory for the search records of pushed streams");
+            fell_back = true;                                  // (the caller runs the one-kernel form)
+            return SPNG_DONE;
+        }
+        c->graph_cap = slab;
+    }
+    const size_t sslot = a.take(nfast * sizeof(D3Stream)), tslot = a.take(nfast * sizeof(D1State));
+    D3Stream *hs = a.host<D3Stream>(sslot);
+    // (a zeroed state = a stream's beginning: dfl3_begin_kernel; only the head of a D1State matters -- the terms of a state that
+    //  has not started are never read)
+    for (size_t i = 0; i < nfast; ++i) memset(a.host<D1State>(tslot) + i, 0, sizeof(D1State));
+    std::vector<uint32_t> rounds_of(nfast, 1);
+    for (auto &gr : groups) {
+        char *base = (char *)c->d_graph;
+        uint64_t at = 0;
+        for (size_t i = gr.first; i < gr.second; ++i) {
+            const DeflateJob &j = sorted[i];
+            D3Stream &s = hs[i - first];
+            const uint64_t half = scratch_of(j) / 2;
+            s.src = j.src; s.dst = j.dst; s.src_len = j.src_len; s.dst_cap = j.dst_cap; s.format = j.format; s.level = j.level;
+            s.image = j.image; s.exponent = j.exponent; s.more = j.more; s.pad = 0;
+            s.state = j.state ? j.state : a.dev<D1State>(tslot) + (i - first);
+            s.match[0] = (uint32_t *)(base + at); s.match[1] = (uint32_t *)(base + at + half);
+            at += 2 * half;
+            const uint64_t sp = span_of(j);
+            rounds_of[i - first] = sp ? (uint32_t)((sp + RV - 1) / RV) : 1u;   // (one launch at least: it reports where the stream stands)
+        }
+    }
+    if (int32_t st = c->upload(sslot, tslot + nfast * sizeof(D1State))) return st;
+    if (!c->stream2) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        for (hipEvent_t *e : {&c->ev_fork, &c->ev_mid, &c->ev_join}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    if (!c->ev_dfl[0]) for (hipEvent_t &e : c->ev_dfl) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &gr : groups) {
+        const uint32_t cnt = (uint32_t)(gr.second - gr.first);
+        uint32_t cps = (256 + cnt - 1) / cnt;                 // (as the level >= 8 search: one round of workgroups where the streams are few)
+        cps = cps < 2 ? 2 : cps > 64 ? 64 : cps;
+        const uint32_t chunk = (uint32_t)(((RV / cps + 63) / 64) * 64);
+        uint32_t rounds = 0;
+        for (size_t i = gr.first; i < gr.second; ++i) rounds = rounds_of[i - first] > rounds ? rounds_of[i - first] : rounds;
+        const D3Stream *ds = a.dev<D3Stream>(sslot) + (gr.first - first);
+        HIP_TRY(launch_deflate3_begin(ds, cnt, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        for (uint32_t r = 0; r < rounds; ++r) {
+            const uint32_t par = r & 1;
+            if (r >= 2) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_dfl[2 + par], 0));     // the parse of round r - 2 is done with these records
+            { Timed t(c, SPNG_K_DFL_SEARCH, c->stream2); HIP_TRY(launch_deflate3_search(ds, cnt, cps, chunk, par, c->stream2)); }
+            HIP_TRY(hipEventRecord(c->ev_dfl[par], c->stream2));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_dfl[par], 0));
+            { Timed t(c, SPNG_K_DFL_PARSE); HIP_TRY(launch_deflate3_parse(ds, cnt, dr, par, c->stream)); }
+            HIP_TRY(hipEventRecord(c->ev_dfl[2 + par], c->stream));
+        }
+    }
+    return SPNG_DONE;
+}
+
 // shared by spng_deflate_batch / spng_encode_batch.  Per-stream link rings of the greedy / lazy kernel live in a context-owned slab.
 static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_result *dr, Arena &a, size_t jslot,
                               size_t gzparts = (size_t)-1)
@@ -1790,7 +1892,13 @@ static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_r
     for (auto &j : jobs) if (j.level >= 8) sorted.push_back(j);
     bool legacy = c->cfg[SPNG_CFG_DEFLATE_MODE] == SPNG_DEFLATE_ONE_KERNEL;
     for (auto &j : jobs) if (j.state) legacy = false;          // (streams that arrive in pieces: only the two-kernel search keeps a state)
-    const size_t nring = nfast;
+    // levels 0-7: the search chip-wide and a parse wave per stream, round by round -- unless the one-kernel form is asked for
+    bool fast_one_kernel = legacy && nfast;
+    if (nfast && !fast_one_kernel) {
+        Timed t(c, SPNG_K_DEFLATE);
+        if (int32_t st = deflate_fast_rounds(c, sorted, 0, nfast, dr, a, jslot, fast_one_kernel)) return st;
+    }
+    const size_t nring = fast_one_kernel ? nfast : 0;
     const size_t ring_bytes = nring * 65536 * 4;
     if (ring_bytes > c->ring_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1804,7 +1912,7 @@ static int32_t deflate_launch(spng_ctx *c, std::vector<DeflateJob> &jobs, spng_r
     if (int32_t st = c->upload(jslot, jslot + sorted.size() * sizeof(DeflateJob))) return st;
     {
         Timed t(c, SPNG_K_DEFLATE);
-        if (nfast) HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)nfast, dr, c->stream));
+        if (fast_one_kernel) HIP_TRY(launch_deflate(a.dev<DeflateJob>(jslot), (uint32_t)nfast, dr, c->stream));
         if (legacy) { if (int32_t st = deflate_full_legacy(c, sorted, nfast, sorted.size(), dr, a, jslot)) return st; }
         else if (int32_t st = deflate_full_rounds(c, sorted, nfast, sorted.size(), dr, a, jslot)) return st;
     }
@@ -1833,7 +1941,7 @@ int32_t spng_deflate_batch(spng_ctx *c, const spng_stream_desc *descs, const int
                              descs[i].dst_cap, nullptr, descs[i].format, levels[i], i,
                              descs[i].format == SPNG_FORMAT_IOS ? 15u : (uint32_t)e, nullptr, 0, 0};
     }
-    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + sizeof(D2Stream) + sizeof(D2State) + 16 + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 8192)) return st;
+    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + sizeof(D2Stream) + sizeof(D2State) + sizeof(D3Stream) + sizeof(D1State) + 1024 + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 8192)) return st;
     Arena a{c};
     const size_t jslot = a.take(count * sizeof(DeflateJob));
     const size_t res = a.take(count * sizeof(spng_result));
@@ -1867,11 +1975,11 @@ int32_t spng_deflate_resume_batch(spng_ctx *c, const spng_stream_desc *descs, co
         j.src = (const uint8_t *)descs[i].d_src; j.dst = (uint8_t *)descs[i].d_dst; j.src_len = descs[i].src_len; j.dst_cap = descs[i].dst_cap;
         j.format = descs[i].format; j.level = levels[i]; j.image = i; j.exponent = descs[i].format == SPNG_FORMAT_IOS ? 15u : (uint32_t)e;
         j.more = last[i] ? 0u : 1u; j.state = (D1State *)d_states[i];
-        if (h_state) { j.plan_pos = h_state[2 * i]; j.plan_limit = (uint32_t)h_state[2 * i + 1]; }
+        if (h_state) { j.plan_pos = h_state[2 * i]; j.plan_limit = (uint32_t)h_state[2 * i + 1]; j.plan_aux = h_state[2 * i + 1]; }
         if (j.plan_pos > j.src_len) return SPNG_E_ARGUMENT;     // (a state is only ever what an earlier call handed out)
         jobs[i] = j;
     }
-    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + sizeof(D2Stream) + sizeof(D2State) + 16 + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 8192)) return st;
+    if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + sizeof(D2Stream) + sizeof(D2State) + sizeof(D3Stream) + sizeof(D1State) + 1024 + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 8192)) return st;
     Arena a{c};
     const size_t jslot = a.take(count * sizeof(DeflateJob));
     const size_t res = a.take(count * sizeof(spng_result));

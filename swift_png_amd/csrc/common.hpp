@@ -197,18 +197,34 @@ struct DeflateJob {
     uint32_t       graph_vertices;
     uint32_t       more;          // spng_deflate_resume_batch: more input will follow (src_len is what arrived so far)
     struct D1State *state;        // ... and where the stream keeps itself between pushes (levels 0-7: a D1State, 8 and up: a D2State; null: one-shot)
-    uint64_t       plan_pos;      // (host side, levels >= 8: where the previous push left the parse, and its block limit)
-    uint32_t       plan_limit, pad2;
+    uint64_t       plan_pos;      // (host side: where the previous push left the parse; levels >= 8: its block limit, 0-7: how far
+    uint32_t       plan_limit, pad2;   //  the input has been searched -- what the previous call returned in aux[0], aux[1])
+    uint64_t       plan_aux;
 };
 
 // Greedy / lazy kernel between two pushes (spng_deflate_resume_batch, levels 0-7): the parse position, the terms queued for the
 // block being filled, the bit writer, the Adler sums.  The hash window is not kept: the next push enters the last 32 KiB again.
 struct D1State {
-    uint64_t w, inserted;         // first unparsed position; positions below `inserted` are in the Adler sums
+    uint64_t w, inserted;         // first unparsed position; (one-kernel form) positions below `inserted` are in the Adler sums
     uint64_t acc, total;          // the bit writer: pending bits, bytes produced
     uint32_t nacc, overflow, count, started;
     uint32_t adlerS, adlerI, pad[2];
     uint32_t terms[2048];
+    // the two-kernel form (round 5: dfl3_search_kernel + dfl3_parse_kernel): the positions of the round the parse is at, the
+    // search's own cursor (it runs a round ahead) and how far the input has been searched -- rounds partition the positions, so the
+    // Adler sums the search workgroups add up (unreduced, adlerS / adlerI) count every byte once whatever the pushes were
+    uint64_t rb, re, srb, sre, spos;
+    uint32_t done, pad3;
+};
+// One stream of the greedy / lazy levels in the two-kernel form
+struct D3Stream {
+    const uint8_t *src; uint8_t *dst;
+    uint64_t src_len, dst_cap;
+    int32_t  format, level;
+    uint32_t image, exponent;
+    uint32_t more, pad;
+    D1State *state;
+    uint32_t *match[2];           // by round parity: per position of the round (and one behind it) run << 16 | distance, 0: no run > 5
 };
 
 // levels >= 8, the two-kernel form (deflate.hip, "round 4"): what the search and the parse kernel share per stream.
@@ -288,6 +304,12 @@ uint64_t deflate2_vertices(uint64_t n);
 hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t *d_pool, unsigned long long *d_pool_next,
                                   uint64_t pool_words, uint32_t *d_temp, uint32_t parity, hipStream_t stream);
 uint64_t deflate2_temp_bytes(uint32_t workgroups);
+// levels 0-7 in rounds (deflate.hip, "round 5")
+uint64_t deflate3_round_positions();
+uint64_t deflate3_end(uint64_t n, bool more);
+hipError_t launch_deflate3_begin(const D3Stream *d_streams, uint32_t count, hipStream_t stream);
+hipError_t launch_deflate3_search(const D3Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t parity, hipStream_t stream);
+hipError_t launch_deflate3_parse(const D3Stream *d_streams, uint32_t count, spng_result *d_results, uint32_t parity, hipStream_t stream);
 hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, uint32_t parity, hipStream_t stream);
 hipError_t launch_deflate2_failed(const D2Stream *d_streams, uint32_t count, uint32_t *d_failed, hipStream_t stream);
 uint64_t deflate_graph_vertices(uint64_t n);

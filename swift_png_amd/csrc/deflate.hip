@@ -88,13 +88,11 @@ struct DLds {                                    // what every kernel of this fi
     uint8_t  msym[320], mbits[320];              // code-length RLE terms
     uint8_t  cl[20];                             // code-length-code lengths in transmission order
 };
-struct DLdsSearch {                              // the match search: greedy / lazy kernel, one-wave full kernel
+struct DLdsSearch {                              // the match search of the one-kernel forms (greedy / lazy, full)
     uint32_t head[(1 << HBITS) + 1];             // most recent position per bucket (low 32 bits); + a slot nobody reads
-    union {
-        uint32_t terms[2048];                    // greedy / lazy: the queued terms
-        uint32_t cslot[2][30 * 64];              // full: per lane and half, the best run of every distance decade (distance << 16 | run)
-    };
+    uint32_t cslot[2][30 * 64];                  // full: per lane and half, the best run of every distance decade (distance << 16 | run)
 };
+struct DLdsTerms { uint32_t terms[2048]; };      // greedy / lazy: the queued terms (of their own: dfl3_parse_kernel has no search in it)
 struct DLdsOld {                                 // the one-kernel full search (deflate_full_kernel)
     uint32_t batch[64 * 30];                     // the edge slots of the 64 vertices at hand
     // the full kernel's helper waves (forward pass): what wave 0 hands them per pass and per batch of 64 vertices
@@ -107,6 +105,7 @@ struct DLdsOld {                                 // the one-kernel full search (
 // with LDS instructions instead of through a generic pointer.
 __shared__ __attribute__((aligned(16))) DLds g_lds;
 __shared__ __attribute__((aligned(16))) DLdsSearch g_sea;
+__shared__ __attribute__((aligned(16))) DLdsTerms g_trm;
 __shared__ __attribute__((aligned(16))) DLdsOld g_old;
 
 struct Bits {                                    // LSB-first bit writer (LZ77.DeflatorOut.append)
@@ -455,7 +454,7 @@ __device__ __attribute__((noinline)) Bits write_block(Bits b_, int count_, bool 
     for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     for (int i = lane; i < count; i += 64) {
-        const uint32_t t = g_sea.terms[i];
+        const uint32_t t = g_trm.terms[i];
         atomicAdd(&s.freq[t & 0x1ff], 1u);
         atomicAdd(&s.freq[288 + (t >> 27)], 1u);
     }
@@ -470,7 +469,7 @@ __device__ __attribute__((noinline)) Bits write_block(Bits b_, int count_, bool 
         const int i = i0 + lane;
         uint64_t v = 0; uint32_t nb = 0;
         if (i < count) {
-            const uint32_t t = g_sea.terms[i];
+            const uint32_t t = g_trm.terms[i];
             const uint32_t sym = t & 0x1ff;
             if (sym > 256) v = match_bits(s, sym & 0xff, (t >> 9) & 0x1f, t >> 27, (t >> 14) & 0x1fff, nb);
             else v = literal_bits(s, sym, nb);
@@ -703,7 +702,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
     uint64_t w0 = 0, summed = 0;                               // where the parse goes on; positions below `summed` are in the sums already
     if (resumed) {
         w0 = uni64(st1->w); summed = uni64(st1->inserted); count = (int)UNI(st1->count);
-        for (int i = lane; i < count; i += 64) g_sea.terms[i] = st1->terms[i];
+        for (int i = lane; i < count; i += 64) g_trm.terms[i] = st1->terms[i];
         if (lane == 0) { accS = st1->adlerS; accI = st1->adlerI; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     }
@@ -764,7 +763,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                 if (!(unfilled() > (lazy ? 1 : 0))) { DPROF_END(2); DPROF_BEGIN(); b = uni_bits(write_block(b, count, false, lane)); count = 0; DPROF_END(3); DPROF_BEGIN(); }
                 const uint32_t run = at(mrunA, mrunB, t);
                 const uint32_t lit = at(litA, litB, t);
-                if (!run) { g_sea.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
+                if (!run) { g_trm.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
                 uint32_t use_run = run, use_dist = at(bdA, bdB, t);
                 uint32_t adv = run;
                 if (lazy) {
@@ -773,7 +772,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                     // lazy match at a+1 (:293-299); it exists only if that position is still searched
                     const uint32_t lrun = (w + t + 1 < last_main) ? at(mrunA, mrunB, t + 1) : 0u;
                     if (lrun > run) {
-                        g_sea.terms[count] = 0xf8000000u | lit;
+                        g_trm.terms[count] = 0xf8000000u | lit;
                         ++count;
                         use_run = lrun; use_dist = at(bdA, bdB, t + 1);
                         adv = 1 + lrun;
@@ -781,7 +780,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                 }
                 // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
                 const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
-                g_sea.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
+                g_trm.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
                 ++count;
                 t += adv;
             }
@@ -794,7 +793,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
             uint32_t S = accS % 65521, I = accI % 65521;
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) { S += __shfl_xor(S, m, 64); I += __shfl_xor(I, m, 64); }
-            for (int i = lane; i < count; i += 64) st1->terms[i] = g_sea.terms[i];
+            for (int i = lane; i < count; i += 64) st1->terms[i] = g_trm.terms[i];
             if (lane == 0) {
                 st1->w = w; st1->inserted = inserted > summed ? inserted : summed; st1->acc = b.acc; st1->nacc = b.nacc; st1->total = b.total;
                 st1->overflow = b.overflow ? 1u : 0u; st1->count = (uint32_t)count; st1->started = 1;
@@ -809,7 +808,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
         for (uint64_t p = w; p < n; ++p) {
             if (!(unfilled() > 0)) { b = uni_bits(write_block(b, count, false, lane)); count = 0; }
-            g_sea.terms[count] = 0xf8000000u | UNI(in[p]);
+            g_trm.terms[count] = 0xf8000000u | UNI(in[p]);
             ++count;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1700,24 +1699,32 @@ __device__ __forceinline__ uint32_t d3_common_prefix(const D3Lds &s, uint32_t q,
 // young one and its link leads into another bucket's chain.  Harmless: along a walk positions only decrease, every candidate is
 // compared with the key itself, and had the bucket a member inside the window the head would be that member -- a stray link
 // can only stand where the true chain has ended.
-__device__ __forceinline__ void d3_insert(D3Lds &s, uint32_t rel, uint32_t idx, uint64_t p0, uint32_t p0m, uint64_t n, bool sum, uint32_t &accS, uint32_t &accI, int lane)
+// (the emulator runs a wave's lanes one after another between two wave builtins: where the hardware's "every lane reads, then
+//  every lane writes" is relied on, its lanes have to meet; the hardware serves a wave's LDS operations in order as they are)
+#ifdef SPNG_EMU
+#define D3_MEET() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#else
+#define D3_MEET() ((void)0)
+#endif
+__device__ __forceinline__ void d3_insert(D3Lds &s, uint32_t rel, uint32_t idx, uint32_t key, uint64_t p0, uint32_t pm, uint64_t n, bool sum, uint32_t &accS, uint32_t &accI, int lane)
 {
     const uint64_t p = p0 + lane;
     const bool live = p + 4 <= n;                              // the last three positions never start a match
-    const uint32_t key = d3_u32(s, idx + lane);
-    if (p < n && sum) {                                        // Adler-32 accumulators (p0m: p0 mod 65521 + a multiple of it, < 2^24)
+    if (p < n && sum) {                                        // Adler-32 accumulators (pm: this lane's position mod 65521; accI is reduced by the caller)
         const uint32_t byte = key & 0xff;
         accS += byte;
-        accI = (accI + (p0m + (uint32_t)lane) % 65521 * byte) % 65521;
+        accI += pm * byte;
     }
     const uint32_t h = (key * 0x9E3779B1u) >> (32 - SPNG_D3_HBITS);
     const uint32_t mine = (rel + (uint32_t)lane) & 0xffffu, spare = (1u << SPNG_D3_HBITS) + (uint32_t)lane;
     const uint32_t slot = live ? h : spare;
+    // (the store and the read-back are atomic operations: what comes back is what SOME lane of the bucket stored -- plain
+    //  accesses the compiler forwards from this lane's own store, and the duplicate test below is never true)
     const uint32_t old = s.head[slot];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    s.head[slot] = (uint16_t)mine;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    const uint32_t back = s.head[slot];
+    D3_MEET();
+    __hip_atomic_store(&s.head[slot], (uint16_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    D3_MEET();
+    const uint32_t back = __hip_atomic_load(&s.head[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     uint32_t d = (mine - old) & 0xffffu;
     if (__ballot(back != mine)) {
         // two positions of one bucket in the batch: the nearest lower lane of the same bucket is the previous position, the
@@ -1731,18 +1738,18 @@ __device__ __forceinline__ void d3_insert(D3Lds &s, uint32_t rel, uint32_t idx, 
         const unsigned long long lower = (1ull << lane) - 1;
         const unsigned long long below = same & lower, above = same & ~lower & ~(1ull << lane);
         if (live && below) d = (uint32_t)lane - (uint32_t)(63 - __clzll((long long)below));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        D3_MEET();
         s.head[live && !above ? h : spare] = (uint16_t)mine;
     }
     s.link[idx + lane] = (uint16_t)(live && d <= 32767u ? d : 0u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    D3_MEET();
 }
 
 // One chunk [c0, c1) of a stream's positions on one workgroup.  rb: the round's first position (records are kept in round
-// coordinates).  FULL: vinfo / bbase / bwords / pool as dfl2_search_kernel; else match[position - rb] = run << 16 | distance
+// coordinates); extra: the last `extra` positions are searched but not summed (the next chunk's: a lazy parse looks one ahead).  FULL: vinfo / bbase / bwords / pool as dfl2_search_kernel; else match[position - rb] = run << 16 | distance
 // (0: no run > 5).  temp: SPNG_D3_WAVES x 30 x 64 words of global scratch of this workgroup (FULL).
 template <bool FULL>
-__device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uint64_t rb, uint64_t c0, uint64_t c1, int attempts, int goal, uint32_t wmask,
+__device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uint64_t rb, uint64_t c0, uint64_t c1, uint32_t extra, int attempts, int goal, uint32_t wmask,
                                                 uint32_t *adlerS, uint32_t *adlerI, uint32_t *fail,
                                                 uint16_t *vinfo, uint64_t *bbase, uint32_t *bwords, uint32_t *pool, unsigned long long *pool_next, uint64_t pool_cap,
                                                 uint32_t *temp, uint32_t *match)
@@ -1783,7 +1790,7 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
         uint32_t fetched = 1280;                               // next offset to ask for
         uint32_t smin = 0;                                     // lowest batch some wave may still be at (as last looked up)
         uint32_t iidx = 0;
-        const uint32_t warm_m = (uint32_t)(warm % 65521);
+        uint32_t pm = (uint32_t)((warm + (uint32_t)lane) % 65521);      // this lane's position in the batch at hand, mod 65521
         // one more step of 256 bytes into the ring -- never beyond what the slowest searcher still needs: the slot of position x
         // is x + D3_R's, and a batch looks back 32767 positions
         auto stage_step = [&]() {
@@ -1806,14 +1813,20 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
                 if (lane == 0) __hip_atomic_store(&s.staged, staged, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         };
+        uint32_t key_next = 0;
         for (uint32_t i = 0; i < c1r; i += 256) {
             if (staged < stage_end) stage_step();              // the step behind this quad's positions: their keys reach three bytes into it
+            if (i == 0) key_next = d3_u32(s, (uint32_t)lane);
 #pragma unroll 1
             for (uint32_t k = 0; k < 256 && i + k < c1r; k += 64) {
                 const uint32_t rel = i + k;
-                d3_insert(s, rel, iidx, warm + rel, warm_m + rel, n, rel + (uint32_t)lane >= c0r && rel + (uint32_t)lane < c1r, accS, accI, lane);
-                iidx = iidx + 64 >= D3_R ? 0 : iidx + 64;
+                const uint32_t key = key_next, nidx = iidx + 64 >= D3_R ? 0 : iidx + 64;
+                key_next = d3_u32(s, nidx + (uint32_t)lane);   // (keys travel a batch ahead: bytes below rel + 131, and i + 512 are staged)
+                d3_insert(s, rel, iidx, key, warm + rel, pm, n, rel + (uint32_t)lane >= c0r && rel + (uint32_t)lane < c1r - extra, accS, accI, lane);
+                iidx = nidx;
+                pm = pm + 64 >= 65521 ? pm + 64 - 65521 : pm + 64;
             }
+            accI %= 65521;                                     // (four products < 2^24 each on top of a reduced sum)
             const uint32_t done = i + 256 < c1r ? i + 256 : c1r;
             if (lane == 0) __hip_atomic_store(&s.inserted, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -1839,7 +1852,7 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
             SpinGuard guard;
             while (__hip_atomic_load(&s.inserted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < upto ||
                    __hip_atomic_load(&s.staged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < ahead) {
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(8);
                 guard.tick();
             }
         }
@@ -1916,11 +1929,239 @@ __global__ __launch_bounds__(SPNG_D3_WAVES * 64) void dfl3_search_kernel(const D
     // DeflatorSearch.init(level:) (:13-35), full rows
     const int attempts = lv == 8 ? 14 : lv == 9 ? 20 : lv == 10 ? 30 : lv == 11 ? 60 : lv == 12 ? 100 : 0x7fffffff;
     const int goal = lv == 8 ? 20 : lv == 9 ? 32 : lv == 10 ? 50 : lv == 11 ? 80 : lv == 12 ? 133 : 258;
-    d3_search_chunk<true>((const gbyte *)uni64((uint64_t)st.src), n, rb, c0, c1, attempts, goal, (1u << UNI(st.exponent)) - 1,
+    d3_search_chunk<true>((const gbyte *)uni64((uint64_t)st.src), n, rb, c0, c1, 0, attempts, goal, (1u << UNI(st.exponent)) - 1,
                           &state->adlerS, &state->adlerI, &state->fail,
                           (uint16_t *)uni64((uint64_t)(parity ? st.vinfo2 : st.vinfo)), (uint64_t *)uni64((uint64_t)(parity ? st.bbase2 : st.bbase)),
                           (uint32_t *)uni64((uint64_t)(parity ? st.bwords2 : st.bwords)), pool, pool_next, pool_cap,
                           temp + (uint64_t)blockIdx.x * (SPNG_D3_WAVES * 30 * 64), nullptr);
+}
+
+// ---- levels 0-7 in rounds: dfl3_search_kernel<false> + dfl3_parse_kernel ----------------------------------------------------
+// deflate_kernel keeps insertion, chain walk, parse, trees and bits of a stream on ONE wave (2.6 MB/s per stream at level 6, two
+// thirds of it the chain walk, 512 streams resident).  What DeflatorWindow.match answers is a function of the input alone at
+// these levels too (the design note at the top of this file), so the search goes chip-wide exactly as at levels >= 8: a stream's
+// positions in rounds of 2^21, every round cut into chunks for the search workgroups above, which leave ONE word per position --
+// the first strictly longest run > 5 within `attempts` candidates, stopped at `goal` (:132-212) -- and a parse wave per stream
+// that only walks those answers with the greedy / lazy rules (DeflatorBuffers.Stream.swift:209-342), queues terms and writes
+// blocks; its state (parse position, queued terms, bit writer) is the D1State of spng_deflate_resume_batch, kept in HBM from
+// round to round.  The search of round r + 1 runs beside the parse of round r.  A round's search covers one position more than
+// the round (a lazy parse looks at position + 1).
+static constexpr uint32_t D3_RV = 1u << 21;
+uint64_t deflate3_round_positions() { return D3_RV; }
+// the positions a call may parse: all of them, or -- more input to come -- those whose look-ahead (their own and that of the
+// position behind them: 258 bytes + the key) is complete whatever follows
+__host__ __device__ inline uint64_t d3_end(uint64_t n, bool more) { return more ? (n > 264 ? n - 264 : 0) : n; }
+uint64_t deflate3_end(uint64_t n, bool more) { return d3_end(n, more); }
+
+__global__ void dfl3_begin_kernel(const D3Stream *__restrict__ streams, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const D3Stream &st = streams[i];
+    D1State &t = *st.state;
+    if (!t.started) { t.started = 1; t.w = 0; t.spos = 0; t.count = 0; t.acc = 0; t.total = 0; t.nacc = 0; t.overflow = 0; t.adlerS = 0; t.adlerI = 0; t.done = 0; }
+    uint64_t E = d3_end(st.src_len, st.more != 0);
+    if (E < t.spos) E = t.spos;
+    t.srb = t.spos; t.sre = t.srb + D3_RV < E ? t.srb + D3_RV : E;
+    t.rb = t.srb; t.re = t.sre;
+}
+__global__ void dfl3_advance_kernel(const D3Stream *__restrict__ streams, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const D3Stream &st = streams[i];
+    D1State &t = *st.state;
+    uint64_t E = d3_end(st.src_len, st.more != 0);
+    if (E < t.sre) E = t.sre;
+    t.spos = t.sre; t.srb = t.sre; t.sre = t.srb + D3_RV < E ? t.srb + D3_RV : E;
+}
+
+__global__ __launch_bounds__(SPNG_D3_WAVES * 64) void dfl3_search_fast_kernel(const D3Stream *__restrict__ streams, uint32_t cps, uint32_t chunk_len, uint32_t parity)
+{
+    const D3Stream &st = streams[blockIdx.x / cps];
+    D1State *state = (D1State *)uni64((uint64_t)st.state);
+    if (UNI(state->done)) return;
+    const uint64_t n = uni64(st.src_len), rb = uni64(state->srb), re = uni64(state->sre);
+    const uint64_t c0 = rb + (uint64_t)(blockIdx.x % cps) * chunk_len;
+    if (c0 >= re || n < 3) return;
+    uint64_t c1 = c0 + chunk_len < re ? c0 + chunk_len : re;
+    uint32_t extra = 0;
+    if (c1 == re && c1 < n) { c1 += 1; extra = 1; }           // (the position behind the round: what a lazy parse looks at from the last one)
+    // DeflatorSearch.init(level:) (:13-35), greedy and lazy rows
+    const int level = (int)UNI(st.level) < 0 ? 0 : (int)UNI(st.level);
+    const int lv = level & 7;
+    const int attempts = lv == 0 ? 1 : lv == 1 ? 2 : lv == 2 ? 4 : lv == 3 ? 40 : lv == 4 ? 20 : lv == 5 ? 40 : lv == 6 ? 64 : 100;
+    const int goal = lv == 0 ? 6 : lv == 1 ? 8 : lv == 2 ? 10 : lv == 3 ? 24 : lv == 4 ? 32 : lv == 5 ? 54 : lv == 6 ? 80 : 160;
+    d3_search_chunk<false>((const gbyte *)uni64((uint64_t)st.src), n, rb, c0, c1, extra, attempts, goal, (1u << UNI(st.exponent)) - 1,
+                           &state->adlerS, &state->adlerI, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                           (uint32_t *)uni64((uint64_t)st.match[parity]));
+}
+
+__global__ __launch_bounds__(64) void dfl3_parse_kernel(const D3Stream *__restrict__ streams, spng_result *__restrict__ results, uint32_t parity)
+{
+    DLds &s = g_lds;
+    const D3Stream *sp = streams + blockIdx.x;
+    const int lane = threadIdx.x;
+    D1State *state = (D1State *)uni64((uint64_t)sp->state);
+    if (UNI(state->done)) return;
+    const gbyte *in = (const gbyte *)uni64((uint64_t)sp->src);
+    const uint64_t n = uni64(sp->src_len);
+    const int32_t format = (int32_t)UNI(sp->format);
+    const bool lazy = (int32_t)UNI(sp->level) >= 4;            // Stream.compress lazy (:268-323) from level 4 on
+    const bool more = UNI(sp->more) != 0;                      // spng_deflate_resume_batch: the input goes on behind src_len
+    const uint32_t image = UNI(sp->image);
+    const gword *match = (const gword *)uni64((uint64_t)sp->match[parity]);
+
+    for (int i = lane; i < OUTB / 4; i += 64) s.out32[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    Bits b = {uni64(state->acc), UNI(state->nacc), uni64(state->total), uni64(state->total), (gbyte *)uni64((uint64_t)sp->dst), uni64(sp->dst_cap),
+              UNI(state->overflow) != 0};
+    uint64_t w = uni64(state->w);
+    int count = (int)UNI(state->count);
+    const uint64_t rb = uni64(state->rb), re = uni64(state->re);
+    uint64_t E = d3_end(n, more);
+    E = E < re ? re : E;
+    if (n < 3 && more) {
+        // (nothing can be decided yet: not even whether this will be a stored tail)
+        if (lane == 0) {
+            spng_result &res = results[image];
+            res.status = SPNG_NEED_MORE_INPUT; res.reserved = 0; res.written = b.total; res.consumed = w; res.aux[0] = w; res.aux[1] = uni64(state->spos);
+        }
+        return;
+    }
+    if (w == 0 && b.total == 0 && b.nacc == 0 && count == 0) {
+        // the stream's first round
+        if (format == SPNG_FORMAT_ZLIB) {
+            // StreamHeader.write (StreamHeader.swift:56-62)
+            const uint32_t unpaired = (UNI(sp->exponent) - 8) << 4 | 0x08;
+            const uint32_t check = ~(((unpaired << 8 | unpaired >> 8) & 0xffff) % 31) & 31;
+            put(s, b, check << 8 | unpaired, 16, lane);
+        } else if (format == SPNG_FORMAT_GZIP) {
+            // Gzip.StreamHeader.write (Gzip.StreamHeader.swift:84-96); the trailer is appended by gzip.hip
+            put(s, b, 0x8b1f, 16, lane); put(s, b, 0x0008, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0xff00, 16, lane);
+        }
+    }
+    for (int i = lane; i < count; i += 64) g_trm.terms[i] = state->terms[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    const int limit_terms = 2048;
+    auto unfilled = [&]() { return limit_terms - 1 - count; };
+
+    uint32_t tailS = 0, tailI = 0;
+    if (n < 3) {
+        // Stream.compressBlocks stored tail (:45-60, :417-434)
+        put(s, b, 1, 3, lane);
+        if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
+        put(s, b, (uint32_t)n, 16, lane); put(s, b, ~(uint32_t)n & 0xffff, 16, lane);
+        for (uint64_t k = 0; k < n; ++k) put(s, b, in[k], 8, lane);
+        if ((uint64_t)lane < n) { tailS = in[lane]; tailI = (uint32_t)lane * in[lane]; }
+        w = n;
+    } else {
+        const uint64_t last_main = n - 4 + 1;                  // positions 0 .. n-4 are searched
+        const uint64_t stop = re < last_main ? re : last_main; // tokens that start below `stop` are this round's
+        // the answers of 128 positions at a time (two per lane), fetched a batch ahead: a wave alone has nobody to hide a load behind
+        auto ask = [&](uint64_t p, uint32_t &m, uint32_t &lit) {
+            m = (p <= re && p < last_main) ? match[p - rb] : 0u;
+            lit = p < n ? (uint32_t)in[p] : 0u;
+        };
+        uint32_t nmA, nmB, nlA, nlB;
+        uint64_t asked = w;
+        ask(w + lane, nmA, nlA); ask(w + 64 + lane, nmB, nlB);
+        while (w < stop) {
+            uint32_t mA, mB, litA, litB;
+            if (asked == w) { mA = nmA; mB = nmB; litA = nlA; litB = nlB; }
+            else { ask(w + lane, mA, litA); ask(w + 64 + lane, mB, litB); }
+            asked = w + 128;                                   // (the guess: the batch is used up to its end -- a run across it asks again)
+            ask(asked + lane, nmA, nlA); ask(asked + 64 + lane, nmB, nlB);
+            auto at = [&](uint32_t xa, uint32_t xb, uint32_t t) -> uint32_t {
+                return t < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)xa, (int)t) : (uint32_t)__builtin_amdgcn_readlane((int)xb, (int)(t - 64));
+            };
+            // ---- the parse: Stream.compress greedy (:209-252) / lazy (:268-323) over these 128 answers
+            uint32_t t = 0;
+            while (t < 128 && w + t < stop) {
+                if (!(unfilled() > (lazy ? 1 : 0))) { b = uni_bits(write_block(b, count, false, lane)); count = 0; }
+                const uint32_t m = at(mA, mB, t);
+                const uint32_t lit = at(litA, litB, t);
+                if (!m) { g_trm.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
+                uint32_t use_run = m >> 16, use_dist = m & 0xffff;
+                uint32_t adv = use_run;
+                if (lazy) {
+                    // the answer for position w + t + 1 is needed: start the next batch there if it is not in this one
+                    if (t + 1 >= 128) break;
+                    // lazy match at a + 1 (:293-299); it exists only if that position is still searched
+                    const uint32_t lm = at(mA, mB, t + 1);
+                    if ((lm >> 16) > use_run) {
+                        g_trm.terms[count] = 0xf8000000u | lit;
+                        ++count;
+                        use_run = lm >> 16; use_dist = lm & 0xffff;
+                        adv = 1 + use_run;
+                    }
+                }
+                // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
+                const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
+                g_trm.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
+                ++count;
+                t += adv;
+            }
+            w = uni64(w + t);
+        }
+    }
+    if (re < E) {
+        // on with the next round: whole bytes out, the rest into the state
+        drain(s, b, b.total, lane);
+        for (int i = lane; i < count; i += 64) state->terms[i] = g_trm.terms[i];
+        if (lane == 0) {
+            state->w = w; state->acc = b.acc; state->nacc = b.nacc; state->total = b.total; state->overflow = b.overflow ? 1u : 0u;
+            state->count = (uint32_t)count;
+            state->rb = re; state->re = re + D3_RV < E ? re + D3_RV : E;
+        }
+        return;
+    }
+    if (more) {
+        // on with the next push
+        drain(s, b, b.total, lane);
+        for (int i = lane; i < count; i += 64) state->terms[i] = g_trm.terms[i];
+        if (lane == 0) {
+            state->w = w; state->acc = b.acc; state->nacc = b.nacc; state->total = b.total; state->overflow = b.overflow ? 1u : 0u;
+            state->count = (uint32_t)count;
+            spng_result &res = results[image];
+            res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_NEED_MORE_INPUT; res.reserved = 0;
+            res.written = b.total; res.consumed = w; res.aux[0] = w; res.aux[1] = uni64(state->spos);
+        }
+        return;
+    }
+    if (n >= 3) {
+        // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
+        for (uint64_t p = w; p < n; ++p) {
+            if (!(unfilled() > 0)) { b = uni_bits(write_block(b, count, false, lane)); count = 0; }
+            g_trm.terms[count] = 0xf8000000u | UNI(in[p]);
+            ++count;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        b = uni_bits(write_block(b, count, true, lane));
+    }
+    if (format == SPNG_FORMAT_ZLIB) {
+        // Adler-32 from the sums the search kernel left (s1 = 1 + S, s2 = N + N * S - I)
+        uint32_t S, I;
+        if (n < 3) {
+            S = tailS; I = tailI;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { S += __shfl_xor(S, m, 64); I += __shfl_xor(I, m, 64); }
+        } else { S = UNI(state->adlerS); I = UNI(state->adlerI); }
+        S %= 65521; I %= 65521;
+        const uint32_t N = (uint32_t)(n % 65521);
+        const uint32_t sum = ((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
+        if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);
+        put(s, b, sum >> 24, 8, lane); put(s, b, (sum >> 16) & 0xff, 8, lane);
+        put(s, b, (sum >> 8) & 0xff, 8, lane); put(s, b, sum & 0xff, 8, lane);
+    }
+    if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);                // DeflatorOut.pull flushes padding bits
+    drain(s, b, b.total, lane);
+    if (lane == 0) {
+        spng_result &res = results[image];
+        res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_DONE; res.reserved = 0;
+        res.written = b.total; res.consumed = n; res.aux[0] = res.aux[1] = 0;
+        state->done = 1;
+    }
 }
 
 // ---- the parse kernel -------------------------------------------------------------------------------------------
@@ -2686,6 +2927,25 @@ hipError_t launch_deflate2_search(const D2Stream *d_streams, uint32_t count, uin
     if (e != hipSuccess) return e;
     dfl3_search_kernel<<<count * cps, SPNG_D3_WAVES * 64, 0, stream>>>(d_streams, cps, chunk_len, d_pool, d_pool_next, pool_words, d_temp, parity);
     dfl2_advance_kernel<<<(count + 255) / 256, 256, 0, stream>>>(d_streams, count);
+    return hipGetLastError();
+}
+hipError_t launch_deflate3_begin(const D3Stream *d_streams, uint32_t count, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    dfl3_begin_kernel<<<(count + 255) / 256, 256, 0, stream>>>(d_streams, count);
+    return hipGetLastError();
+}
+hipError_t launch_deflate3_search(const D3Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t parity, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    dfl3_search_fast_kernel<<<count * cps, SPNG_D3_WAVES * 64, 0, stream>>>(d_streams, cps, chunk_len, parity);
+    dfl3_advance_kernel<<<(count + 255) / 256, 256, 0, stream>>>(d_streams, count);
+    return hipGetLastError();
+}
+hipError_t launch_deflate3_parse(const D3Stream *d_streams, uint32_t count, spng_result *d_results, uint32_t parity, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    dfl3_parse_kernel<<<count, 64, 0, stream>>>(d_streams, d_results, parity);
     return hipGetLastError();
 }
 hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, uint32_t parity, hipStream_t stream)

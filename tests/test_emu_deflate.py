@@ -1,5 +1,5 @@
-"""The deflate kernels of csrc/deflate.hip -- levels >= 8: dfl2_begin -> dfl2_search -> dfl2_advance -> dfl2_parse, round by round;
-levels 0-7: deflate_kernel -- run on the CPU by the wave emulator of tools/emu and compared with the oracle's stream bit for bit.  The build container has no GPU:
+"""The deflate kernels of csrc/deflate.hip -- levels >= 8: dfl2_begin -> dfl3_search -> dfl2_advance -> dfl2_parse, round by round;
+levels 0-7: dfl3_begin -> dfl3_search_fast -> dfl3_advance -> dfl3_parse (and the one-kernel form, deflate_kernel) -- run on the CPU by the wave emulator of tools/emu and compared with the oracle's stream bit for bit.  The build container has no GPU:
 this is how the LOGIC of the device deflater -- hash chains and candidate records, the skip rule, offer tables, the shortest-path
 passes, trees, the bit writer -- is checked before a GPU minute is spent.  The emulator compiles a COPY of the source prepared by
 tools/emu/prep_deflate.py (launches blanked, a few meetings of the wave where the source relies on lock-step execution); timing
@@ -18,14 +18,16 @@ sys.path.insert(0, os.path.join(ROOT, "tools", "emu"))
 import pnghelp as ph  # noqa: E402
 
 
-def build(d, round_vertices=0):
+def build(d, round_vertices=0, waves=4):
     if not shutil.which("g++"):
         pytest.skip("g++ not available")
     import prep_deflate
     inc = d / "deflate_emu.inc"
     inc.write_text(prep_deflate.prepare(open(os.path.join(ROOT, "swift_png_amd", "csrc", "deflate.hip")).read(), round_vertices))
     out = d / "emu_deflate2"
-    subprocess.run(["g++", "-O1", "-std=c++17", "-DSPNG_EMU", f'-DEMU_DEFLATE_SRC="{inc}"', "-I" + os.path.join(ROOT, "tools", "emu"),
+    # (four waves per search workgroup instead of the product's sixteen: an inserter and three searchers -- the same protocol, a
+    #  quarter of the fibers; test_emulated_search_workgroup_of_sixteen_waves runs the product's shape)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DSPNG_EMU", f"-DSPNG_D3_WAVES={waves}", f'-DEMU_DEFLATE_SRC="{inc}"', "-I" + os.path.join(ROOT, "tools", "emu"),
                     "-I" + os.path.join(ROOT, "swift_png_amd", "csrc"), "-x", "c++", "-fpermissive", "-Wno-attributes", "-w", "-o", str(out),
                     os.path.join(ROOT, "tools", "emu", "emu_deflate2.cpp")], check=True, capture_output=True, timeout=600)
     return out
@@ -93,13 +95,89 @@ def test_emulated_rounds_carry_their_state(emu_small_rounds, tmp_path, name, lev
 @pytest.mark.parametrize("level", [0, 1, 6, 7])
 @pytest.mark.parametrize("name", ["walk", "text", "zeros", "noise", "rows", "mixed", "empty", "two"])
 def test_emulated_greedy_lazy_kernel_matches_the_oracle(emu, tmp_path, name, level):
-    """levels 0-7 (`deflate_kernel`, one wave per stream; level 6 is what the bench's swift-png-made inputs are made with)"""
+    """levels 0-7, the two-kernel form (round 5): the chip-wide search leaves one answer per position, a parse wave walks them
+    (level 6 is what the bench's swift-png-made inputs are made with)"""
     data = INPUTS[name]
     want = ph.orc_deflate(data, level)
     (tmp_path / "in").write_bytes(data)
     (tmp_path / "want").write_bytes(want)
     r = subprocess.run([str(emu), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (name, level, r.stdout[-300:], r.stderr[-300:])
+    assert "search + parse kernels" in r.stdout
+
+
+@pytest.mark.parametrize("level", [1, 6])
+@pytest.mark.parametrize("name", ["walk", "rows", "mixed", "two"])
+def test_emulated_one_kernel_greedy_lazy_form(emu, tmp_path, name, level):
+    """SPNG_DEFLATE_ONE_KERNEL at levels 0-7: `deflate_kernel`, one wave per stream does everything (the fallback when the search
+    records find no memory)"""
+    data = INPUTS[name]
+    want = ph.orc_deflate(data, level)
+    (tmp_path / "in").write_bytes(data)
+    (tmp_path / "want").write_bytes(want)
+    r = subprocess.run([str(emu), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, EMU_ONE_KERNEL="1"))
+    assert r.returncode == 0, (name, level, r.stdout[-300:], r.stderr[-300:])
+    assert "greedy / lazy kernel" in r.stdout
+
+
+@pytest.mark.parametrize("level,name", [(0, "walk"), (4, "rows"), (6, "mixed"), (7, "runs"), (6, "noise")])
+def test_emulated_greedy_lazy_rounds_carry_their_state(emu_small_rounds, tmp_path, level, name):
+    """rounds of 2^14 positions: parse position, queued terms and bit writer carried from round to round in the D1State, the
+    search a round ahead with its own cursor, the answers of a round in the set of its parity, a lazy look at the position
+    behind a round's last"""
+    data = (INPUTS[name] * 20)[:50000]
+    want = ph.orc_deflate(data, level)
+    (tmp_path / "in").write_bytes(data)
+    (tmp_path / "want").write_bytes(want)
+    r = subprocess.run([str(emu_small_rounds), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0", "2"], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (name, level, r.stdout[-300:], r.stderr[-300:])
+    assert int(r.stdout.split(" in ")[1].split()[0]) >= 2, r.stdout
+
+
+@pytest.mark.parametrize("level,cuts", [(6, (100, 5000, 5001, 12000)), (1, (1, 2, 3, 300, 19999)), (7, (263, 264, 265, 266, 530)), (4, (7000,))])
+def test_emulated_greedy_lazy_pushes_give_the_one_shot_stream(emu_small_rounds, tmp_path, level, cuts):
+    """spng_deflate_resume_batch at levels 0-7 through the two kernels: a call per piece with `more` set -- only positions whose
+    look-ahead (and that of the position behind them) is complete are parsed --, the search cursor and the Adler sums of the
+    search workgroups kept between the calls: the bytes are those of one call over everything"""
+    data = INPUTS["walk"]
+    want = ph.orc_deflate(data, level)
+    (tmp_path / "in").write_bytes(data)
+    (tmp_path / "want").write_bytes(want)
+    r = subprocess.run([str(emu_small_rounds), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0", "2"] + [str(c) for c in cuts],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (cuts, r.stdout[-300:], r.stderr[-300:])
+
+
+def test_emulated_search_window_wraps_its_ring(emu, tmp_path):
+    """the search's window is a ring of 36864 positions in LDS: 90 KB in one chunk wrap it twice, with matches 32760 bytes back
+    (the far end of the window, read through the mirrored bytes behind the ring's end) -- level 9 records and level 6 answers"""
+    rng = np.random.default_rng(5)
+    blk = rng.integers(0, 256, 32760, dtype=np.uint8).tobytes()
+    far = blk + blk[:20000] + rng.integers(0, 256, 5000, dtype=np.uint8).tobytes() + blk[3000:30000] + blk[:100] * 50
+    for level in (9, 6):
+        want = ph.orc_deflate(far, level)
+        (tmp_path / "in").write_bytes(far)
+        (tmp_path / "want").write_bytes(want)
+        r = subprocess.run([str(emu), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0", "1"], capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, (level, r.stdout[-300:], r.stderr[-300:])
+
+
+def test_emulated_search_workgroup_of_sixteen_waves(tmp_path_factory, tmp_path):
+    """the product's shape -- an inserter and fifteen searchers per workgroup -- on the filtered rows of a small interlaced image
+    (the input on which the first GPU run of the kernel showed a store forwarded over the heads' read-back)"""
+    emu16 = build(tmp_path_factory.mktemp("emu_deflate16"), waves=16)
+    rng = np.random.default_rng(77)
+    w, h = 37, 23
+    storage = ((np.arange(w * h * 4) * 7 + rng.integers(0, 2, w * h * 4)) % 256).astype(np.uint8)
+    rows = ph.orc_filter(storage, w, h, 8, 4, True)
+    for level, chunks in ((9, "64"), (6, "5")):
+        want = ph.orc_deflate(rows, level)
+        (tmp_path / "in").write_bytes(rows)
+        (tmp_path / "want").write_bytes(want)
+        r = subprocess.run([str(emu16), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0", chunks], capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, (level, r.stdout[-300:], r.stderr[-300:])
 
 
 def test_emulated_level6_over_many_blocks(emu, tmp_path):
@@ -137,4 +215,4 @@ def test_prepared_copy_only_differs_where_it_says(tmp_path):
     changed = [l for l in difflib.unified_diff(src.splitlines(), out.splitlines(), lineterm="", n=0) if l[:1] in "+-" and l[:3] not in ("+++", "---")]
     assert 0 < len(changed) < 80, len(changed)
     for l in changed:
-        assert any(k in l for k in ("<<<", "(void)0", "s_waitcnt", "__builtin_amdgcn_fence", 'asm volatile("" ::: "memory")', "emu_bb", "g.bbase[q]", "b.nacc", "hipMemsetAsync", "dfl2_", "deflate_")), l
+        assert any(k in l for k in ("<<<", "(void)0", "s_waitcnt", "__builtin_amdgcn_fence", 'asm volatile("" ::: "memory")', "emu_bb", "g.bbase[q]", "b.nacc", "hipMemsetAsync", "dfl2_", "dfl3_", "deflate_")), l

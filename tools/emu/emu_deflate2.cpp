@@ -30,8 +30,8 @@ int main(int argc, char **argv)
     std::vector<uint8_t> dst(want.size() + 4096, 0xEE);
     src.resize(n + 64);                                          // (the kernels read keys a few bytes past positions they search)
 
-    if (level < 8) {
-        // levels 0-7: the greedy / lazy kernel, one wave per stream
+    if (level < 8 && getenv("EMU_ONE_KERNEL")) {
+        // levels 0-7, the one-kernel form (SPNG_DEFLATE_ONE_KERNEL): one wave per stream does everything
         std::vector<uint32_t> ring(65536, 0);
         DeflateJob j;
         memset(&j, 0, sizeof j);
@@ -48,6 +48,51 @@ int main(int argc, char **argv)
             return 1;
         }
         printf("ok: %llu -> %llu bytes (greedy / lazy kernel)\n", (unsigned long long)n, (unsigned long long)r1.written);
+        return 0;
+    }
+    if (level < 8) {
+        // levels 0-7 in rounds: dfl3_begin -> (dfl3_search_fast + dfl3_advance, dfl3_parse) per round, the two sets of answers
+        // alternating; `cut ...`: a call per piece with `more` set and the state kept, as spng_deflate_resume_batch drives it
+        const uint64_t RV = deflate3_round_positions();
+        std::vector<uint32_t> match[2] = {std::vector<uint32_t>(RV + 64, 0xDEADBEEF), std::vector<uint32_t>(RV + 64, 0xBEEFDEAD)};
+        std::vector<uint8_t> statebuf(deflate_state_bytes(), 0);
+        D3Stream st;
+        memset(&st, 0, sizeof st);
+        st.src = src.data(); st.dst = dst.data(); st.src_len = n; st.dst_cap = dst.size();
+        st.format = format == 1 ? SPNG_FORMAT_IOS : SPNG_FORMAT_ZLIB; st.level = level; st.image = 0; st.exponent = 15;
+        st.state = (D1State *)statebuf.data();
+        st.match[0] = match[0].data(); st.match[1] = match[1].data();
+        spng_result res;
+        memset(&res, 0xff, sizeof res);
+        const uint32_t chunk = (uint32_t)(((RV / cps + 63) / 64) * 64);
+        std::vector<uint64_t> cuts;
+        for (int a = 6; a < argc; ++a) cuts.push_back(strtoull(argv[a], nullptr, 10));
+        cuts.push_back(n);
+        uint32_t rounds = 0;
+        uint64_t spos = 0;
+        for (size_t call = 0; call < cuts.size(); ++call) {
+            st.src_len = cuts[call] < n ? cuts[call] : n;
+            st.more = call + 1 < cuts.size() ? 1 : 0;
+            const uint64_t E = deflate3_end(st.src_len, st.more != 0), span = E > spos ? E - spos : 0;
+            const uint32_t calls_rounds = span ? (uint32_t)((span + RV - 1) / RV) : 1;
+            emu::launch(1, 256, [&] { dfl3_begin_kernel(&st, 1); });
+            for (uint32_t r = 0; r < calls_rounds; ++r, ++rounds) {
+                const uint32_t par = r & 1;
+                emu::launch(cps, SPNG_D3_WAVES * 64, [&] { dfl3_search_fast_kernel(&st, cps, chunk, par); });
+                emu::launch(1, 256, [&] { dfl3_advance_kernel(&st, 1); });
+                emu::launch(1, 64, [&] { dfl3_parse_kernel(&st, &res, par); });
+            }
+            if (st.more && res.status != SPNG_NEED_MORE_INPUT) { printf("call %zu (more): status %d\n", call, res.status); return 1; }
+            if (st.more) { if (res.aux[1] != st.state->spos) { printf("call %zu: aux[1] %llu != spos %llu\n", call, (unsigned long long)res.aux[1], (unsigned long long)st.state->spos); return 1; } spos = res.aux[1]; }
+        }
+        if (res.status != SPNG_DONE || !st.state->done) { printf("status %d done %u after %u rounds\n", res.status, st.state->done, rounds); return 1; }
+        if (res.written != want.size() || memcmp(dst.data(), want.data(), want.size())) {
+            size_t k = 0;
+            while (k < want.size() && k < res.written && dst[k] == want[k]) ++k;
+            printf("stream differs: %llu bytes against %zu expected, first difference at %zu\n", (unsigned long long)res.written, want.size(), k);
+            return 1;
+        }
+        printf("ok: %llu -> %llu bytes in %u rounds (search + parse kernels)\n", (unsigned long long)n, (unsigned long long)res.written, rounds);
         return 0;
     }
     const uint64_t V = deflate2_vertices(n), B = V / 64 + 2;

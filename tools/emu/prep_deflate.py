@@ -30,6 +30,9 @@ def prepare(text: str, round_vertices: int = 0) -> str:
         old = "static constexpr uint32_t D2_RV = 1u << 21;"
         assert old in text
         text = text.replace(old, f"static constexpr uint32_t D2_RV = {round_vertices}u;")
+        old3 = "static constexpr uint32_t D3_RV = 1u << 21;"
+        assert old3 in text
+        text = text.replace(old3, f"static constexpr uint32_t D3_RV = {round_vertices}u;")
     out = text.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory")', "((void)0)")
     # "LDS serves a wave's operations in order": where the source only tells the COMPILER to keep an order (the keys of a group
     # of vertices before the next group's reads of the ring), the emulator's lanes have to meet
