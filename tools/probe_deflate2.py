@@ -24,6 +24,18 @@ if "random" in which:
     rnd = [torch.randint(0, 256, (64 << 20,), dtype=torch.uint8, device=s.tdev, generator=gen) for _ in range(8)]
     run("random 64 MiB", [rnd[i % 8] for i in range(N)])
     del rnd
+if "synth4k" in which:
+    # the filtered scanlines of the bench's synthetic 4096^2 RGBA8 images (BASELINE configs[1]'s rasters): what an encode at level 6 deflates
+    U = 4096 * (4096 * 4 + 1)
+    imgs = [s.to_device(synth.image(k, 4096, 4096).tobytes()) for k in range(4)]
+    rows4k = []
+    for im in imgs:
+        r = s.empty(U)
+        res = s.filter_batch([s.image_desc(None, r, im, 4096, 4096, 8, 4, False, rows_cap=U)])
+        rows4k.append(r)
+    torch.cuda.synchronize()
+    run("synthetic 4096^2 rows", [rows4k[i % 4] for i in range(N)])
+    del rows4k, imgs
 if "photo" in which:
     ph = [s.to_device(s.filter(synth.image(k, 1024, 1024).tobytes(), 1024, 1024, 8, 4, False)) for k in range(8)]
     run("photographic 1024^2 rows", [ph[i % 8] for i in range(N)])
