@@ -44,7 +44,9 @@ def encode_cpu_all_cores(rows: bytes, level: int, cores: int):
                       f"{r['wall_s']:.1f} s wall, {r['task_s']:.2f} s per slice (filter excluded)"}
 
 
-def run_encode(args, torch, dist, spng, s, rank, world):
+def run_encode(args, torch, dist, spng, s, rank, world, rasters_kind="random"):
+    """rasters_kind: "random" (BASELINE configs[3]: incompressible rasters) or "synthetic" (the structured images of the decode
+    headline, swift_png_amd.synth: what the level-6 inputs of configs[1] are made from)"""
     from swift_png_amd.distributed import shard
     lo, hi = shard(args.images, world, rank)
     weak = args.scaling == "weak" or world == 1
@@ -55,7 +57,11 @@ def run_encode(args, torch, dist, spng, s, rank, world):
     cap = s.lib.spng_deflate_bound(U)
     gen = torch.Generator(device=s.tdev)
     gen.manual_seed(1234 + rank)
-    rasters = [torch.randint(0, 256, (S,), dtype=torch.uint8, device=s.tdev, generator=gen) for _ in range(unique)]
+    if rasters_kind == "synthetic":
+        from swift_png_amd import synth
+        rasters = [s.to_device(synth.image(k, W, H).tobytes()) for k in range(unique)]
+    else:
+        rasters = [torch.randint(0, 256, (S,), dtype=torch.uint8, device=s.tdev, generator=gen) for _ in range(unique)]
     d_rows = torch.empty(n * U, dtype=torch.uint8, device=s.tdev)
     d_out = torch.empty(n * cap, dtype=torch.uint8, device=s.tdev)
     descs = (spng.ImageDesc * n)()
@@ -112,8 +118,8 @@ def run_encode(args, torch, dist, spng, s, rank, world):
                     "frac_of_hbm_peak": round((n * U + total_c) / (prof["deflate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)},
     }
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
-    # the two kernels of the level >= 8 rounds (both inside "deflate"): the chip-wide match search reads U, the one-wave-per-stream
-    # parse reads U again and writes C
+    # the two kernels of a round (both inside "deflate", at every level since round 5): the chip-wide match search reads U, the
+    # one-wave-per-stream parse reads U (levels 0-7: and the search's 4 bytes per position) and writes C
     kernels["deflate"]["search_ms"] = round(prof["dfl_search"], 3)
     kernels["deflate"]["parse_ms"] = round(prof["dfl_parse"], 3)
     out = {
@@ -121,8 +127,9 @@ def run_encode(args, torch, dist, spng, s, rank, world):
         "unit": "MPixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": f"{args.images} x 4096x4096 RGBA8 random rasters -> filter-select + DEFLATE level {args.level} "
-                               f"(spng_encode_batch); BASELINE configs[3]", "unique_images": unique,
+        "config": {"workload": f"{args.images} x 4096x4096 RGBA8 {rasters_kind} rasters -> filter-select + DEFLATE level {args.level} "
+                               f"(spng_encode_batch)" + ("; BASELINE configs[3]" if rasters_kind == "random" and args.level == 9 else ""),
+                   "unique_images": unique,
                    "compressed_ratio": round(n * U / total_c, 4)},
         "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": kernels[dom]["gbps"], "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None,

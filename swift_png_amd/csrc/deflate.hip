@@ -92,7 +92,11 @@ struct DLdsSearch {                              // the match search of the one-
     uint32_t head[(1 << HBITS) + 1];             // most recent position per bucket (low 32 bits); + a slot nobody reads
     uint32_t cslot[2][30 * 64];                  // full: per lane and half, the best run of every distance decade (distance << 16 | run)
 };
-struct DLdsTerms { uint32_t terms[2048]; };      // greedy / lazy: the queued terms (of their own: dfl3_parse_kernel has no search in it)
+struct DLdsTerms {                               // greedy / lazy: the queued terms (of their own: dfl3_parse_kernel has no search in it)
+    uint32_t terms[2][2048];                     // two blocks' worth: dfl3_parse_kernel's parser fills one while its writer emits the other
+    uint32_t cmd[2];                             // parser -> writer, per buffer: 0 free, else D3_CMD_* | terms
+    uint64_t fin_w;                              // the parse position a SAVE / NEED_MORE command carries
+};
 struct DLdsOld {                                 // the one-kernel full search (deflate_full_kernel)
     uint32_t batch[64 * 30];                     // the edge slots of the 64 vertices at hand
     // the full kernel's helper waves (forward pass): what wave 0 hands them per pass and per batch of 64 vertices
@@ -444,17 +448,18 @@ __device__ __forceinline__ uint64_t match_bits(const DLds &s, uint32_t rd, uint3
 }
 
 // Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), greedy / lazy form
-__device__ __attribute__((noinline)) Bits write_block(Bits b_, int count_, bool final_, int lane)
+__device__ __attribute__((noinline)) Bits write_block(Bits b_, int count_, bool final_, int lane, int tb_ = 0)
 {
     Bits b = uni_bits(b_);
     const int count = (int)UNI(count_);
     const bool final = UB(final_);
+    const uint32_t *terms = g_trm.terms[UNI(tb_)];
     DLds &s = g_lds;
     // DeflatorMatches.trees() (:138-159)
     for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     for (int i = lane; i < count; i += 64) {
-        const uint32_t t = g_trm.terms[i];
+        const uint32_t t = terms[i];
         atomicAdd(&s.freq[t & 0x1ff], 1u);
         atomicAdd(&s.freq[288 + (t >> 27)], 1u);
     }
@@ -469,7 +474,7 @@ __device__ __attribute__((noinline)) Bits write_block(Bits b_, int count_, bool 
         const int i = i0 + lane;
         uint64_t v = 0; uint32_t nb = 0;
         if (i < count) {
-            const uint32_t t = g_trm.terms[i];
+            const uint32_t t = terms[i];
             const uint32_t sym = t & 0x1ff;
             if (sym > 256) v = match_bits(s, sym & 0xff, (t >> 9) & 0x1f, t >> 27, (t >> 14) & 0x1fff, nb);
             else v = literal_bits(s, sym, nb);
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
     uint64_t w0 = 0, summed = 0;                               // where the parse goes on; positions below `summed` are in the sums already
     if (resumed) {
         w0 = uni64(st1->w); summed = uni64(st1->inserted); count = (int)UNI(st1->count);
-        for (int i = lane; i < count; i += 64) g_trm.terms[i] = st1->terms[i];
+        for (int i = lane; i < count; i += 64) g_trm.terms[0][i] = st1->terms[i];
         if (lane == 0) { accS = st1->adlerS; accI = st1->adlerI; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     }
@@ -763,7 +768,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                 if (!(unfilled() > (lazy ? 1 : 0))) { DPROF_END(2); DPROF_BEGIN(); b = uni_bits(write_block(b, count, false, lane)); count = 0; DPROF_END(3); DPROF_BEGIN(); }
                 const uint32_t run = at(mrunA, mrunB, t);
                 const uint32_t lit = at(litA, litB, t);
-                if (!run) { g_trm.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
+                if (!run) { g_trm.terms[0][count] = 0xf8000000u | lit; ++count; t += 1; continue; }
                 uint32_t use_run = run, use_dist = at(bdA, bdB, t);
                 uint32_t adv = run;
                 if (lazy) {
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                     // lazy match at a+1 (:293-299); it exists only if that position is still searched
                     const uint32_t lrun = (w + t + 1 < last_main) ? at(mrunA, mrunB, t + 1) : 0u;
                     if (lrun > run) {
-                        g_trm.terms[count] = 0xf8000000u | lit;
+                        g_trm.terms[0][count] = 0xf8000000u | lit;
                         ++count;
                         use_run = lrun; use_dist = at(bdA, bdB, t + 1);
                         adv = 1 + lrun;
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
                 }
                 // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
                 const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
-                g_trm.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
+                g_trm.terms[0][count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
                 ++count;
                 t += adv;
             }
@@ -793,7 +798,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
             uint32_t S = accS % 65521, I = accI % 65521;
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) { S += __shfl_xor(S, m, 64); I += __shfl_xor(I, m, 64); }
-            for (int i = lane; i < count; i += 64) st1->terms[i] = g_trm.terms[i];
+            for (int i = lane; i < count; i += 64) st1->terms[i] = g_trm.terms[0][i];
             if (lane == 0) {
                 st1->w = w; st1->inserted = inserted > summed ? inserted : summed; st1->acc = b.acc; st1->nacc = b.nacc; st1->total = b.total;
                 st1->overflow = b.overflow ? 1u : 0u; st1->count = (uint32_t)count; st1->started = 1;
@@ -808,7 +813,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(const DeflateJob *__restric
         // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
         for (uint64_t p = w; p < n; ++p) {
             if (!(unfilled() > 0)) { b = uni_bits(write_block(b, count, false, lane)); count = 0; }
-            g_trm.terms[count] = 0xf8000000u | UNI(in[p]);
+            g_trm.terms[0][count] = 0xf8000000u | UNI(in[p]);
             ++count;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1632,11 +1637,11 @@ __global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D
 // of a microsecond each, and with 13-bit bucket heads over a 32 K window a position of incompressible input walks ~4 foreign
 // bucket members to find nothing (10 GB/s with the whole chip on it).  Here a workgroup is a whole CU -- sixteen waves, 141 KB
 // of LDS -- and everything a hop touches lives in LDS:
-//   * `in`:   the input bytes of the last D3_R = 36864 positions (the 32 K window + 4 K of lead), a ring with its first 320
+//   * `in`:   the input bytes of the last D3_R = 34816 positions (the 32 K window + 2 K of lead), a ring with its first 320
 //             bytes mirrored behind its end so that a compare never wraps;
 //   * `link`: per position the distance to the previous position of its bucket (16 bits, 0 = none): no tags -- a candidate is
 //             verified against the input itself, four bytes at its ring slot;
-//   * `head`: 2^14 bucket heads (16 bits, positions mod 2^16; a head nobody touched for 2^16 positions aliases a young one and
+//   * `head`: 2^13 bucket heads (16 bits, positions mod 2^16; a head nobody touched for 2^16 positions aliases a young one and
 //             sends a walk into another bucket's chain -- positions only ever decrease along a walk and every candidate is
 //             verified, so that costs hops, never a candidate: the note at d3_insert).
 // Wave 0 stages the bytes (global -> LDS, three 256-byte steps in flight) and inserts, 64 positions at a time: when the 64
@@ -1649,12 +1654,14 @@ __global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D
 // per-wave area in global memory and from there, when the batch's total is known, to the pool in the same lane-major order as
 // before.  Levels 0-7 (FULL = false) leave one word per position instead: the first strictly longest run > 5 and its distance
 // (DeflatorWindow.match :145-208 as Stream.compress greedy / lazy asks it), for dfl3_parse_kernel.
-static constexpr uint32_t D3_R = 36864, D3_MIR = 320;           // ring positions (a multiple of 256), mirrored bytes
+// (121 KB: a search workgroup and ONE parse wave -- 38 KB -- share a CU, so that in batches of up to 256 streams the search of
+//  round r + 1 runs beside the parse of round r; 2^14 heads and 4 K of lead -- 144 KB -- measured the same on incompressible input)
+static constexpr uint32_t D3_R = 34816, D3_MIR = 320;           // ring positions (a multiple of 256), mirrored bytes
 #ifndef SPNG_D3_WAVES
 #define SPNG_D3_WAVES 16
 #endif
 #ifndef SPNG_D3_HBITS
-#define SPNG_D3_HBITS 14
+#define SPNG_D3_HBITS 13
 #endif
 struct D3Lds {
     union { uint8_t in[D3_R + D3_MIR]; uint32_t in32[(D3_R + D3_MIR) / 4]; };
@@ -1873,7 +1880,12 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
             const uint32_t cidx = idx >= acc ? idx - acc : idx + D3_R - acc;
             const uint32_t e = s.link[cidx];
             if (d3_u32(s, cidx) == key) {
-                const uint32_t run = d3_common_prefix(s, cidx, idx, lim);
+                // A run that does not exceed the longest one seen (FULL: of its decade) changes nothing -- only a strictly longer
+                // one is taken, and the goal lies above the longest (a run at the goal ends the walk) -- so the byte at that
+                // length is looked at first: one byte settles most candidates of a long chain.
+                const uint32_t have = FULL ? (dist_decade(acc) == cdec ? crun : 0u) : ext;
+                uint32_t run = 0;
+                if (!(have && (have >= lim || s.in[cidx + have] != s.in[idx + have]))) run = d3_common_prefix(s, cidx, idx, lim);
                 if (FULL) {
                     ext = run > ext ? run : ext;
                     const uint32_t dec = dist_decade(acc);
@@ -1997,11 +2009,19 @@ __global__ __launch_bounds__(SPNG_D3_WAVES * 64) void dfl3_search_fast_kernel(co
                            (uint32_t *)uni64((uint64_t)st.match[parity]));
 }
 
-__global__ __launch_bounds__(64) void dfl3_parse_kernel(const D3Stream *__restrict__ streams, spng_result *__restrict__ results, uint32_t parity)
+// Two waves per stream.  Wave 0, the parser, walks the answers and queues terms -- into one of two buffers; wave 1, the writer,
+// owns the bit writer: the stream's header, every block (symbol counts, the trees, the tables, the bits: write_block), the
+// trailer, the results.  A full buffer is handed over with a command word and the parser goes on in the other one: the walk of
+// block k + 1 runs beside the trees and bits of block k (one wave did them one after the other: at level 6 the blocks were 60 %
+// of a stream's time).  At the end of a round the parser keeps its position and the terms of the unfinished block in the
+// D1State, the writer its pending bits.
+enum : uint32_t { D3_CMD_BLOCK = 1u << 28, D3_CMD_FINAL = 2u << 28, D3_CMD_SAVE = 3u << 28, D3_CMD_MORE = 4u << 28, D3_CMD_MASK = 7u << 28 };
+
+__global__ __launch_bounds__(128) void dfl3_parse_kernel(const D3Stream *__restrict__ streams, spng_result *__restrict__ results, uint32_t parity)
 {
     DLds &s = g_lds;
     const D3Stream *sp = streams + blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = (int)UNI(threadIdx.x >> 6);
     D1State *state = (D1State *)uni64((uint64_t)sp->state);
     if (UNI(state->done)) return;
     const gbyte *in = (const gbyte *)uni64((uint64_t)sp->src);
@@ -2010,26 +2030,125 @@ __global__ __launch_bounds__(64) void dfl3_parse_kernel(const D3Stream *__restri
     const bool lazy = (int32_t)UNI(sp->level) >= 4;            // Stream.compress lazy (:268-323) from level 4 on
     const bool more = UNI(sp->more) != 0;                      // spng_deflate_resume_batch: the input goes on behind src_len
     const uint32_t image = UNI(sp->image);
-    const gword *match = (const gword *)uni64((uint64_t)sp->match[parity]);
-
-    for (int i = lane; i < OUTB / 4; i += 64) s.out32[i] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    Bits b = {uni64(state->acc), UNI(state->nacc), uni64(state->total), uni64(state->total), (gbyte *)uni64((uint64_t)sp->dst), uni64(sp->dst_cap),
-              UNI(state->overflow) != 0};
-    uint64_t w = uni64(state->w);
-    int count = (int)UNI(state->count);
     const uint64_t rb = uni64(state->rb), re = uni64(state->re);
     uint64_t E = d3_end(n, more);
     E = E < re ? re : E;
     if (n < 3 && more) {
         // (nothing can be decided yet: not even whether this will be a stored tail)
-        if (lane == 0) {
+        if (threadIdx.x == 0) {
             spng_result &res = results[image];
-            res.status = SPNG_NEED_MORE_INPUT; res.reserved = 0; res.written = b.total; res.consumed = w; res.aux[0] = w; res.aux[1] = uni64(state->spos);
+            res.status = SPNG_NEED_MORE_INPUT; res.reserved = 0; res.written = state->total; res.consumed = state->w; res.aux[0] = state->w; res.aux[1] = state->spos;
         }
         return;
     }
-    if (w == 0 && b.total == 0 && b.nacc == 0 && count == 0) {
+    // (what both waves need of the state is read before either of them writes to it)
+    const uint64_t w0 = uni64(state->w);
+    const uint32_t count0 = UNI(state->count);
+    if (threadIdx.x < 2) g_trm.cmd[threadIdx.x] = 0;
+    __syncthreads();
+
+    if (wave == 0) {
+        // ---- the parser
+        const gword *match = (const gword *)uni64((uint64_t)sp->match[parity]);
+        uint64_t w = w0;
+        int count = (int)count0;
+        uint32_t tb = 0;                                       // the buffer being filled
+        uint32_t *terms = g_trm.terms[0];
+        for (int i = lane; i < count; i += 64) terms[i] = state->terms[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        const int limit_terms = 2048;
+        auto unfilled = [&]() { return limit_terms - 1 - count; };
+        // hands the buffer's `count` terms to the writer and turns to the other buffer (once the writer has let go of it)
+        auto hand_over = [&](uint32_t cmd) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) __hip_atomic_store(&g_trm.cmd[tb], cmd | (uint32_t)count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            tb ^= 1; terms = g_trm.terms[tb]; count = 0;
+            SpinGuard guard;
+            while (__hip_atomic_load(&g_trm.cmd[tb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
+                __builtin_amdgcn_s_sleep(4);
+                guard.tick();
+            }
+        };
+        if (n >= 3) {
+            const uint64_t last_main = n - 4 + 1;              // positions 0 .. n-4 are searched
+            const uint64_t stop = re < last_main ? re : last_main; // tokens that start below `stop` are this round's
+            // the answers of 128 positions at a time (two per lane), fetched a batch ahead: a wave alone has nobody to hide a load behind
+            auto ask = [&](uint64_t p, uint32_t &m, uint32_t &lit) {
+                m = (p <= re && p < last_main) ? match[p - rb] : 0u;
+                lit = p < n ? (uint32_t)in[p] : 0u;
+            };
+            uint32_t nmA, nmB, nlA, nlB;
+            uint64_t asked = w;
+            ask(w + lane, nmA, nlA); ask(w + 64 + lane, nmB, nlB);
+            while (w < stop) {
+                uint32_t mA, mB, litA, litB;
+                if (asked == w) { mA = nmA; mB = nmB; litA = nlA; litB = nlB; }
+                else { ask(w + lane, mA, litA); ask(w + 64 + lane, mB, litB); }
+                asked = w + 128;                               // (the guess: the batch is used up to its end -- a run across it asks again)
+                ask(asked + lane, nmA, nlA); ask(asked + 64 + lane, nmB, nlB);
+                auto at = [&](uint32_t xa, uint32_t xb, uint32_t t) -> uint32_t {
+                    return t < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)xa, (int)t) : (uint32_t)__builtin_amdgcn_readlane((int)xb, (int)(t - 64));
+                };
+                // ---- the parse: Stream.compress greedy (:209-252) / lazy (:268-323) over these 128 answers
+                uint32_t t = 0;
+                while (t < 128 && w + t < stop) {
+                    if (!(unfilled() > (lazy ? 1 : 0))) hand_over(D3_CMD_BLOCK);
+                    const uint32_t m = at(mA, mB, t);
+                    const uint32_t lit = at(litA, litB, t);
+                    if (!m) { terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
+                    uint32_t use_run = m >> 16, use_dist = m & 0xffff;
+                    uint32_t adv = use_run;
+                    if (lazy) {
+                        // the answer for position w + t + 1 is needed: start the next batch there if it is not in this one
+                        if (t + 1 >= 128) break;
+                        // lazy match at a + 1 (:293-299); it exists only if that position is still searched
+                        const uint32_t lm = at(mA, mB, t + 1);
+                        if ((lm >> 16) > use_run) {
+                            terms[count] = 0xf8000000u | lit;
+                            ++count;
+                            use_run = lm >> 16; use_dist = lm & 0xffff;
+                            adv = 1 + use_run;
+                        }
+                    }
+                    // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
+                    const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
+                    terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
+                    ++count;
+                    t += adv;
+                }
+                w = uni64(w + t);
+            }
+        } else w = n;                                          // (a stored tail: the writer's)
+        if (re < E || more) {
+            // on with the next round / the next push: the unfinished block's terms and the position into the state
+            for (int i = lane; i < count; i += 64) state->terms[i] = terms[i];
+            if (lane == 0) {
+                state->w = w; state->count = (uint32_t)count;
+                if (re < E) { state->rb = re; state->re = re + D3_RV < E ? re + D3_RV : E; }
+                g_trm.fin_w = w;
+            }
+            count = 0;
+            hand_over(re < E ? D3_CMD_SAVE : D3_CMD_MORE);
+            return;
+        }
+        if (n >= 3) {
+            // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
+            for (uint64_t p = w; p < n; ++p) {
+                if (!(unfilled() > 0)) hand_over(D3_CMD_BLOCK);
+                terms[count] = 0xf8000000u | UNI(in[p]);
+                ++count;
+            }
+        }
+        hand_over(D3_CMD_FINAL);
+        return;
+    }
+
+    // ---- the writer
+    for (int i = lane; i < OUTB / 4; i += 64) s.out32[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    Bits b = {uni64(state->acc), UNI(state->nacc), uni64(state->total), uni64(state->total), (gbyte *)uni64((uint64_t)sp->dst), uni64(sp->dst_cap),
+              UNI(state->overflow) != 0};
+    if (w0 == 0 && b.total == 0 && b.nacc == 0 && count0 == 0) {
         // the stream's first round
         if (format == SPNG_FORMAT_ZLIB) {
             // StreamHeader.write (StreamHeader.swift:56-62)
@@ -2041,11 +2160,6 @@ __global__ __launch_bounds__(64) void dfl3_parse_kernel(const D3Stream *__restri
             put(s, b, 0x8b1f, 16, lane); put(s, b, 0x0008, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0xff00, 16, lane);
         }
     }
-    for (int i = lane; i < count; i += 64) g_trm.terms[i] = state->terms[i];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    const int limit_terms = 2048;
-    auto unfilled = [&]() { return limit_terms - 1 - count; };
-
     uint32_t tailS = 0, tailI = 0;
     if (n < 3) {
         // Stream.compressBlocks stored tail (:45-60, :417-434)
@@ -2054,90 +2168,37 @@ __global__ __launch_bounds__(64) void dfl3_parse_kernel(const D3Stream *__restri
         put(s, b, (uint32_t)n, 16, lane); put(s, b, ~(uint32_t)n & 0xffff, 16, lane);
         for (uint64_t k = 0; k < n; ++k) put(s, b, in[k], 8, lane);
         if ((uint64_t)lane < n) { tailS = in[lane]; tailI = (uint32_t)lane * in[lane]; }
-        w = n;
-    } else {
-        const uint64_t last_main = n - 4 + 1;                  // positions 0 .. n-4 are searched
-        const uint64_t stop = re < last_main ? re : last_main; // tokens that start below `stop` are this round's
-        // the answers of 128 positions at a time (two per lane), fetched a batch ahead: a wave alone has nobody to hide a load behind
-        auto ask = [&](uint64_t p, uint32_t &m, uint32_t &lit) {
-            m = (p <= re && p < last_main) ? match[p - rb] : 0u;
-            lit = p < n ? (uint32_t)in[p] : 0u;
-        };
-        uint32_t nmA, nmB, nlA, nlB;
-        uint64_t asked = w;
-        ask(w + lane, nmA, nlA); ask(w + 64 + lane, nmB, nlB);
-        while (w < stop) {
-            uint32_t mA, mB, litA, litB;
-            if (asked == w) { mA = nmA; mB = nmB; litA = nlA; litB = nlB; }
-            else { ask(w + lane, mA, litA); ask(w + 64 + lane, mB, litB); }
-            asked = w + 128;                                   // (the guess: the batch is used up to its end -- a run across it asks again)
-            ask(asked + lane, nmA, nlA); ask(asked + 64 + lane, nmB, nlB);
-            auto at = [&](uint32_t xa, uint32_t xb, uint32_t t) -> uint32_t {
-                return t < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)xa, (int)t) : (uint32_t)__builtin_amdgcn_readlane((int)xb, (int)(t - 64));
-            };
-            // ---- the parse: Stream.compress greedy (:209-252) / lazy (:268-323) over these 128 answers
-            uint32_t t = 0;
-            while (t < 128 && w + t < stop) {
-                if (!(unfilled() > (lazy ? 1 : 0))) { b = uni_bits(write_block(b, count, false, lane)); count = 0; }
-                const uint32_t m = at(mA, mB, t);
-                const uint32_t lit = at(litA, litB, t);
-                if (!m) { g_trm.terms[count] = 0xf8000000u | lit; ++count; t += 1; continue; }
-                uint32_t use_run = m >> 16, use_dist = m & 0xffff;
-                uint32_t adv = use_run;
-                if (lazy) {
-                    // the answer for position w + t + 1 is needed: start the next batch there if it is not in this one
-                    if (t + 1 >= 128) break;
-                    // lazy match at a + 1 (:293-299); it exists only if that position is still searched
-                    const uint32_t lm = at(mA, mB, t + 1);
-                    if ((lm >> 16) > use_run) {
-                        g_trm.terms[count] = 0xf8000000u | lit;
-                        ++count;
-                        use_run = lm >> 16; use_dist = lm & 0xffff;
-                        adv = 1 + use_run;
-                    }
-                }
-                // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
-                const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
-                g_trm.terms[count] = dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9;
-                ++count;
-                t += adv;
-            }
-            w = uni64(w + t);
-        }
     }
-    if (re < E) {
-        // on with the next round: whole bytes out, the rest into the state
-        drain(s, b, b.total, lane);
-        for (int i = lane; i < count; i += 64) state->terms[i] = g_trm.terms[i];
-        if (lane == 0) {
-            state->w = w; state->acc = b.acc; state->nacc = b.nacc; state->total = b.total; state->overflow = b.overflow ? 1u : 0u;
-            state->count = (uint32_t)count;
-            state->rb = re; state->re = re + D3_RV < E ? re + D3_RV : E;
+    uint32_t tb = 0, kind = 0;
+    for (;;) {
+        uint32_t c;
+        SpinGuard guard;
+        while ((c = __hip_atomic_load(&g_trm.cmd[tb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            guard.tick();
         }
-        return;
-    }
-    if (more) {
-        // on with the next push
-        drain(s, b, b.total, lane);
-        for (int i = lane; i < count; i += 64) state->terms[i] = g_trm.terms[i];
-        if (lane == 0) {
-            state->w = w; state->acc = b.acc; state->nacc = b.nacc; state->total = b.total; state->overflow = b.overflow ? 1u : 0u;
-            state->count = (uint32_t)count;
-            spng_result &res = results[image];
-            res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_NEED_MORE_INPUT; res.reserved = 0;
-            res.written = b.total; res.consumed = w; res.aux[0] = w; res.aux[1] = uni64(state->spos);
-        }
-        return;
-    }
-    if (n >= 3) {
-        // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342)
-        for (uint64_t p = w; p < n; ++p) {
-            if (!(unfilled() > 0)) { b = uni_bits(write_block(b, count, false, lane)); count = 0; }
-            g_trm.terms[count] = 0xf8000000u | UNI(in[p]);
-            ++count;
-        }
+        c = UNI(c);
+        kind = c & D3_CMD_MASK;
+        if (kind == D3_CMD_BLOCK || (kind == D3_CMD_FINAL && n >= 3))
+            b = uni_bits(write_block(b, (int)(c & 0xfffffu), kind == D3_CMD_FINAL, lane, (int)tb));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        b = uni_bits(write_block(b, count, true, lane));
+        if (lane == 0) __hip_atomic_store(&g_trm.cmd[tb], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tb ^= 1;
+        if (kind != D3_CMD_BLOCK) break;
+    }
+    if (kind != D3_CMD_FINAL) {
+        // on with the next round / the next push: whole bytes out, the rest into the state
+        drain(s, b, b.total, lane);
+        if (lane == 0) {
+            state->acc = b.acc; state->nacc = b.nacc; state->total = b.total; state->overflow = b.overflow ? 1u : 0u;
+            if (kind == D3_CMD_MORE) {
+                const uint64_t w = g_trm.fin_w;
+                spng_result &res = results[image];
+                res.status = b.overflow ? SPNG_E_OUTPUT_CAPACITY : SPNG_NEED_MORE_INPUT; res.reserved = 0;
+                res.written = b.total; res.consumed = w; res.aux[0] = w; res.aux[1] = state->spos;
+            }
+        }
+        return;
     }
     if (format == SPNG_FORMAT_ZLIB) {
         // Adler-32 from the sums the search kernel left (s1 = 1 + S, s2 = N + N * S - I)
@@ -2945,7 +3006,7 @@ hipError_t launch_deflate3_search(const D3Stream *d_streams, uint32_t count, uin
 hipError_t launch_deflate3_parse(const D3Stream *d_streams, uint32_t count, spng_result *d_results, uint32_t parity, hipStream_t stream)
 {
     if (!count) return hipSuccess;
-    dfl3_parse_kernel<<<count, 64, 0, stream>>>(d_streams, d_results, parity);
+    dfl3_parse_kernel<<<count, 128, 0, stream>>>(d_streams, d_results, parity);
     return hipGetLastError();
 }
 hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, uint32_t parity, hipStream_t stream)

@@ -80,7 +80,7 @@ int main(int argc, char **argv)
                 const uint32_t par = r & 1;
                 emu::launch(cps, SPNG_D3_WAVES * 64, [&] { dfl3_search_fast_kernel(&st, cps, chunk, par); });
                 emu::launch(1, 256, [&] { dfl3_advance_kernel(&st, 1); });
-                emu::launch(1, 64, [&] { dfl3_parse_kernel(&st, &res, par); });
+                emu::launch(1, 128, [&] { dfl3_parse_kernel(&st, &res, par); });
             }
             if (st.more && res.status != SPNG_NEED_MORE_INPUT) { printf("call %zu (more): status %d\n", call, res.status); return 1; }
             if (st.more) { if (res.aux[1] != st.state->spos) { printf("call %zu: aux[1] %llu != spos %llu\n", call, (unsigned long long)res.aux[1], (unsigned long long)st.state->spos); return 1; } spos = res.aux[1]; }
