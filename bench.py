@@ -224,10 +224,12 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
 
     pending = []
 
+    gather_on = [True]
+
     def step():
         for g in range(len(job.groups)):
             job.decode_group(g)
-            if do_gather:
+            if do_gather and gather_on[0]:
                 # the only exchange step of the path: this group's rasters -> rank 0 over xGMI, as one batch of
                 # point-to-point transfers that runs (on RCCL's stream) while the next group decodes
                 glo, ghi = job.groups[g]
@@ -267,6 +269,17 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
     dt = time.perf_counter() - t0
     prof = {k: s.profile_get(getattr(spng, "K_" + k.upper())) for k in STAGES}
     s.profile(False)
+    # N > 1: the same steps without the exchange, so that the line shows what the gather costs on top of the decode
+    dt_decode_only = None
+    if do_gather:
+        gather_on[0] = False
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_decode_only = time.perf_counter() - t0
+        gather_on[0] = True
 
     # parity of the whole batch: every slot equals its source raster, every status is DONE
     res = job.results()
@@ -284,6 +297,10 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    if dt_decode_only is not None:
+        t = torch.tensor([dt_decode_only], dtype=torch.float64, device=s.tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_decode_only = float(t.item())
     total_c = sum(C[k] for k in job.src)
     del ref, gathered, d_streams
     job.d_rows = job.d_out = job.dres = None                  # (the slabs go back to the allocator before the next workload)
@@ -295,7 +312,8 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
     alg = {"pinf_find": 0, "pinf_decode": total_c, "pinf_resolve": n * U,
            "inflate": 0 if fast == n else total_c + n * U, "unfilter": n * (U + S)}
     return {"dt": dt, "n": n, "weak": weak, "per_step_ms": per_step, "launches": launches, "alg": alg, "total_c": total_c, "U": U, "S": S,
-            "fast": fast, "gather": bool(do_gather), "gather_error": gather_error, "hi_lo": hi - lo,
+            "fast": fast, "gather": bool(do_gather), "gather_error": gather_error, "hi_lo": hi - lo, "dt_decode_only": dt_decode_only,
+            "groups": len(job.groups),
             "ratio": round(U * unique / sum(C), 3), "streams": streams, "images": images, "rows": rows}
 
 
@@ -496,6 +514,55 @@ def run_file_to_pixels(torch, spng, s, streams, images, n, steps):
             "bit_exact": True}
 
 
+def run_scanline_formats(torch, spng, s, n=256):
+    """The scanline kernels on the pixel sizes the headline does not touch: n x 4096^2 RGB8 (bpp 3: the most common PNG format) and
+    RGB16 (bpp 6) -- filter-select (spng_filter_batch) and defilter (spng_unfilter_batch) alone, each against the HBM roofline
+    (algorithmic bytes U + S per image and direction), the defiltered rasters equal to the sources."""
+    from swift_png_amd import synth
+    out = {}
+    for name, depth, ch in (("rgb8", 8, 3), ("rgb16", 16, 3)):
+        m = n if depth == 8 else n // 2
+        U = spng.inflated_size(W, H, depth, ch, False)
+        S = spng.storage_size(W, H, depth, ch)
+        unique = 4
+        base = [synth.image(500 + k, W, H) for k in range(unique)]
+        if depth == 8:
+            srcs = [s.to_device(im[..., :3].tobytes()) for im in base]
+        else:
+            import numpy as np
+            srcs = [s.to_device(np.repeat(im[..., :3], 2, axis=-1).tobytes()) for im in base]   # (big-endian samples v << 8 | v)
+        d_sto = torch.empty(m * S, dtype=torch.uint8, device=s.tdev)
+        for j in range(m):
+            d_sto[j * S:(j + 1) * S] = srcs[j % unique]
+        d_rows = torch.empty(m * U, dtype=torch.uint8, device=s.tdev)
+        d_back = torch.empty(m * S, dtype=torch.uint8, device=s.tdev)
+        fd = (spng.ImageDesc * m)()
+        ud = (spng.ImageDesc * m)()
+        for j in range(m):
+            fd[j] = spng.ImageDesc(None, 0, d_rows.data_ptr() + j * U, U, d_sto.data_ptr() + j * S, W, H, depth, ch, 0, 0, 0)
+            ud[j] = spng.ImageDesc(None, 0, d_rows.data_ptr() + j * U, U, d_back.data_ptr() + j * S, W, H, depth, ch, 0, 0, 0)
+        dres = s.empty(m * ctypes.sizeof(spng.Result))
+        assert s.lib.spng_filter_batch(s.ctx, fd, m, ctypes.c_void_p(dres.data_ptr()), None) == 0
+        assert s.lib.spng_unfilter_batch(s.ctx, ud, m, None, ctypes.c_void_p(dres.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(d_back, d_sto), f"{name}: defiltered rasters differ from their sources"
+        s.profile(True)
+        for _ in range(3):
+            assert s.lib.spng_filter_batch(s.ctx, fd, m, ctypes.c_void_p(dres.data_ptr()), None) == 0
+            assert s.lib.spng_unfilter_batch(s.ctx, ud, m, None, ctypes.c_void_p(dres.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        f_ms, u_ms = s.profile_get(spng.K_FILTER)[0] / 3, s.profile_get(spng.K_UNFILTER)[0] / 3
+        s.profile(False)
+        moved = m * (U + S)
+        out[name] = {"images": m, "algorithmic_bytes": moved,
+                     "unfilter": {"ms": round(u_ms, 3), "gbps": round(moved / (u_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(moved / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                     "filter": {"ms": round(f_ms, 3), "gbps": round(moved / (f_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(moved / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                     "bit_exact": True}
+        del d_sto, d_rows, d_back, srcs
+        torch.cuda.empty_cache()
+    return out
+
+
 def run_pixels_to_file(torch, spng, s, n, size, level=9):
     """Pixels -> file, the mirror of file_to_pixels (PNG.Image.init(packing:size:layout:) + compress): spng_pack_batch ([RGBA<UInt8>]
     -> storage of an rgb8 image: alpha dropped) -> spng_encode_batch (filter-select + DEFLATE at the reference's default level 9) ->
@@ -683,6 +750,18 @@ def main():
                                                "workload, not measured in this run)"} if d.get("traffic") else {})},
             "kernels": kernels,
         }
+        if world > 1:
+            # what the exchange costs: the same steps with and without it, and the floor of the gather itself -- every peer's share
+            # over its own xGMI link into rank 0 (7 links x ~153 GB/s per GPU both ways: ~76.5 GB/s per link and direction,
+            # MI355X_MICROARCH.md); with g groups per shard the last group's rasters cannot hide behind a decode
+            per_peer = m["hi_lo"] * m["S"]
+            floor_ms = per_peer / 76.5e9 * 1e3
+            out["multi"] = {"with_gather_mpixels_per_s": out["value"],
+                            "decode_only_mpixels_per_s": round(args.images * (world if weak else 1) * MPIX / (m["dt_decode_only"] / args.steps), 1) if m.get("dt_decode_only") else None,
+                            "decode_only_ms_per_step": round(m["dt_decode_only"] / args.steps * 1e3, 3) if m.get("dt_decode_only") else None,
+                            "groups_per_shard": m.get("groups"), "gathered_bytes_per_peer": per_peer,
+                            "xgmi_floor_ms_whole_share": round(floor_ms, 2), "xgmi_floor_ms_last_group": round(floor_ms / max(1, m.get("groups") or 1), 2),
+                            "link_gbps_assumed_per_direction": 76.5}
         if other:
             alt, mo = other
         if other and "error" in other[1]:
@@ -730,6 +809,7 @@ def main():
             leg("encode_level6", enc6)
 
             leg("pixels_to_file", lambda: run_pixels_to_file(torch, spng, s, 256, 1024))
+            leg("scanline_formats", lambda: run_scanline_formats(torch, spng, s, min(256, args.images)))
 
             def enc_photo():
                 from bench_encode import run_encode_photographic

@@ -42,7 +42,7 @@ K_LEX = 12
 K_PINF_FIND, K_PINF_DECODE, K_PINF_RESOLVE = 8, 9, 11
 K_DFL_SEARCH, K_DFL_PARSE = 13, 14
 CFG_INFLATE_MODE, CFG_SEGMENT_BYTES, CFG_TOKEN_BYTES, CFG_UNFILTER_PIECE_ROWS, CFG_INFLATE_OVERLAP, CFG_RESOLVE_PARTS = 0, 1, 2, 3, 4, 5
-CFG_DEFLATE_MODE, CFG_DEFLATE_BYTES = 6, 7
+CFG_DEFLATE_MODE, CFG_DEFLATE_BYTES, CFG_MULTI_GROUPS = 6, 7, 8
 DEFLATE_AUTO, DEFLATE_ONE_KERNEL = 0, 1
 OVERLAP_AUTO, OVERLAP_ALWAYS, OVERLAP_NEVER = 0, 1, 2
 INFLATE_AUTO, INFLATE_SERIAL = 0, 1

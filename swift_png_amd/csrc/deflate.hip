@@ -1868,36 +1868,50 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
         const bool inchunk = rel < c1r, live = inchunk && p < last_main;
         const uint32_t key = d3_u32(s, idx);
         const uint32_t lim = n - p < 258 ? (uint32_t)(n - p) : 258u;
-        // LZ77.DeflatorWindow.match (:132-212): the candidates of the key, most recent first
+        // LZ77.DeflatorWindow.match (:132-212): the candidates of the key, most recent first.  One loop, two kinds of step -- a
+        // hop to the next member of the bucket's chain, or eight more bytes of the candidate being compared -- so that a lane
+        // deep in a long compare does not hold the other 63 at its hop (nested, the compare loop inside the hop loop, a batch
+        // cost the SUM over its hops of the longest compare any lane made there: 20 x what the slowest lane alone needs).
         uint32_t d = live ? s.link[idx] : 0u, acc = 0;
         int rem = attempts;
         bool first = true;
         uint32_t ext = FULL ? 1u : 5u, bestd = 1;              // longest run seen (levels 0-7: it must exceed 5, and its distance)
         uint32_t cdec = 0xff, crun = 0, cdist = 0, cnt = 0;    // FULL: the decade at hand, its longest run and that run's distance; words so far
-        while (d) {
-            acc += d;
-            if (acc > wmask || (!first && acc >= wmask)) break;
-            const uint32_t cidx = idx >= acc ? idx - acc : idx + D3_R - acc;
-            const uint32_t e = s.link[cidx];
-            if (d3_u32(s, cidx) == key) {
+        bool cmp = false;                                       // a candidate is being compared:
+        uint32_t cq = 0, ci = 0, ce = 0;                        // its ring slot, the bytes known equal so far, its own link
+        auto hit = [&](uint32_t run, uint32_t e) {             // a candidate of the key with its run (0: known not to exceed the longest)
+            if (FULL) {
+                ext = run > ext ? run : ext;
+                const uint32_t dec = dist_decade(acc);
+                if (dec != cdec) {
+                    if (cdec != 0xff) { tw[cnt * 64 + (uint32_t)lane] = (uint32_t)lane << 24 | cdist << 9 | crun; ++cnt; }
+                    cdec = dec; crun = run; cdist = acc;
+                } else if (run > crun) { crun = run; cdist = acc; }    // (strict: the closest candidate of a decade stays)
+            } else if (ext < run) { ext = run; bestd = acc; }          // (the first strictly longest run wins, :145-208)
+            first = false; rem -= 1;
+            d = (rem > 0 && goal > (int)run) ? e : 0u;
+        };
+        while (d != 0 || cmp) {
+            if (cmp) {
+                const uint32_t left = lim - ci;                 // (> 0)
+                uint64_t x = d3_u64(s, cq + ci) ^ d3_u64(s, idx + ci);
+                if (left < 8) x &= (1ull << (8 * left)) - 1;    // (bytes behind the limit do not count)
+                if (x) { cmp = false; hit(ci + ((uint32_t)__builtin_ctzll(x) >> 3), ce); }
+                else if (left <= 8) { cmp = false; hit(lim, ce); }
+                else ci += 8;
+            } else {
+                acc += d;
+                if (acc > wmask || (!first && acc >= wmask)) { d = 0; continue; }
+                const uint32_t cidx = idx >= acc ? idx - acc : idx + D3_R - acc;
+                const uint32_t e = s.link[cidx];
+                if (d3_u32(s, cidx) != key) { d = e; continue; }
                 // A run that does not exceed the longest one seen (FULL: of its decade) changes nothing -- only a strictly longer
                 // one is taken, and the goal lies above the longest (a run at the goal ends the walk) -- so the byte at that
                 // length is looked at first: one byte settles most candidates of a long chain.
                 const uint32_t have = FULL ? (dist_decade(acc) == cdec ? crun : 0u) : ext;
-                uint32_t run = 0;
-                if (!(have && (have >= lim || s.in[cidx + have] != s.in[idx + have]))) run = d3_common_prefix(s, cidx, idx, lim);
-                if (FULL) {
-                    ext = run > ext ? run : ext;
-                    const uint32_t dec = dist_decade(acc);
-                    if (dec != cdec) {
-                        if (cdec != 0xff) { tw[cnt * 64 + (uint32_t)lane] = (uint32_t)lane << 24 | cdist << 9 | crun; ++cnt; }
-                        cdec = dec; crun = run; cdist = acc;
-                    } else if (run > crun) { crun = run; cdist = acc; }    // (strict: the closest candidate of a decade stays)
-                } else if (ext < run) { ext = run; bestd = acc; }          // (the first strictly longest run wins, :145-208)
-                first = false; rem -= 1;
-                if (!(rem > 0 && goal > (int)run)) break;
+                if (have && (have >= lim || s.in[cidx + have] != s.in[idx + have])) hit(0, e);
+                else { cmp = true; cq = cidx; ci = 4; ce = e; }   // (the key: four bytes are equal already)
             }
-            d = e;
         }
         const uint64_t v = (warm + p0r - rb) + (uint32_t)lane;  // round coordinates
         if (!FULL) {

@@ -57,6 +57,23 @@ def test_decode_batch_multi(gpu, n_ctx):
         # without a gather list the rasters stay where they are
         res2 = spng.decode_batch_multi(sessions, descs)
         assert [r.status for r in res2] == [r.status for r in res]
+        # a shard in one call (SPNG_CFG_MULTI_GROUPS = 1) and in two (the default where rasters leave: a group's copies on the
+        # context's copy stream beside the next group's decode): the same rasters arrive, the caller's device stays current
+        import torch
+        for groups in (1, 2):
+            for s in sessions:
+                s.configure(spng.CFG_MULTI_GROUPS, groups)
+            for g in gbuf:
+                g.zero_()
+            before = torch.cuda.current_device()
+            res3 = spng.decode_batch_multi(sessions, descs, gather)
+            assert torch.cuda.current_device() == before
+            assert [r.status for r in res3] == [r.status for r in res]
+            for k, (st_o, storage_o) in enumerate(want):
+                if st_o == 0:
+                    assert bytes(gbuf[k].cpu().numpy()) == storage_o.tobytes(), ("gathered", groups, k)
+        for s in sessions:
+            s.configure(spng.CFG_MULTI_GROUPS, 0)
     finally:
         for s in sessions[1:]:
             s.close()
