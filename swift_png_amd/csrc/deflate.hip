@@ -80,7 +80,7 @@ struct DLds {                                    // what every kernel of this fi
     union { uint8_t out[OUTB]; uint32_t out32[OUTB / 4]; };   // output staging ring; bytes not written yet are zero
     // Huffman scratch (one tree at a time)
     uint16_t order[288];                         // symbols by descending frequency (stable)
-    uint64_t heap[288];                          // heap entries: key << 32 | node id; afterwards ancestor / depth of every node
+    alignas(16) uint64_t heap[292];              // heap entries (1-based): key << 32 | node id; afterwards ancestor / depth of every node
     uint16_t parent[576];                        // tree nodes: leaves 0..m-1 (in `order`), then merges
     uint32_t depthcnt[300];                      // leaves per depth
     uint8_t  ll[288], dl[32], ml[19];            // code lengths
@@ -208,31 +208,50 @@ __device__ __attribute__((noinline)) void build_tree(const uint32_t *freq_, int 
         // heap over symbols.reversed(): ascending frequency; leaf k = order[m-1-k].  Entries are
         // (key << 32 | node) so that one LDS access moves an element; the sifts carry the moving
         // element in registers (same comparisons, same outcome as the reference's swap form).
-        uint64_t *hp = s.heap;                                 // 1-based: hp[i - 1]
+        // 1-based in place (hp[i], slot 0 unused): the children of i are one aligned 16-byte read at 2 i, its grandchildren
+        // two at 4 i -- asked for together, so that a sift-down takes two levels per LDS round trip (this lane is alone with the
+        // latency of every dependent read: the replay was ~0.9 M cycles of a 2047-term block's ~1.5 M).  A sift only ever
+        // writes the slot it has just left, never one it has read ahead.
+        uint64_t *hp = s.heap;
         int count = m, nodes = m;
-        for (int k = 0; k < m; ++k) hp[k] = (uint64_t)freq[s.order[m - 1 - k]] << 32 | (uint32_t)k;
+        for (int k = 0; k < m; ++k) hp[k + 1] = (uint64_t)freq[s.order[m - 1 - k]] << 32 | (uint32_t)k;
+        struct alignas(16) u64x2 { uint64_t x, y; };           // (one aligned 16-byte read)
+        constexpr int HCAP = 290;                              // (reads ahead of the heap's end are clamped into the array and not looked at)
         auto sift_down = [&](int i, uint64_t moving) {         // Heap.siftDown / lowest(below:) (:94-135)
             const uint32_t key = (uint32_t)(moving >> 32);
             for (;;) {
-                const int l = i << 1, r = l + 1;
+                const int l = i << 1;
                 if (l > count) break;
-                const uint64_t el = hp[l - 1], er = r <= count ? hp[r - 1] : ~0ull;
-                const bool right = r <= count && (uint32_t)(er >> 32) < (uint32_t)(el >> 32);
-                const uint64_t ec = right ? er : el;
+                const int g = l << 1;                          // first grandchild
+                const u64x2 c = *(const u64x2 *)&hp[l < HCAP - 2 ? l : HCAP - 2];
+                const u64x2 g0 = *(const u64x2 *)&hp[g < HCAP - 4 ? g : HCAP - 4], g1 = *(const u64x2 *)&hp[g < HCAP - 4 ? g + 2 : HCAP - 2];
+                // level 1
+                const int r = l + 1;
+                const bool right = r <= count && (uint32_t)(c.y >> 32) < (uint32_t)(c.x >> 32);
+                const uint64_t ec = right ? c.y : c.x;
                 if (!((uint32_t)(ec >> 32) < key)) break;
-                hp[i - 1] = ec;
+                hp[i] = ec;
                 i = right ? r : l;
+                // level 2: the children of the child taken
+                const int l2 = i << 1, r2 = l2 + 1;
+                if (l2 > count) break;
+                const uint64_t el2 = right ? g1.x : g0.x, er2 = right ? g1.y : g0.y;
+                const bool right2 = r2 <= count && (uint32_t)(er2 >> 32) < (uint32_t)(el2 >> 32);
+                const uint64_t ec2 = right2 ? er2 : el2;
+                if (!((uint32_t)(ec2 >> 32) < key)) break;
+                hp[i] = ec2;
+                i = right2 ? r2 : l2;
             }
-            hp[i - 1] = moving;
+            hp[i] = moving;
         };
         auto dequeue = [&]() -> uint64_t {                     // Heap.dequeue (:149-164)
-            const uint64_t top = hp[0];
-            const uint64_t moving = hp[count - 1];
+            const uint64_t top = hp[1];
+            const uint64_t moving = hp[count];
             --count;
             if (count > 0) sift_down(1, moving);
             return top;
         };
-        for (int i = count >> 1; i >= 1; --i) sift_down(i, hp[i - 1]);   // heapify (:166-175)
+        for (int i = count >> 1; i >= 1; --i) sift_down(i, hp[i]);   // heapify (:166-175)
         uint16_t root = 0;
         for (;;) {
             const uint64_t e1 = dequeue();
@@ -241,15 +260,18 @@ __device__ __attribute__((noinline)) void build_tree(const uint32_t *freq_, int 
             const uint16_t id = (uint16_t)nodes++;
             s.parent[(uint16_t)e1] = id; s.parent[(uint16_t)e2] = id;
             const uint32_t key = (uint32_t)(e1 >> 32) + (uint32_t)(e2 >> 32);
-            int i = ++count;                                   // enqueue + siftUp (:137-147, :113-123)
+            int i = ++count;                                   // enqueue + siftUp (:137-147, :113-123): parent and grandparent read together
             for (;;) {
-                const int p = i >> 1;
+                const int p = i >> 1, pp = i >> 2;
                 if (p < 1) break;
-                const uint64_t ep = hp[p - 1];
+                const uint64_t ep = hp[p], epp = hp[pp < 1 ? 1 : pp];
                 if (!(key < (uint32_t)(ep >> 32))) break;
-                hp[i - 1] = ep; i = p;
+                hp[i] = ep; i = p;
+                if (pp < 1) break;
+                if (!(key < (uint32_t)(epp >> 32))) break;
+                hp[i] = epp; i = pp;
             }
-            hp[i - 1] = (uint64_t)key << 32 | id;
+            hp[i] = (uint64_t)key << 32 | id;
         }
         s.parent[root] = root;                                 // (root == 2 m - 2: the last merge)
     }
@@ -1641,9 +1663,8 @@ __global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D
 //             bytes mirrored behind its end so that a compare never wraps;
 //   * `link`: per position the distance to the previous position of its bucket (16 bits, 0 = none): no tags -- a candidate is
 //             verified against the input itself, four bytes at its ring slot;
-//   * `head`: 2^13 bucket heads (16 bits, positions mod 2^16; a head nobody touched for 2^16 positions aliases a young one and
-//             sends a walk into another bucket's chain -- positions only ever decrease along a walk and every candidate is
-//             verified, so that costs hops, never a candidate: the note at d3_insert).
+//   * `head`: 2^13 bucket heads (16 bits, positions mod 2^16; the inserter moves heads that fell out of the window to a fixed
+//             distance behind the present every 2^14 positions, so that none ever aliases a young one: the note in its loop).
 // Wave 0 stages the bytes (global -> LDS, three 256-byte steps in flight) and inserts, 64 positions at a time: when the 64
 // buckets are all different -- what a read-back of the heads tells -- a batch costs three LDS round trips; the radix match over
 // the hash bits is the slow path.  The other fifteen waves (and wave 0 once it is done) claim batches of 64 positions behind
@@ -1657,6 +1678,7 @@ __global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D
 // (121 KB: a search workgroup and ONE parse wave -- 38 KB -- share a CU, so that in batches of up to 256 streams the search of
 //  round r + 1 runs beside the parse of round r; 2^14 heads and 4 K of lead -- 144 KB -- measured the same on incompressible input)
 static constexpr uint32_t D3_R = 34816, D3_MIR = 320;           // ring positions (a multiple of 256), mirrored bytes
+static constexpr uint32_t D3_FAR = 40000;                       // where a head too old for the window is kept (+ 2^14 between two sweeps: < 2^16)
 #ifndef SPNG_D3_WAVES
 #define SPNG_D3_WAVES 16
 #endif
@@ -1669,7 +1691,19 @@ struct D3Lds {
     uint16_t head[(1u << SPNG_D3_HBITS) + 64];                  // (+ a spare slot for idle lanes)
     uint32_t cur[SPNG_D3_WAVES];                                // the batch each wave is at (~0: none any more)
     uint32_t staged, inserted, next, pad;                       // positions (relative to the warm-up's first) below which bytes / links stand; batches claimed
+#ifdef SPNG_D3_PROF
+    unsigned long long prof[16];                                // tuning builds: cycles / counts of the phases, summed over the waves
+#endif
 };
+#ifdef SPNG_D3_PROF
+#define D3P_T0() const unsigned long long d3p_t0 = __builtin_readcyclecounter()
+#define D3P_ADD(k) do { if (lane == 0) atomicAdd(&s.prof[k], __builtin_readcyclecounter() - d3p_t0); } while (0)
+#define D3P_CNT(k, v) do { if (lane == 0) atomicAdd(&s.prof[k], (unsigned long long)(v)); } while (0)
+#else
+#define D3P_T0() ((void)0)
+#define D3P_ADD(k) ((void)0)
+#define D3P_CNT(k, v) ((void)0)
+#endif
 __shared__ __attribute__((aligned(16))) D3Lds g_d3;
 
 // four / eight input bytes at ring offset `off` (any alignment; the mirror makes them contiguous)
@@ -1702,10 +1736,8 @@ __device__ __forceinline__ uint32_t d3_common_prefix(const D3Lds &s, uint32_t q,
 
 // Hash insertion of 64 positions (LZ77.DeflatorWindow.update, :78-128) with heads and links in LDS.  rel: the batch's first
 // position relative to the warm-up's first, idx: its ring slot.  A position's link is the distance to the previous position of
-// its bucket, 0 when that is 32768 or more away.  Heads are positions mod 2^16: a head older than 2^16 positions reads as a
-// young one and its link leads into another bucket's chain.  Harmless: along a walk positions only decrease, every candidate is
-// compared with the key itself, and had the bucket a member inside the window the head would be that member -- a stray link
-// can only stand where the true chain has ended.
+// its bucket, 0 when that is 32768 or more away (heads are positions mod 2^16; the inserter's sweep keeps old ones from
+// aliasing young ones).  A candidate is compared with the key itself: a bucket's chain holds other keys too.
 // (the emulator runs a wave's lanes one after another between two wave builtins: where the hardware's "every lane reads, then
 //  every lane writes" is relied on, its lanes have to meet; the hardware serves a wave's LDS operations in order as they are)
 #ifdef SPNG_EMU
@@ -1769,9 +1801,13 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
     const uint32_t stage_end = (c1r + 336 + 255) & ~255u;      // bytes staged in all (a batch looks 258 + 8 bytes ahead, + a dword of slack)
     const uint64_t last_main = n - 4 + 1;                      // positions 0 .. n-4 are searched
     const uint32_t nbatches = (c1r - c0r + 63) / 64;
-    for (uint32_t i = threadIdx.x; i < (1u << SPNG_D3_HBITS) + 64; i += SPNG_D3_WAVES * 64) s.head[i] = 32768;   // (2^15 behind position 0: no link)
+    for (uint32_t i = threadIdx.x; i < (1u << SPNG_D3_HBITS) + 64; i += SPNG_D3_WAVES * 64) s.head[i] = (uint16_t)(0u - D3_FAR);   // (far behind position 0: no link)
     if (threadIdx.x < SPNG_D3_WAVES) s.cur[threadIdx.x] = threadIdx.x == 0 ? ~0u : 0u;
     if (threadIdx.x == 0) { s.staged = 0; s.inserted = 0; s.next = 0; }
+#ifdef SPNG_D3_PROF
+    if (threadIdx.x < 16) s.prof[threadIdx.x] = 0;
+    const unsigned long long d3p_start = __builtin_readcyclecounter();
+#endif
     __syncthreads();
 
     if (wave == 0) {
@@ -1802,6 +1838,7 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
         // is x + D3_R's, and a batch looks back 32767 positions
         auto stage_step = [&]() {
             {
+                D3P_T0();
                 SpinGuard guard;
                 while (staged + 256 > c0r + 64u * smin + (D3_R - 32768)) {
                     uint32_t v = (uint32_t)lane < SPNG_D3_WAVES ? __hip_atomic_load(&s.cur[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
@@ -1813,6 +1850,7 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
                     __builtin_amdgcn_s_sleep(4);
                     guard.tick();
                 }
+                D3P_ADD(0);
                 put_step(sidx, q0);
                 staged += 256; sidx = sidx + 256 >= D3_R ? 0 : sidx + 256;
                 q0 = q1; q1 = q2; q2 = q3; q3 = fetch(fetched); fetched += 256;
@@ -1822,8 +1860,21 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
         };
         uint32_t key_next = 0;
         for (uint32_t i = 0; i < c1r; i += 256) {
+            if (i && (i & 16383) == 0) {
+                // Heads are positions mod 2^16: one that nobody has touched for 2^16 positions would read as a young one, and its
+                // link would send every walk that meets it down the chain of whatever stands there -- thousands of hops where
+                // that is a long run of one byte (measured: the chunks that cost 30 x the others).  So every 2^14 positions the
+                // heads older than the window are moved to D3_FAR behind the present: they stay "far" for ever, and a link is
+                // exactly the distance to the bucket's previous member, or none.
+                for (uint32_t k = (uint32_t)lane; k < (1u << SPNG_D3_HBITS); k += 64) {
+                    const uint32_t age = (i - s.head[k]) & 0xffffu;
+                    if (age >= 32768u) s.head[k] = (uint16_t)(i - D3_FAR);
+                }
+                D3_MEET();
+            }
             if (staged < stage_end) stage_step();              // the step behind this quad's positions: their keys reach three bytes into it
             if (i == 0) key_next = d3_u32(s, (uint32_t)lane);
+            D3P_T0();
 #pragma unroll 1
             for (uint32_t k = 0; k < 256 && i + k < c1r; k += 64) {
                 const uint32_t rel = i + k;
@@ -1834,6 +1885,7 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
                 pm = pm + 64 >= 65521 ? pm + 64 - 65521 : pm + 64;
             }
             accI %= 65521;                                     // (four products < 2^24 each on top of a reduced sum)
+            D3P_ADD(1);
             const uint32_t done = i + 256 < c1r ? i + 256 : c1r;
             if (lane == 0) __hip_atomic_store(&s.inserted, done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -1856,63 +1908,70 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
         const uint32_t p0r = c0r + 64u * b, upto = p0r + 64 < c1r ? p0r + 64 : c1r;
         const uint32_t ahead = p0r + 336 < stage_end ? p0r + 336 : stage_end;
         {
+            D3P_T0();
             SpinGuard guard;
             while (__hip_atomic_load(&s.inserted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < upto ||
                    __hip_atomic_load(&s.staged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < ahead) {
                 __builtin_amdgcn_s_sleep(8);
                 guard.tick();
             }
+            D3P_ADD(2);
         }
+        D3P_T0();
+        uint32_t p_hops = 0, p_cmp = 0;
         const uint32_t rel = p0r + (uint32_t)lane, idx0 = UNI(p0r % D3_R) + (uint32_t)lane, idx = idx0 >= D3_R ? idx0 - D3_R : idx0;
         const uint64_t p = warm + rel;
         const bool inchunk = rel < c1r, live = inchunk && p < last_main;
         const uint32_t key = d3_u32(s, idx);
         const uint32_t lim = n - p < 258 ? (uint32_t)(n - p) : 258u;
-        // LZ77.DeflatorWindow.match (:132-212): the candidates of the key, most recent first.  One loop, two kinds of step -- a
-        // hop to the next member of the bucket's chain, or eight more bytes of the candidate being compared -- so that a lane
-        // deep in a long compare does not hold the other 63 at its hop (nested, the compare loop inside the hop loop, a batch
-        // cost the SUM over its hops of the longest compare any lane made there: 20 x what the slowest lane alone needs).
+        // LZ77.DeflatorWindow.match (:132-212): the candidates of the key, most recent first
         uint32_t d = live ? s.link[idx] : 0u, acc = 0;
         int rem = attempts;
         bool first = true;
         uint32_t ext = FULL ? 1u : 5u, bestd = 1;              // longest run seen (levels 0-7: it must exceed 5, and its distance)
         uint32_t cdec = 0xff, crun = 0, cdist = 0, cnt = 0;    // FULL: the decade at hand, its longest run and that run's distance; words so far
-        bool cmp = false;                                       // a candidate is being compared:
-        uint32_t cq = 0, ci = 0, ce = 0;                        // its ring slot, the bytes known equal so far, its own link
-        auto hit = [&](uint32_t run, uint32_t e) {             // a candidate of the key with its run (0: known not to exceed the longest)
-            if (FULL) {
-                ext = run > ext ? run : ext;
-                const uint32_t dec = dist_decade(acc);
-                if (dec != cdec) {
-                    if (cdec != 0xff) { tw[cnt * 64 + (uint32_t)lane] = (uint32_t)lane << 24 | cdist << 9 | crun; ++cnt; }
-                    cdec = dec; crun = run; cdist = acc;
-                } else if (run > crun) { crun = run; cdist = acc; }    // (strict: the closest candidate of a decade stays)
-            } else if (ext < run) { ext = run; bestd = acc; }          // (the first strictly longest run wins, :145-208)
-            first = false; rem -= 1;
-            d = (rem > 0 && goal > (int)run) ? e : 0u;
-        };
-        while (d != 0 || cmp) {
-            if (cmp) {
-                const uint32_t left = lim - ci;                 // (> 0)
-                uint64_t x = d3_u64(s, cq + ci) ^ d3_u64(s, idx + ci);
-                if (left < 8) x &= (1ull << (8 * left)) - 1;    // (bytes behind the limit do not count)
-                if (x) { cmp = false; hit(ci + ((uint32_t)__builtin_ctzll(x) >> 3), ce); }
-                else if (left <= 8) { cmp = false; hit(lim, ce); }
-                else ci += 8;
-            } else {
-                acc += d;
-                if (acc > wmask || (!first && acc >= wmask)) { d = 0; continue; }
-                const uint32_t cidx = idx >= acc ? idx - acc : idx + D3_R - acc;
-                const uint32_t e = s.link[cidx];
-                if (d3_u32(s, cidx) != key) { d = e; continue; }
+        while (d) {
+#ifdef SPNG_D3_PROF
+            p_hops += 1;
+#endif
+            acc += d;
+            if (acc > wmask || (!first && acc >= wmask)) break;
+            const uint32_t cidx = idx >= acc ? idx - acc : idx + D3_R - acc;
+            const uint32_t e = s.link[cidx];
+            if (d3_u32(s, cidx) == key) {
                 // A run that does not exceed the longest one seen (FULL: of its decade) changes nothing -- only a strictly longer
                 // one is taken, and the goal lies above the longest (a run at the goal ends the walk) -- so the byte at that
                 // length is looked at first: one byte settles most candidates of a long chain.
                 const uint32_t have = FULL ? (dist_decade(acc) == cdec ? crun : 0u) : ext;
-                if (have && (have >= lim || s.in[cidx + have] != s.in[idx + have])) hit(0, e);
-                else { cmp = true; cq = cidx; ci = 4; ce = e; }   // (the key: four bytes are equal already)
+                uint32_t run = 0;
+                if (!(have && (have >= lim || s.in[cidx + have] != s.in[idx + have]))) {
+                    run = d3_common_prefix(s, cidx, idx, lim);
+#ifdef SPNG_D3_PROF
+                    p_cmp += run / 8 + 1;
+#endif
+                }
+                if (FULL) {
+                    ext = run > ext ? run : ext;
+                    const uint32_t dec = dist_decade(acc);
+                    if (dec != cdec) {
+                        if (cdec != 0xff) { tw[cnt * 64 + (uint32_t)lane] = (uint32_t)lane << 24 | cdist << 9 | crun; ++cnt; }
+                        cdec = dec; crun = run; cdist = acc;
+                    } else if (run > crun) { crun = run; cdist = acc; }    // (strict: the closest candidate of a decade stays)
+                } else if (ext < run) { ext = run; bestd = acc; }          // (the first strictly longest run wins, :145-208)
+                first = false; rem -= 1;
+                if (!(rem > 0 && goal > (int)run)) break;
             }
+            d = e;
         }
+        D3P_ADD(3);
+#ifdef SPNG_D3_PROF
+        {
+            uint32_t mh = p_hops, mc = p_cmp;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { const uint32_t a = (uint32_t)__shfl_xor((int)mh, m, 64), b2 = (uint32_t)__shfl_xor((int)mc, m, 64); mh = a > mh ? a : mh; mc = b2 > mc ? b2 : mc; }
+            D3P_CNT(4, 1); D3P_CNT(5, mh); D3P_CNT(6, mc);
+        }
+#endif
         const uint64_t v = (warm + p0r - rb) + (uint32_t)lane;  // round coordinates
         if (!FULL) {
             if (inchunk) match[v] = ext > 5 ? ext << 16 | bestd : 0u;
@@ -1939,6 +1998,12 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
         }
     }
     if (lane == 0) __hip_atomic_store(&s.cur[wave], ~0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef SPNG_D3_PROF
+    __syncthreads();
+    if (threadIdx.x == 0 && (blockIdx.x & 63) == 0)
+        printf("d3 prof wg %u (%u positions, %u batches): total %llu kcyc; inserter: throttle wait %llu insert %llu; searchers (sum of 16 waves): wait %llu walk %llu kcyc; batches %llu, max-lane hops %llu, compare steps %llu\n",
+               blockIdx.x, c1r - c0r, nbatches, (__builtin_readcyclecounter() - d3p_start) >> 10, s.prof[0] >> 10, s.prof[1] >> 10, s.prof[2] >> 10, s.prof[3] >> 10, s.prof[4], s.prof[5], s.prof[6]);
+#endif
 }
 
 __global__ __launch_bounds__(SPNG_D3_WAVES * 64) void dfl3_search_kernel(const D2Stream *__restrict__ streams, uint32_t cps, uint32_t chunk_len, uint32_t *__restrict__ pool,
@@ -2072,16 +2137,26 @@ __global__ __launch_bounds__(128) void dfl3_parse_kernel(const D3Stream *__restr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
         const int limit_terms = 2048;
         auto unfilled = [&]() { return limit_terms - 1 - count; };
+#ifdef SPNG_D3_PROF
+        unsigned long long pwait = 0, pblocks = 0;
+        const unsigned long long pstart = __builtin_readcyclecounter();
+#endif
         // hands the buffer's `count` terms to the writer and turns to the other buffer (once the writer has let go of it)
         auto hand_over = [&](uint32_t cmd) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             if (lane == 0) __hip_atomic_store(&g_trm.cmd[tb], cmd | (uint32_t)count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             tb ^= 1; terms = g_trm.terms[tb]; count = 0;
+#ifdef SPNG_D3_PROF
+            const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
             SpinGuard guard;
             while (__hip_atomic_load(&g_trm.cmd[tb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) {
                 __builtin_amdgcn_s_sleep(4);
                 guard.tick();
             }
+#ifdef SPNG_D3_PROF
+            pwait += __builtin_readcyclecounter() - t0; pblocks += 1;
+#endif
         };
         if (n >= 3) {
             const uint64_t last_main = n - 4 + 1;              // positions 0 .. n-4 are searched
@@ -2143,6 +2218,10 @@ __global__ __launch_bounds__(128) void dfl3_parse_kernel(const D3Stream *__restr
             }
             count = 0;
             hand_over(re < E ? D3_CMD_SAVE : D3_CMD_MORE);
+#ifdef SPNG_D3_PROF
+            if (lane == 0 && blockIdx.x == 0) printf("d3 parse prof (round from %llu): parser total %llu kcyc, of it waiting for the writer %llu kcyc; %llu blocks\n",
+                                                     (unsigned long long)rb, (__builtin_readcyclecounter() - pstart) >> 10, pwait >> 10, pblocks);
+#endif
             return;
         }
         if (n >= 3) {
@@ -2184,13 +2263,23 @@ __global__ __launch_bounds__(128) void dfl3_parse_kernel(const D3Stream *__restr
         if ((uint64_t)lane < n) { tailS = in[lane]; tailI = (uint32_t)lane * in[lane]; }
     }
     uint32_t tb = 0, kind = 0;
+#ifdef SPNG_D3_PROF
+    unsigned long long wwait = 0;
+    const unsigned long long wstart = __builtin_readcyclecounter();
+#endif
     for (;;) {
         uint32_t c;
+#ifdef SPNG_D3_PROF
+        const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
         SpinGuard guard;
         while ((c = __hip_atomic_load(&g_trm.cmd[tb], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) {
             __builtin_amdgcn_s_sleep(4);
             guard.tick();
         }
+#ifdef SPNG_D3_PROF
+        wwait += __builtin_readcyclecounter() - t0;
+#endif
         c = UNI(c);
         kind = c & D3_CMD_MASK;
         if (kind == D3_CMD_BLOCK || (kind == D3_CMD_FINAL && n >= 3))
@@ -2200,6 +2289,10 @@ __global__ __launch_bounds__(128) void dfl3_parse_kernel(const D3Stream *__restr
         tb ^= 1;
         if (kind != D3_CMD_BLOCK) break;
     }
+#ifdef SPNG_D3_PROF
+    if (lane == 0 && blockIdx.x == 0) printf("d3 parse prof (round from %llu): writer total %llu kcyc, of it waiting for the parser %llu kcyc\n",
+                                             (unsigned long long)rb, (__builtin_readcyclecounter() - wstart) >> 10, wwait >> 10);
+#endif
     if (kind != D3_CMD_FINAL) {
         // on with the next round / the next push: whole bytes out, the rest into the state
         drain(s, b, b.total, lane);
