@@ -618,41 +618,6 @@ __device__ __forceinline__ void insert_batch(uint32_t *head, const gbyte *in, ui
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 }
 
-// The same with 16-bit heads (the search kernel's: half the LDS, three workgroups per CU): a head is its position mod 2^16.
-// A bucket nobody entered for 2^16 positions or more then reads as a small distance to a position that is not of this bucket.
-// So that a walk notices, the tag of a link is the TOP sixteen bits of the hash here -- the thirteen bucket bits and three
-// more: a link whose tag names another bucket is no link, the chain ends there (chain_walk1).  (A stale head that happens to
-// point into its own bucket -- one in 2^13 -- is a genuine earlier member of the chain: harmless.)  Heads start 2^15 behind the
-// first position.
-__device__ __forceinline__ void insert_batch16(uint16_t *head, const gbyte *in, uint64_t n, gword *ring, uint64_t inserted, uint32_t key,
-                                               uint32_t &accS, uint32_t &accI, int lane, bool sum)
-{
-    const uint64_t p = inserted + lane;
-    const bool live = p + 4 <= n;                              // the last three positions never start a match
-    if (p < n && sum) {                                        // Adler-32 accumulators
-        const uint32_t byte = key & 0xff;
-        accS += byte;
-        accI = (accI + (uint32_t)(p % 65521) * byte) % 65521;
-    }
-    const uint32_t mix = key * 0x9E3779B1u;
-    const uint32_t h = mix >> (32 - HBITS);
-    const uint32_t tag = mix >> 16;                            // (tag >> 3 == h)
-    unsigned long long same = __ballot(live);
-#pragma unroll
-    for (int k = 0; k < HBITS; ++k) {
-        const unsigned long long bk = __ballot((h >> k) & 1);
-        same &= (h >> k) & 1 ? bk : ~bk;
-    }
-    const unsigned long long lower = (1ull << lane) - 1;
-    const unsigned long long below = same & lower, above = same & ~lower & ~(1ull << lane);
-    uint32_t d = live ? ((uint32_t)p - (uint32_t)head[h]) & 0xffffu : 0u;
-    if (below) d = (uint32_t)lane - (uint32_t)(63 - __clzll((long long)below));
-    const uint32_t dist = d <= 32767 ? d : 0u;
-    if (p < n) ring[p & 65535] = dist | tag << 16;
-    head[live && !above ? h : 1u << HBITS] = (uint16_t)p;      // (idle lanes: the spare slot)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-}
-
 #ifdef SPNG_DEFLATE_PROF
 // full kernel: cycles per phase, kept in LDS so that the non-inlined passes can add to them
 __shared__ uint64_t g_prof[12];
@@ -1443,9 +1408,9 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
 // (2047, 4095, ... 2^21 - 1: LZ77.DeflatorMatches.swift:229): nothing about them has to wait for the parse.  So a batch now
 // goes through in ROUNDS of up to 2^21 vertices per stream (the small blocks of a stream's start together, then one block at
 // the cap per round), each round two launches:
-//   * dfl2_search_kernel -- every stream's round cut into chunks, a 4-wave workgroup per chunk: wave 0 inserts (the hash
-//     heads in LDS, the 64 K links of the workgroup's ring in HBM; 32 KiB of warm-up in front of the chunk), then joins the
-//     other three, which take 64 positions at a time behind it, walk the chains and leave, per position, the longest run
+//   * the search kernel (round 4: dfl2_search_kernel, links in HBM; round 5: dfl3_search_kernel below, the window in LDS) --
+//     every stream's round cut into chunks, a workgroup per chunk: wave 0 inserts (32 KiB of warm-up in front of the chunk),
+//     the others take 64 positions at a time behind it, walk the chains and leave, per position, the longest run
 //     seen and its candidates -- ONE packed word each (position-in-batch, distance, run), only for positions that have any:
 //     a batch of 64 positions takes what it needs from a pool shared by all streams.  Incompressible input leaves no words.
 //   * dfl2_parse_kernel -- one wave per stream, 38 KB of LDS (four per CU): the skip rule of runs > 100 (which vertices lose
@@ -1459,17 +1424,6 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
 static constexpr uint32_t D2_RV = 1u << 21;                     // vertices per stream and round
 static constexpr uint32_t D2_PCOLS = 64, D2_PSTRIDE = 65;       // offer table: lengths 3 .. 66, rows padded against bank conflicts
 __shared__ uint32_t g_ptab[66 * D2_PSTRIDE];                    // (parse kernel only; two rows of padding: a group of three vertices is read blind)
-#ifndef SPNG_D2_WAVES
-#define SPNG_D2_WAVES 4          // waves of a search workgroup: one of them inserts first.  4 waves = 47 KB of LDS = three per CU
-#endif                           // (2 waves, five per CU, more inserters: measured 30 % slower -- profiles/r04_probe_deflate2d.log)
-struct D2ALds {                                                 // (search kernel only)
-    uint16_t head[(1 << HBITS) + 2];                            // (16-bit: insert_batch16)
-    uint32_t cslot[SPNG_D2_WAVES][30 * 64];                     // per wave: per lane, the best run of every distance decade
-    uint64_t inserted;                                          // positions < inserted are in the window (published by wave 0)
-    uint32_t next;                                              // batches claimed
-};
-__shared__ __attribute__((aligned(16))) D2ALds g_a;
-
 __host__ __device__ inline uint64_t d2_round_end(uint64_t pos, uint32_t limit, uint64_t n, bool more = false)
 {
     // the blocks of a round: as many whole blocks from `pos` on as fit D2_RV vertices (at least one).  more: the input goes on
@@ -1514,148 +1468,10 @@ uint32_t deflate2_rounds(uint64_t n)
 uint64_t deflate_state_bytes() { return ((sizeof(D1State) > sizeof(D2State) ? sizeof(D1State) : sizeof(D2State)) + 255) & ~(uint64_t)255; }
 uint64_t deflate2_vertices(uint64_t n) { return ((n < D2_RV ? n : D2_RV) + 63) / 64 * 64 + 128; }
 
-// LZ77.DeflatorWindow.match (:132-212) for one position per lane (chain_walk2 without its second half: here the latency of a
-// hop is hidden by the other waves of the CU).  Links come from the workgroup's ring, which another wave writes: L1-bypassing loads.
-__device__ __forceinline__ uint32_t ring_load(const gword *ring, uint64_t at)
-{
-    return __hip_atomic_load((const uint32_t *)(ring + (at & 65535)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <class F>
-__device__ __forceinline__ void chain_walk1(const gbyte *in, const gword *ring, uint64_t n, uint64_t p, bool live, uint32_t key, uint32_t wmask,
-                                            int attempts, int goal, F &&hit)
-{
-    uint32_t tag = 0, d = 0, acc = 0;
-    int rem = attempts;
-    bool first = true;
-    if (live) { const uint32_t m = ring_load(ring, p); tag = m >> 16; d = m & 0xffff; }
-    const uint32_t lim = n - p < 258 ? (uint32_t)(n - p) : 258u;
-    while (d) {
-        bool go = true;
-        acc += d;
-        if (acc > wmask || (!first && acc >= wmask)) go = false;
-        uint32_t e = 0, k = 0;
-        if (go) { e = ring_load(ring, p - acc); k = load32(in + p - acc); }
-        if (go && (e >> 19) != (tag >> 3)) go = false;          // (not of this bucket: a stale head led here, insert_batch16)
-        if (go && (e >> 16) == tag && k == key) {
-            const uint32_t run = common_prefix(in, p - acc, p, lim);
-            hit(acc, run);
-            first = false; rem -= 1;
-            if (!(rem > 0 && goal > (int)run)) go = false;
-        }
-        d = go ? e & 0xffff : 0u;
-    }
-}
-
-__global__ __launch_bounds__(SPNG_D2_WAVES * 64) void dfl2_search_kernel(const D2Stream *__restrict__ streams, uint32_t cps, uint32_t chunk_len, uint32_t *__restrict__ pool,
-                                                          unsigned long long *__restrict__ pool_next, uint64_t pool_cap, uint32_t *__restrict__ rings, uint32_t parity)
-{
-    D2ALds &s = g_a;
-    const int lane = threadIdx.x & 63, wave = (int)UNI(threadIdx.x >> 6);
-    const D2Stream &st = streams[blockIdx.x / cps];
-    D2State *state = (D2State *)uni64((uint64_t)st.state);
-    if (UNI(state->done) || UNI(state->fail)) return;
-    // (the search's own cursor: this round may be a round ahead of the one the parse kernel is at)
-    const uint64_t n = uni64(st.src_len), rb = uni64(state->srb), re = uni64(state->sre);
-    const uint64_t c0 = rb + (uint64_t)(blockIdx.x % cps) * chunk_len, c1 = c0 + chunk_len < re ? c0 + chunk_len : re;
-    if (c0 >= re || n < 3) return;
-    const gbyte *in = (const gbyte *)uni64((uint64_t)st.src);
-    gword *ring = (gword *)(rings + (uint64_t)blockIdx.x * 65536);
-    const int lv = (int)UNI(st.level) > 13 ? 13 : (int)UNI(st.level);
-    // DeflatorSearch.init(level:) (:13-35), full rows
-    const int attempts = lv == 8 ? 14 : lv == 9 ? 20 : lv == 10 ? 30 : lv == 11 ? 60 : lv == 12 ? 100 : 0x7fffffff;
-    const int goal = lv == 8 ? 20 : lv == 9 ? 32 : lv == 10 ? 50 : lv == 11 ? 80 : lv == 12 ? 133 : 258;
-    const uint32_t wmask = (1u << UNI(st.exponent)) - 1;
-    const uint64_t last_main = n - 4 + 1;                      // positions 0 .. n-4 are searched
-    const uint32_t nbatches = (uint32_t)((c1 - c0 + 63) / 64);
-
-    const uint64_t warm = (c0 >= 32768 ? c0 - 32768 : 0) & ~(uint64_t)63;
-    for (int i = threadIdx.x; i <= (1 << HBITS); i += SPNG_D2_WAVES * 64) s.head[i] = (uint16_t)(warm - 32768);     // (2^15 behind the first position: no link)
-    if (threadIdx.x == 0) { s.inserted = warm; s.next = 0; }
-    __syncthreads();
-
-    if (wave == 0) {
-        // ---- the inserter: everything from the warm-up on, never more than 16 K positions ahead of the batches claimed
-        uint32_t accS = 0, accI = 0;
-        uint64_t inserted = warm;
-        uint32_t key_next = load_key(in, n, inserted + lane);
-        uint32_t since = 0;
-        while (inserted < c1) {
-            SpinGuard guard;
-            while (inserted >= c0 + 64ull * __hip_atomic_load(&s.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 16384) {
-                __builtin_amdgcn_s_sleep(4);
-                guard.tick();
-            }
-            const uint32_t key = key_next;
-            key_next = load_key(in, n, inserted + 64 + lane);
-            insert_batch16(s.head, in, n, ring, inserted, key, accS, accI, lane, inserted + lane >= c0 && inserted + lane < c1);   // (sums: this chunk's bytes only)
-            inserted = uni64(inserted + 64);
-            if (++since == 4 || inserted >= c1) {
-                since = 0;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the links are in memory before anybody is told
-                if (lane == 0) __hip_atomic_store(&s.inserted, inserted, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        // Adler-32 sums of the chunk (MRC32.swift:26-50 in the closed form of inflate.hip), added to the stream's
-        uint32_t S = accS % 65521, I = accI % 65521;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { S += __shfl_xor(S, m, 64); I += __shfl_xor(I, m, 64); }
-        if (lane == 0) { atomicAdd(&state->adlerS, S % 65521); atomicAdd(&state->adlerI, I % 65521); }
-    }
-    // ---- the searchers: 64 positions at a time
-    uint32_t *cs = s.cslot[wave];
-    for (;;) {
-        uint32_t b = 0;
-        if (lane == 0) b = atomicAdd(&s.next, 1u);
-        b = UNI(b);
-        if (b >= nbatches) break;
-        const uint64_t p0 = c0 + 64ull * b, upto = p0 + 64 < c1 ? p0 + 64 : c1;
-        {
-            SpinGuard guard;
-            while (__hip_atomic_load(&s.inserted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < upto) {
-                __builtin_amdgcn_s_sleep(2);
-                guard.tick();
-            }
-        }
-        const uint64_t p = p0 + lane;
-        const bool inchunk = p < c1, live = inchunk && p < last_main;
-        const uint32_t key = live ? load32(in + p) : 0u;
-        uint32_t ext = 1, mask = 0;                             // (a decade's slot holds something only where its bit is set: nothing to clear)
-        chain_walk1(in, ring, n, p, live, key, wmask, attempts, goal, [&](uint32_t dist, uint32_t run) {
-            ext = run > ext ? run : ext;
-            const uint32_t dec = dist_decade(dist);
-            uint32_t *slot = &cs[dec * 64 + lane];
-            if (!((mask >> dec) & 1) || run > (*slot & 0xffff)) *slot = dist << 16 | run;   // (strict: the closest candidate of a decade stays, DeflatorMatches.set(edge:) :183-194)
-            mask |= 1u << dec;
-        });
-        // ---- the batch's record: per position candidates << 9 | longest run; the words where the pool has room
-        const uint32_t cnt = (uint32_t)__popc(mask);
-        uint32_t T;
-        const uint32_t pre = wave_excl_scan(cnt, T, lane);
-        uint32_t mr = ext;
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mr, m, 64); mr = o > mr ? o : mr; }
-        unsigned long long base = 0;
-        if (T && lane == 0) base = atomicAdd(pool_next, (unsigned long long)T);
-        base = uni64(base);
-        const bool ok = base + T <= pool_cap;
-        if (!ok && lane == 0) atomicOr(&state->fail, 1u);
-        const uint64_t v = p - rb;
-        if (inchunk) (parity ? st.vinfo2 : st.vinfo)[v] = (uint16_t)(cnt << 9 | ext);
-        if (lane == 0) { (parity ? st.bbase2 : st.bbase)[v >> 6] = base; (parity ? st.bwords2 : st.bwords)[v >> 6] = T | mr << 16; }
-        if (ok) {
-            uint32_t k = 0;
-            for (uint32_t m = mask; m; m &= m - 1, ++k) {
-                const uint32_t sl = cs[(uint32_t)(__ffs((int)m) - 1) * 64 + lane];
-                pool[base + pre + k] = (uint32_t)lane << 24 | (sl >> 16) << 9 | (sl & 0x1ff);
-            }
-        }
-    }
-}
-
 // =====================================================================================================================
 // round 5: the search with its window in LDS (every level)
 // =====================================================================================================================
-// dfl2_search_kernel above hops through HBM: a link is a 4-byte word in a 256 KiB ring per workgroup, a hop two dependent loads
+// Round 4's search kernel (dfl2_search_kernel, gone) hopped through HBM: a link is a 4-byte word in a 256 KiB ring per workgroup, a hop two dependent loads
 // of a microsecond each, and with 13-bit bucket heads over a 32 K window a position of incompressible input walks ~4 foreign
 // bucket members to find nothing (10 GB/s with the whole chip on it).  Here a workgroup is a whole CU -- sixteen waves, 141 KB
 // of LDS -- and everything a hop touches lives in LDS:
@@ -1785,7 +1601,7 @@ __device__ __forceinline__ void d3_insert(D3Lds &s, uint32_t rel, uint32_t idx, 
 }
 
 // One chunk [c0, c1) of a stream's positions on one workgroup.  rb: the round's first position (records are kept in round
-// coordinates); extra: the last `extra` positions are searched but not summed (the next chunk's: a lazy parse looks one ahead).  FULL: vinfo / bbase / bwords / pool as dfl2_search_kernel; else match[position - rb] = run << 16 | distance
+// coordinates); extra: the last `extra` positions are searched but not summed (the next chunk's: a lazy parse looks one ahead).  FULL: vinfo / bbase / bwords / pool (what dfl2_parse_kernel reads); else match[position - rb] = run << 16 | distance
 // (0: no run > 5).  temp: SPNG_D3_WAVES x 30 x 64 words of global scratch of this workgroup (FULL).
 template <bool FULL>
 __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uint64_t rb, uint64_t c0, uint64_t c1, uint32_t extra, int attempts, int goal, uint32_t wmask,

@@ -120,13 +120,18 @@ def test_deflate_kernel_resources():
     for v in full:
         assert v["private_segment_fixed_size"] <= 64 and v["vgpr_spill_count"] <= 10     # (40 bytes today, outside the passes' inner loops)
         assert v["group_segment_fixed_size"] <= 81920           # (the helper-wave form: 76 KiB, one workgroup of four waves per stream)
-    # the two kernels of a level >= 8 round: three 4-wave search workgroups per CU, four parse waves per CU --
-    # all 1024 streams of BASELINE configs[3] resident
-    search = [v for k, v in table.items() if "dfl2_search_kernel" in k]
+    # the kernels of a round.  The search workgroup (every level) is a whole CU's worth of waves with its window in
+    # LDS -- and must leave room for ONE level >= 8 parse wave beside it (batches of <= 256 streams: the search of round r + 1 runs
+    # beside the parse of round r); four parse workgroups per CU at either kind of level: all 1024 streams of BASELINE configs[3]
+    # resident
+    search = [v for k, v in table.items() if "dfl3_search_kernel" in k or "dfl3_search_fast_kernel" in k]
     parse = [v for k, v in table.items() if "dfl2_parse_kernel" in k]
-    assert len(search) == 1 and len(parse) == 1
-    assert search[0]["group_segment_fixed_size"] <= 53248 and search[0]["private_segment_fixed_size"] == 0 and search[0]["vgpr_count"] <= 128
+    parse3 = [v for k, v in table.items() if "dfl3_parse_kernel" in k]
+    assert len(search) == 2 and len(parse) == 1 and len(parse3) == 1
+    for v in search:
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 128 and v["max_flat_workgroup_size"] == 1024
+        assert v["group_segment_fixed_size"] + parse[0]["group_segment_fixed_size"] <= 163840
     # (scratch: 384 bytes, the by-value argument structs of the non-inlined passes at their call sites -- a few per block -- and
     #  callee-saved registers; nothing inside the passes' loops)
     assert parse[0]["group_segment_fixed_size"] <= 40960 and parse[0]["private_segment_fixed_size"] <= 512 and parse[0]["max_flat_workgroup_size"] == 64
-
+    assert parse3[0]["group_segment_fixed_size"] <= 40960 and parse3[0]["private_segment_fixed_size"] <= 64 and parse3[0]["max_flat_workgroup_size"] == 128

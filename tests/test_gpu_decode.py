@@ -517,6 +517,38 @@ def test_deflate_vs_oracle(gpu, level):
         assert zlib.decompress(got if fmt == 0 else want) == data if fmt == 0 else True
 
 
+def test_deflate_one_kernel_mode(gpu):
+    """SPNG_CFG_DEFLATE_MODE = SPNG_DEFLATE_ONE_KERNEL: a wave per stream does everything (`deflate_kernel` at levels 0-7,
+    `deflate_full_kernel` from 8 on) -- the form the rounds of search + parse kernels fall back to when their records find no
+    memory: the same bytes"""
+    s = gpu.load()
+    payloads = _deflate_payloads()
+    try:
+        s.configure(gpu.CFG_DEFLATE_MODE, gpu.DEFLATE_ONE_KERNEL)
+        for level in (1, 6, 9):
+            for kind in ("text", "noise", "sparse", "ramp"):
+                assert s.deflate(payloads[kind], level) == ph.orc_deflate(payloads[kind], level), (kind, level)
+    finally:
+        s.configure(gpu.CFG_DEFLATE_MODE, gpu.DEFLATE_AUTO)
+
+
+@pytest.mark.parametrize("level", [1, 6])
+def test_deflate_greedy_lazy_over_several_rounds(gpu, level):
+    """levels 0-7 go through in rounds of 2^21 positions (search of round r + 1 beside the parse of round r, parse position, queued
+    terms and bit writer kept in the D1State, a lazy look at the position behind a round's last): 5 MiB of mixed content -- three
+    rounds, matches across the round boundaries, windows that wrap the search's LDS ring many times -- equal the oracle's stream"""
+    s = gpu.load()
+    rng = np.random.default_rng(31 + level)
+    a = rng.integers(-3, 4, 3 << 20).astype(np.int16)
+    a[rng.random(len(a)) < 0.6] = 0
+    part = a.astype(np.uint8).tobytes()
+    blk = rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
+    data = part[:(2 << 20) - 1000] + blk + blk + bytes(70000) + part[(2 << 20):] + (b"abcdefgh" * 40000) + blk[:20000] + rng.integers(0, 256, 400000, dtype=np.uint8).tobytes()
+    data = data + part[:(5 << 20) - len(data)] if len(data) < (5 << 20) else data[:5 << 20]
+    assert len(data) > 2 * (1 << 21)
+    assert s.deflate(data, level) == ph.orc_deflate(data, level)
+
+
 def test_deflate_block_boundaries(gpu):
     """Blocks close after 2047 terms (greedy) / 2046-2047 (lazy); literal-only inputs around the
     boundary exercise the term-buffer guards (DeflatorBuffers.Stream.swift:219,277)."""

@@ -1,4 +1,4 @@
-// emu_deflate2.cpp -- TEST INFRASTRUCTURE: runs the level >= 8 kernels of csrc/deflate.hip (dfl2_begin / dfl2_search /
+// emu_deflate2.cpp -- TEST INFRASTRUCTURE: runs the round kernels of csrc/deflate.hip (dfl2_begin / dfl3_search /
 // dfl2_advance / dfl2_parse) on the CPU (tools/emu/hip/hip_runtime.h) over one stream, round by round and with the two sets
 // of candidate records alternating the way api.hip drives them, and compares the bytes with the expected stream (the oracle's).
 // Built and used by tests/test_emu_deflate.py from a copy of deflate.hip whose launchers and `s_waitcnt` lines are blanked
