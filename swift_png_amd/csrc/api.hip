@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -1788,30 +1789,45 @@ static int32_t deflate_fast_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
     if (first >= last) return SPNG_DONE;
     const size_t nfast = last - first;
     const uint64_t RV = deflate3_round_positions();
+    // one-shot streams first: their blocks are written side by side (dfl4_*); streams that arrive in pieces keep their state
+    // between calls and take the two-wave parse (dfl3_parse_kernel)
+    std::stable_partition(sorted.begin() + first, sorted.begin() + last, [](const DeflateJob &j) { return !j.state && !j.more; });
+    size_t mid = first;
+    while (mid < last && !sorted[mid].state && !sorted[mid].more) ++mid;
     // what a call searches: from where the previous push left the search (plan_aux) to the end the input allows
     auto span_of = [&](const DeflateJob &j) -> uint64_t {
         const uint64_t from = j.state ? j.plan_aux : 0, E = deflate3_end(j.src_len, j.more != 0);
         return E > from ? E - from : 0;
     };
-    auto scratch_of = [&](const DeflateJob &j) -> uint64_t {
-        const uint64_t sp = span_of(j), V = (sp < RV ? sp : RV) + 64;
-        return 2 * ((4 * V + 255) & ~255ull);
+    auto round_of = [&](const DeflateJob &j) -> uint64_t { const uint64_t sp = span_of(j); return sp < RV ? sp : RV; };
+    auto al = [](uint64_t b) -> uint64_t { return (b + 255) & ~255ull; };
+    auto scratch_of = [&](const DeflateJob &j, bool blocks) -> uint64_t {
+        const uint64_t V = round_of(j) + 64;
+        uint64_t b = 2 * al(4 * V);
+        if (blocks) {
+            const uint64_t mb = deflate4_max_blocks(round_of(j));
+            b += al(4 * (V + 4096)) + al(4 * (4 + 2 * mb)) + al(16 * mb) + al(mb * deflate4_block_bytes() + 64);
+        }
+        return b;
     };
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     uint64_t budget = c->cfg[SPNG_CFG_DEFLATE_BYTES] ? (uint64_t)c->cfg[SPNG_CFG_DEFLATE_BYTES] : (uint64_t)(free_b + c->graph_cap + c->ring_cap) / 2;
-    std::vector<std::pair<size_t, size_t>> groups;
+    struct Group { size_t first, last; bool blocks; };
+    std::vector<Group> groups;
     uint64_t slab = 0;
     for (size_t i = first; i < last;) {
+        const bool blocks = i < mid;
+        const size_t stop = blocks ? mid : last;
         uint64_t used = 0;
         size_t k = i;
-        while (k < last) {
-            const uint64_t sc = scratch_of(sorted[k]);
+        while (k < stop) {
+            const uint64_t sc = scratch_of(sorted[k], blocks);
             if (used + sc > budget && k > i) break;
             used += sc; ++k;
         }
         slab = used > slab ? used : slab;
-        groups.push_back({i, k});
+        groups.push_back({i, k, blocks});
         i = k;
     }
     slab += 4096;
@@ -1830,22 +1846,28 @@ static int32_t deflate_fast_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
     }
     const size_t sslot = a.take(nfast * sizeof(D3Stream)), tslot = a.take(nfast * sizeof(D1State));
     D3Stream *hs = a.host<D3Stream>(sslot);
-    // (a zeroed state = a stream's beginning: dfl3_begin_kernel; only the head of a D1State matters -- the terms of a state that
-    //  has not started are never read)
+    // (a zeroed state = a stream's beginning: dfl3_begin_kernel)
     for (size_t i = 0; i < nfast; ++i) memset(a.host<D1State>(tslot) + i, 0, sizeof(D1State));
-    std::vector<uint32_t> rounds_of(nfast, 1);
+    std::vector<uint32_t> rounds_of(nfast, 1), maxb_of(nfast, 0);
     for (auto &gr : groups) {
         char *base = (char *)c->d_graph;
         uint64_t at = 0;
-        for (size_t i = gr.first; i < gr.second; ++i) {
+        auto take = [&](uint64_t bytes) { char *p = base + at; at += al(bytes); return p; };
+        for (size_t i = gr.first; i < gr.last; ++i) {
             const DeflateJob &j = sorted[i];
             D3Stream &s = hs[i - first];
-            const uint64_t half = scratch_of(j) / 2;
+            memset(&s, 0, sizeof s);
+            const uint64_t V = round_of(j) + 64;
             s.src = j.src; s.dst = j.dst; s.src_len = j.src_len; s.dst_cap = j.dst_cap; s.format = j.format; s.level = j.level;
             s.image = j.image; s.exponent = j.exponent; s.more = j.more; s.pad = 0;
             s.state = j.state ? j.state : a.dev<D1State>(tslot) + (i - first);
-            s.match[0] = (uint32_t *)(base + at); s.match[1] = (uint32_t *)(base + at + half);
-            at += 2 * half;
+            s.match[0] = (uint32_t *)take(4 * V); s.match[1] = (uint32_t *)take(4 * V);
+            if (gr.blocks) {
+                const uint64_t mb = deflate4_max_blocks(round_of(j));
+                s.terms = (uint32_t *)take(4 * (V + 4096)); s.bdesc = (uint32_t *)take(4 * (4 + 2 * mb));
+                s.bbits = (uint64_t *)take(16 * mb); s.scratch = (uint8_t *)take(mb * deflate4_block_bytes() + 64);
+                maxb_of[i - first] = (uint32_t)mb;
+            }
             const uint64_t sp = span_of(j);
             rounds_of[i - first] = sp ? (uint32_t)((sp + RV - 1) / RV) : 1u;   // (one launch at least: it reports where the stream stands)
         }
@@ -1857,12 +1879,15 @@ static int32_t deflate_fast_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
     }
     if (!c->ev_dfl[0]) for (hipEvent_t &e : c->ev_dfl) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &gr : groups) {
-        const uint32_t cnt = (uint32_t)(gr.second - gr.first);
+        const uint32_t cnt = (uint32_t)(gr.last - gr.first);
         uint32_t cps = (256 + cnt - 1) / cnt;                 // (as the level >= 8 search: one round of workgroups where the streams are few)
         cps = cps < 2 ? 2 : cps > 64 ? 64 : cps;
         const uint32_t chunk = (uint32_t)(((RV / cps + 63) / 64) * 64);
-        uint32_t rounds = 0;
-        for (size_t i = gr.first; i < gr.second; ++i) rounds = rounds_of[i - first] > rounds ? rounds_of[i - first] : rounds;
+        uint32_t rounds = 0, maxb = 0;
+        for (size_t i = gr.first; i < gr.last; ++i) {
+            rounds = rounds_of[i - first] > rounds ? rounds_of[i - first] : rounds;
+            maxb = maxb_of[i - first] > maxb ? maxb_of[i - first] : maxb;
+        }
         const D3Stream *ds = a.dev<D3Stream>(sslot) + (gr.first - first);
         HIP_TRY(launch_deflate3_begin(ds, cnt, c->stream));
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
@@ -1873,7 +1898,11 @@ static int32_t deflate_fast_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
             { Timed t(c, SPNG_K_DFL_SEARCH, c->stream2); HIP_TRY(launch_deflate3_search(ds, cnt, cps, chunk, par, c->stream2)); }
             HIP_TRY(hipEventRecord(c->ev_dfl[par], c->stream2));
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_dfl[par], 0));
-            { Timed t(c, SPNG_K_DFL_PARSE); HIP_TRY(launch_deflate3_parse(ds, cnt, dr, par, c->stream)); }
+            {
+                Timed t(c, SPNG_K_DFL_PARSE);
+                if (gr.blocks) HIP_TRY(launch_deflate4_round(ds, cnt, maxb, dr, par, c->stream));
+                else HIP_TRY(launch_deflate3_parse(ds, cnt, dr, par, c->stream));
+            }
             HIP_TRY(hipEventRecord(c->ev_dfl[2 + par], c->stream));
         }
     }

@@ -225,6 +225,11 @@ struct D3Stream {
     uint32_t more, pad;
     D1State *state;
     uint32_t *match[2];           // by round parity: per position of the round (and one behind it) run << 16 | distance, 0: no run > 5
+    // the block-parallel form (one-shot streams: dfl4_walk / dfl4_block / dfl4_scan / dfl4_place), null otherwise
+    uint32_t *terms;              // the round's terms, block after block
+    uint32_t *bdesc;              // [0] blocks of the round, [1] the stream's last round, [2..3] the bit the round starts at; then per block {first term, terms | final << 31}
+    uint64_t *bbits;              // per block: the bits it takes (dfl4_block), its first bit in the stream (dfl4_scan) at [max blocks + k]
+    uint8_t  *scratch;            // per block D4_BCAP bytes: its bits from bit 0 on
 };
 
 // levels >= 8, the two-kernel form (deflate.hip, "round 4"): what the search and the parse kernel share per stream.
@@ -310,6 +315,10 @@ uint64_t deflate3_end(uint64_t n, bool more);
 hipError_t launch_deflate3_begin(const D3Stream *d_streams, uint32_t count, hipStream_t stream);
 hipError_t launch_deflate3_search(const D3Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t parity, hipStream_t stream);
 hipError_t launch_deflate3_parse(const D3Stream *d_streams, uint32_t count, spng_result *d_results, uint32_t parity, hipStream_t stream);
+// ... with the blocks written side by side (one-shot streams)
+uint64_t deflate4_max_blocks(uint64_t positions);
+uint64_t deflate4_block_bytes();
+hipError_t launch_deflate4_round(const D3Stream *d_streams, uint32_t count, uint32_t max_blocks, spng_result *d_results, uint32_t parity, hipStream_t stream);
 hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, uint32_t parity, hipStream_t stream);
 hipError_t launch_deflate2_failed(const D2Stream *d_streams, uint32_t count, uint32_t *d_failed, hipStream_t stream);
 uint64_t deflate_graph_vertices(uint64_t n);

@@ -470,12 +470,12 @@ __device__ __forceinline__ uint64_t match_bits(const DLds &s, uint32_t rd, uint3
 }
 
 // Stream.writeBlock (DeflatorBuffers.Stream.swift:440-709), greedy / lazy form
-__device__ __attribute__((noinline)) Bits write_block(Bits b_, int count_, bool final_, int lane, int tb_ = 0)
+template <class TP>
+__device__ __forceinline__ Bits write_block_from(Bits b_, int count_, bool final_, int lane, TP terms)
 {
     Bits b = uni_bits(b_);
     const int count = (int)UNI(count_);
     const bool final = UB(final_);
-    const uint32_t *terms = g_trm.terms[UNI(tb_)];
     DLds &s = g_lds;
     // DeflatorMatches.trees() (:138-159)
     for (int i = lane; i < 320; i += 64) s.freq[i] = 0;
@@ -507,6 +507,16 @@ __device__ __attribute__((noinline)) Bits write_block(Bits b_, int count_, bool 
     put(s, b, s.lcode[256], s.ll[256], lane);
     maybe_drain(s, b, lane);
     return b;
+}
+// ... the queued terms of the one-wave / two-wave forms (LDS, buffer tb)
+__device__ __attribute__((noinline)) Bits write_block(Bits b_, int count_, bool final_, int lane, int tb_ = 0)
+{
+    return write_block_from(b_, count_, final_, lane, (const uint32_t *)g_trm.terms[UNI(tb_)]);
+}
+// ... a block of the block-parallel form: its terms where the walk left them (global memory)
+__device__ __attribute__((noinline)) Bits write_block_global(Bits b_, int count_, bool final_, int lane, const gword *terms_)
+{
+    return write_block_from(b_, count_, final_, lane, UNIP(const gword *, terms_));
 }
 
 __device__ __forceinline__ uint32_t load32(const gbyte *p) { return ((const gU32u *)p)->v; }
@@ -2148,6 +2158,252 @@ __global__ __launch_bounds__(128) void dfl3_parse_kernel(const D3Stream *__restr
     }
 }
 
+// ---- levels 0-7, one-shot streams: the blocks side by side (dfl4_walk / dfl4_block / dfl4_scan / dfl4_place) -----------------
+// With the answers in hand a stream's serial part is only the walk -- which positions are asked, which terms that gives.  The
+// blocks themselves (2047 terms: symbol counts, two Huffman trees with the reference's heap replayed on one lane, the
+// run-length coded tables, the bits: ~1 M cycles of a latency-bound wave) do not depend on each other at all but for WHERE
+// in the stream their bits go.  So, per round and stream:
+//   * dfl4_walk_kernel: a wave walks the answers (the parser half of dfl3_parse_kernel) and leaves the terms in global memory,
+//     block after block, with a list of the blocks; the terms of the unfinished block go to the next round in the D1State;
+//   * dfl4_block_kernel: a wave per BLOCK, the whole chip over all blocks of all streams: write_block into a scratch of the
+//     block's own, from bit 0 on; its length in bits;
+//   * dfl4_scan_kernel: per stream the prefix sum of the lengths = where each block starts (header, stored tail, trailer and
+//     result are its business too);
+//   * dfl4_place_kernel: a wave per block moves the block's bits to their place: output byte b is the eight bits from 8 b on,
+//     a two-byte read and a shift per lane; a byte is written by the block its first bit lies in, which takes the missing bits
+//     from the blocks behind (and, first block of a round, the bits the round before left pending).
+// Streams that arrive in pieces (spng_deflate_resume_batch) keep the two-wave form above: their state outlives the call.
+static constexpr uint32_t D4_BCAP = 13312;      // bytes of a block's bits: 2047 terms of <= 48 bits, the tables, the end-of-block symbol; slack
+uint64_t deflate4_max_blocks(uint64_t positions) { return positions / 2046 + 4; }
+uint64_t deflate4_block_bytes() { return D4_BCAP; }
+__shared__ uint32_t g_wterms[2048];             // dfl4_walk_kernel: the terms of the block being filled (carried over a round's end)
+
+__global__ __launch_bounds__(64) void dfl4_walk_kernel(const D3Stream *__restrict__ streams, uint32_t parity)
+{
+    const D3Stream *sp = streams + blockIdx.x;
+    const int lane = threadIdx.x;
+    D1State *state = (D1State *)uni64((uint64_t)sp->state);
+    gword *bd = (gword *)uni64((uint64_t)sp->bdesc);
+    if (UNI(state->done)) { if (lane == 0) bd[0] = 0; return; }
+    const gbyte *in = (const gbyte *)uni64((uint64_t)sp->src);
+    const uint64_t n = uni64(sp->src_len);
+    const bool lazy = (int32_t)UNI(sp->level) >= 4;            // Stream.compress lazy (:268-323) from level 4 on
+    const gword *match = (const gword *)uni64((uint64_t)sp->match[parity]);
+    gword *tbuf = (gword *)uni64((uint64_t)sp->terms);
+    const uint64_t rb = uni64(state->rb), re = uni64(state->re);
+    const uint64_t E = n < re ? re : n;
+    uint64_t w = uni64(state->w);
+    int count = (int)UNI(state->count);
+    uint32_t off = 0, nblk = 0;                                // first term of the block being filled; blocks closed
+    for (int i = lane; i < count; i += 64) { const uint32_t t = state->terms[i]; g_wterms[i] = t; tbuf[i] = t; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    const int limit_terms = 2048;
+    auto unfilled = [&]() { return limit_terms - 1 - count; };
+    auto emit = [&](uint32_t t) { g_wterms[count] = t; if (lane == 0) tbuf[off + (uint32_t)count] = t; ++count; };
+    auto close = [&](bool final) {
+        if (lane == 0) { bd[4 + 2 * nblk] = off; bd[5 + 2 * nblk] = (uint32_t)count | (final ? 1u << 31 : 0u); }
+        off += (uint32_t)count; count = 0; nblk += 1;
+    };
+    if (n >= 3) {
+        const uint64_t last_main = n - 4 + 1;                  // positions 0 .. n-4 are searched
+        const uint64_t stop = re < last_main ? re : last_main; // tokens that start below `stop` are this round's
+        auto ask = [&](uint64_t p, uint32_t &m, uint32_t &lit) {
+            m = (p <= re && p < last_main) ? match[p - rb] : 0u;
+            lit = p < n ? (uint32_t)in[p] : 0u;
+        };
+        uint32_t nmA, nmB, nlA, nlB;
+        uint64_t asked = w;
+        ask(w + lane, nmA, nlA); ask(w + 64 + lane, nmB, nlB);
+        while (w < stop) {
+            uint32_t mA, mB, litA, litB;
+            if (asked == w) { mA = nmA; mB = nmB; litA = nlA; litB = nlB; }
+            else { ask(w + lane, mA, litA); ask(w + 64 + lane, mB, litB); }
+            asked = w + 128;                                   // (the guess: the batch is used up to its end -- a run across it asks again)
+            ask(asked + lane, nmA, nlA); ask(asked + 64 + lane, nmB, nlB);
+            auto at = [&](uint32_t xa, uint32_t xb, uint32_t t) -> uint32_t {
+                return t < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)xa, (int)t) : (uint32_t)__builtin_amdgcn_readlane((int)xb, (int)(t - 64));
+            };
+            // ---- the parse: Stream.compress greedy (:209-252) / lazy (:268-323) over these 128 answers
+            uint32_t t = 0;
+            while (t < 128 && w + t < stop) {
+                if (!(unfilled() > (lazy ? 1 : 0))) close(false);
+                const uint32_t m = at(mA, mB, t);
+                const uint32_t lit = at(litA, litB, t);
+                if (!m) { emit(0xf8000000u | lit); t += 1; continue; }
+                uint32_t use_run = m >> 16, use_dist = m & 0xffff;
+                uint32_t adv = use_run;
+                if (lazy) {
+                    if (t + 1 >= 128) break;                   // (the answer for position w + t + 1: the next batch starts there)
+                    const uint32_t lm = at(mA, mB, t + 1);     // lazy match at a + 1 (:293-299)
+                    if ((lm >> 16) > use_run) {
+                        emit(0xf8000000u | lit);
+                        use_run = lm >> 16; use_dist = lm & 0xffff;
+                        adv = 1 + use_run;
+                    }
+                }
+                // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
+                const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
+                emit(dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9);
+                t += adv;
+            }
+            w = uni64(w + t);
+        }
+    } else w = n;
+    const bool last = !(re < E);
+    if (!last) {
+        // on with the next round: the unfinished block's terms and the position into the state
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        for (int i = lane; i < count; i += 64) state->terms[i] = g_wterms[i];
+        if (lane == 0) { state->w = w; state->count = (uint32_t)count; state->rb = re; state->re = re + D3_RV < E ? re + D3_RV : E; }
+    } else if (n >= 3) {
+        // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342), then the final block
+        for (uint64_t p = w; p < n; ++p) {
+            if (!(unfilled() > 0)) close(false);
+            emit(0xf8000000u | UNI(in[p]));
+        }
+        close(true);
+    }
+    if (lane == 0) { bd[0] = nblk; bd[1] = last ? 1u : 0u; bd[2] = (uint32_t)rb; bd[3] = (uint32_t)(rb >> 32); }
+}
+
+__global__ __launch_bounds__(64) void dfl4_block_kernel(const D3Stream *__restrict__ streams)
+{
+    DLds &s = g_lds;
+    const D3Stream *sp = streams + blockIdx.y;
+    const int lane = threadIdx.x;
+    const gword *bd = (const gword *)uni64((uint64_t)sp->bdesc);
+    const uint32_t k = blockIdx.x;
+    if (k >= UNI(bd[0])) return;
+    const uint32_t first = UNI(bd[4 + 2 * k]), cw = UNI(bd[5 + 2 * k]);
+    for (int i = lane; i < OUTB / 4; i += 64) s.out32[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    Bits b = {0, 0, 0, 0, (gbyte *)uni64((uint64_t)sp->scratch) + (uint64_t)k * D4_BCAP, D4_BCAP, false};
+    b = uni_bits(write_block_global(b, (int)(cw & 0x7fffffffu), (cw >> 31) != 0, lane, (const gword *)uni64((uint64_t)sp->terms) + first));
+    const uint64_t bits = b.total * 8 + b.nacc;
+    if (b.nacc) put(s, b, 0, 8 - b.nacc, lane);                // (the bits behind the block's last in its last byte: zero)
+    put(s, b, 0, 16, lane);                                    // (dfl4_place reads two bytes at a time)
+    drain(s, b, b.total, lane);
+    if (lane == 0) ((unsigned long long *)sp->bbits)[k] = b.overflow ? ~0ull : bits;
+}
+
+// one workgroup per stream: where the blocks of the round start; header, stored tail, trailer, result
+__global__ __launch_bounds__(256) void dfl4_scan_kernel(const D3Stream *__restrict__ streams, uint32_t maxb, spng_result *__restrict__ results)
+{
+    const D3Stream &st = streams[blockIdx.x];
+    D1State *state = st.state;
+    uint32_t *bd = st.bdesc;
+    unsigned long long *bb = (unsigned long long *)st.bbits;
+    const uint32_t nb = bd[0];
+    const bool last = bd[1] != 0;
+    const uint64_t rb = (uint64_t)bd[3] << 32 | bd[2];
+    __shared__ unsigned long long part[256];
+    __shared__ unsigned long long shared_p0;
+    const int tid = threadIdx.x;
+    if (state->done) return;
+    uint8_t *dst = st.dst;
+    const uint64_t cap = st.dst_cap, n = st.src_len;
+    if (tid == 0) {
+        if (rb == 0 && state->total == 0 && state->nacc == 0) {
+            // the stream's first round: its header
+            uint8_t hdr[10]; uint32_t hn = 0;
+            if (st.format == SPNG_FORMAT_ZLIB) {
+                // StreamHeader.write (StreamHeader.swift:56-62)
+                const uint32_t unpaired = (st.exponent - 8) << 4 | 0x08;
+                const uint32_t check = ~(((unpaired << 8 | unpaired >> 8) & 0xffff) % 31) & 31;
+                hdr[0] = (uint8_t)unpaired; hdr[1] = (uint8_t)check; hn = 2;
+            } else if (st.format == SPNG_FORMAT_GZIP) {
+                // Gzip.StreamHeader.write (Gzip.StreamHeader.swift:84-96); the trailer is appended by gzip.hip
+                const uint8_t g[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 0xff};
+                for (int i = 0; i < 10; ++i) hdr[i] = g[i];
+                hn = 10;
+            }
+            for (uint32_t i = 0; i < hn; ++i) if (i < cap) dst[i] = hdr[i];
+            state->total = hn;
+        }
+        shared_p0 = state->total * 8 + state->nacc;
+    }
+    __syncthreads();
+    const unsigned long long p0 = shared_p0;
+    // prefix sum of the blocks' lengths (a thread takes a run of consecutive blocks)
+    const uint32_t per = (nb + 255) / 256;
+    unsigned long long mine = 0;
+    bool over = false;
+    for (uint32_t k = tid * per; k < nb && k < (tid + 1) * per; ++k) { const unsigned long long l = bb[k]; if (l == ~0ull) over = true; else mine += l; }
+    part[tid] = mine;
+    __syncthreads();
+    unsigned long long before = 0, total = 0;
+    for (int t = 0; t < 256; ++t) { if (t < tid) before += part[t]; total += part[t]; }
+    unsigned long long at = p0 + before;
+    for (uint32_t k = tid * per; k < nb && k < (tid + 1) * per; ++k) { bb[maxb + k] = at; at += bb[k] == ~0ull ? 0 : bb[k]; }
+    over = __syncthreads_or(over);
+    if (tid != 0) return;
+    const unsigned long long pend = p0 + total;
+    // what dfl4_place needs of the state as it was: the pending bits in front of the round
+    bd[2] = state->nacc; bd[3] = (uint32_t)state->acc & 0xff;
+    state->total = pend >> 3; state->nacc = (uint32_t)(pend & 7);
+    if (!last) return;
+    uint64_t written = (pend + 7) >> 3;                        // DeflatorOut.pull flushes padding bits
+    uint32_t S = state->adlerS % 65521, I = state->adlerI % 65521;
+    if (n < 3) {
+        // Stream.compressBlocks stored tail (:45-60, :417-434): no block was queued; the bytes by hand (the header ends on a byte)
+        uint8_t t[8]; uint32_t tn = 0;
+        t[tn++] = 1; t[tn++] = (uint8_t)n; t[tn++] = 0; t[tn++] = (uint8_t)~n; t[tn++] = 0xff;
+        S = 0; I = 0;
+        for (uint64_t k = 0; k < n; ++k) { t[tn++] = st.src[k]; S += st.src[k]; I += (uint32_t)k * st.src[k]; }
+        for (uint32_t i = 0; i < tn; ++i) if (written + i < cap) dst[written + i] = t[i];
+        written += tn;
+    }
+    if (st.format == SPNG_FORMAT_ZLIB) {
+        // Adler-32 from the sums the search kernel left (s1 = 1 + S, s2 = N + N * S - I)
+        const uint32_t N = (uint32_t)(n % 65521);
+        const uint32_t sum = ((N + (uint64_t)N * S % 65521 + 65521 - I) % 65521) << 16 | (1 + S) % 65521;
+        for (int i = 0; i < 4; ++i) if (written + i < cap) dst[written + i] = (uint8_t)(sum >> (24 - 8 * i));
+        written += 4;
+    }
+    spng_result &res = results[st.image];
+    res.status = (over || written > cap) ? SPNG_E_OUTPUT_CAPACITY : SPNG_DONE; res.reserved = 0;
+    res.written = written; res.consumed = n; res.aux[0] = res.aux[1] = 0;
+    state->total = written; state->nacc = 0;
+    state->done = 1;
+}
+
+__global__ __launch_bounds__(64) void dfl4_place_kernel(const D3Stream *__restrict__ streams, uint32_t maxb)
+{
+    const D3Stream *sp = streams + blockIdx.y;
+    const int lane = threadIdx.x;
+    const gword *bd = (const gword *)uni64((uint64_t)sp->bdesc);
+    const uint32_t nb = UNI(bd[0]), k = blockIdx.x;
+    if (k >= nb) return;
+    const unsigned long long *bb = (const unsigned long long *)uni64((uint64_t)sp->bbits);
+    const gbyte *scr = (const gbyte *)uni64((uint64_t)sp->scratch);
+    gbyte *dst = (gbyte *)uni64((uint64_t)sp->dst);
+    const uint64_t cap = uni64(sp->dst_cap);
+    D1State *state = (D1State *)uni64((uint64_t)sp->state);
+    const uint64_t S = uni64(bb[maxb + k]), Lk = uni64(bb[k]);
+    if (Lk == ~0ull) return;                                   // (a block that outgrew its scratch: the stream reports the capacity error)
+    const uint64_t Eb = S + Lk;
+    const uint64_t pend = uni64(bb[maxb + nb - 1]) + (uni64(bb[nb - 1]) == ~0ull ? 0 : uni64(bb[nb - 1]));   // the round's last bit + 1
+    // byte b of the stream from `have` valid low bits of v on: the rest from block kk on, from its bit `o`
+    auto finish = [&](uint64_t b, uint32_t v, uint32_t have, uint32_t kk, uint64_t o) {
+        while (have < 8 && kk < nb) {
+            const uint64_t lk = bb[kk];
+            if (lk != ~0ull && o < lk) {
+                const gbyte *src = scr + (uint64_t)kk * D4_BCAP;
+                const uint32_t two = (uint32_t)src[o >> 3] | (uint32_t)src[(o >> 3) + 1] << 8;
+                const uint32_t avail = lk - o < 8 - have ? (uint32_t)(lk - o) : 8 - have;
+                v |= ((two >> (o & 7)) & ((1u << avail) - 1)) << have;
+                have += avail; o += avail;
+            }
+            if (have < 8) { kk += 1; o = 0; }
+        }
+        if (b < cap) dst[b] = (gbyte)v;
+        if ((b << 3) + 8 > pend && (pend & 7)) state->acc = v;          // the round's last, unfinished byte: pending for the next round
+    };
+    const uint64_t b0 = (S + 7) >> 3, b1 = (Eb + 7) >> 3;      // the bytes whose first bit lies in this block
+    for (uint64_t b = b0 + (uint32_t)lane; b < b1; b += 64) finish(b, 0u, 0u, k, (b << 3) - S);
+    if (k == 0 && lane == 0 && UNI(bd[2])) finish(S >> 3, UNI(bd[3]) & ((1u << UNI(bd[2])) - 1), UNI(bd[2]), 0u, 0);   // the byte the round before left unfinished
+}
+
 // ---- the parse kernel -------------------------------------------------------------------------------------------
 struct D2Arrays {                                               // (pointers of one stream, wave-uniform)
     const uint16_t *vinfo; const uint64_t *bbase; const uint32_t *bwords; uint64_t *emask;
@@ -2930,6 +3186,21 @@ hipError_t launch_deflate3_parse(const D3Stream *d_streams, uint32_t count, spng
 {
     if (!count) return hipSuccess;
     dfl3_parse_kernel<<<count, 128, 0, stream>>>(d_streams, d_results, parity);
+    return hipGetLastError();
+}
+hipError_t launch_deflate4_round(const D3Stream *d_streams, uint32_t count, uint32_t max_blocks, spng_result *d_results, uint32_t parity, hipStream_t stream)
+{
+    if (!count) return hipSuccess;
+    dfl4_walk_kernel<<<count, 64, 0, stream>>>(d_streams, parity);
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u) {           // (grid y stops at 65535)
+        const uint32_t ny = count - y0 < 65535u ? count - y0 : 65535u;
+        dfl4_block_kernel<<<dim3(max_blocks, ny), 64, 0, stream>>>(d_streams + y0);
+    }
+    dfl4_scan_kernel<<<count, 256, 0, stream>>>(d_streams, max_blocks, d_results);
+    for (uint32_t y0 = 0; y0 < count; y0 += 65535u) {
+        const uint32_t ny = count - y0 < 65535u ? count - y0 : 65535u;
+        dfl4_place_kernel<<<dim3(max_blocks, ny), 64, 0, stream>>>(d_streams + y0, max_blocks);
+    }
     return hipGetLastError();
 }
 hipError_t launch_deflate2_parse(const D2Stream *d_streams, uint32_t count, const uint32_t *d_pool, spng_result *d_results, uint32_t parity, hipStream_t stream)

@@ -68,6 +68,14 @@ int main(int argc, char **argv)
         std::vector<uint64_t> cuts;
         for (int a = 6; a < argc; ++a) cuts.push_back(strtoull(argv[a], nullptr, 10));
         cuts.push_back(n);
+        // one-shot streams: the blocks side by side (dfl4_walk / dfl4_block / dfl4_scan / dfl4_place), as api.hip drives them;
+        // EMU_TWO_WAVE forces the two-wave parse (the form of streams that arrive in pieces)
+        const bool blocks = cuts.size() == 1 && !getenv("EMU_TWO_WAVE");
+        const uint32_t maxb = (uint32_t)deflate4_max_blocks(RV);
+        std::vector<uint32_t> terms(RV + 64 + 4096, 0xABABABAB), bdesc(4 + 2 * (size_t)maxb, 0);
+        std::vector<uint64_t> bbits(2 * (size_t)maxb, 0);
+        std::vector<uint8_t> scratch(blocks ? (size_t)maxb * deflate4_block_bytes() + 64 : 64, 0xCD);
+        if (blocks) { st.terms = terms.data(); st.bdesc = bdesc.data(); st.bbits = bbits.data(); st.scratch = scratch.data(); }
         uint32_t rounds = 0;
         uint64_t spos = 0;
         for (size_t call = 0; call < cuts.size(); ++call) {
@@ -80,7 +88,12 @@ int main(int argc, char **argv)
                 const uint32_t par = r & 1;
                 emu::launch(cps, SPNG_D3_WAVES * 64, [&] { dfl3_search_fast_kernel(&st, cps, chunk, par); });
                 emu::launch(1, 256, [&] { dfl3_advance_kernel(&st, 1); });
-                emu::launch(1, 128, [&] { dfl3_parse_kernel(&st, &res, par); });
+                if (blocks) {
+                    emu::launch(1, 64, [&] { dfl4_walk_kernel(&st, par); });
+                    emu::launch(maxb, 64, [&] { dfl4_block_kernel(&st); });
+                    emu::launch(1, 256, [&] { dfl4_scan_kernel(&st, maxb, &res); });
+                    emu::launch(maxb, 64, [&] { dfl4_place_kernel(&st, maxb); });
+                } else emu::launch(1, 128, [&] { dfl3_parse_kernel(&st, &res, par); });
             }
             if (st.more && res.status != SPNG_NEED_MORE_INPUT) { printf("call %zu (more): status %d\n", call, res.status); return 1; }
             if (st.more) { if (res.aux[1] != st.state->spos) { printf("call %zu: aux[1] %llu != spos %llu\n", call, (unsigned long long)res.aux[1], (unsigned long long)st.state->spos); return 1; } spos = res.aux[1]; }
@@ -92,7 +105,7 @@ int main(int argc, char **argv)
             printf("stream differs: %llu bytes against %zu expected, first difference at %zu\n", (unsigned long long)res.written, want.size(), k);
             return 1;
         }
-        printf("ok: %llu -> %llu bytes in %u rounds (search + parse kernels)\n", (unsigned long long)n, (unsigned long long)res.written, rounds);
+        printf("ok: %llu -> %llu bytes in %u rounds (search + parse kernels%s)\n", (unsigned long long)n, (unsigned long long)res.written, rounds, blocks ? ", blocks side by side" : "");
         return 0;
     }
     const uint64_t V = deflate2_vertices(n), B = V / 64 + 2;
