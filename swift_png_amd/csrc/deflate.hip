@@ -71,11 +71,13 @@ __device__ __forceinline__ uint32_t dist_decade(uint32_t d)
     return 2 * e + 2 + ((x >> e) & 1);
 }
 
-struct DLds {                                    // what every kernel of this file needs
-    // full search (levels >= 8), forward pass: the best way into each of the next vertices found so far, as
-    // one 64-bit key (depth << 32 | writer order: see full_forward)
+struct DLdsFull {                                // the full search (levels >= 8) only
+    // forward pass: the best way into each of the next vertices found so far, as one 64-bit key (depth << 32 | writer order:
+    // see full_forward)
     uint64_t win[512];
     uint8_t  depths[544];                        // LZ77.DeflatorMatches.Depths: cost of every symbol in quarter bits
+};
+struct DLds {                                    // what every kernel of this file that writes blocks needs
     uint32_t freq[320];                          // 0..287 lit/len, 288..319 distance
     union { uint8_t out[OUTB]; uint32_t out32[OUTB / 4]; };   // output staging ring; bytes not written yet are zero
     // Huffman scratch (one tree at a time)
@@ -108,6 +110,7 @@ struct DLdsOld {                                 // the one-kernel full search (
 // One instance per workgroup, at namespace scope so that the (non-inlined) block writer reaches it
 // with LDS instructions instead of through a generic pointer.
 __shared__ __attribute__((aligned(16))) DLds g_lds;
+__shared__ __attribute__((aligned(16))) DLdsFull g_full;
 __shared__ __attribute__((aligned(16))) DLdsSearch g_sea;
 __shared__ __attribute__((aligned(16))) DLdsTerms g_trm;
 __shared__ __attribute__((aligned(16))) DLdsOld g_old;
@@ -950,11 +953,11 @@ __device__ __attribute__((noinline)) void forward_body(const FullArrays g, const
 {
     DLds &s = g_lds;
     // costs in registers: distance decade `lane`; run lengths 3 + lane + 64 j
-    const uint32_t dcost = lane < 30 ? s.depths[512 + lane] : 0u;
+    const uint32_t dcost = lane < 30 ? g_full.depths[512 + lane] : 0u;
     uint32_t rc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint32_t L = 3u + (uint32_t)lane + 64u * j; rc[j] = L <= 258 ? s.depths[253 + L] : 0u; }
-    if (wave == 0 && lane == 0) s.win[0] = 0;                  // vertex 0: depth 0
+    for (int j = 0; j < 4; ++j) { const uint32_t L = 3u + (uint32_t)lane + 64u * j; rc[j] = L <= 258 ? g_full.depths[253 + L] : 0u; }
+    if (wave == 0 && lane == 0) g_full.win[0] = 0;                  // vertex 0: depth 0
     uint32_t inited = 1, carry = DINF;                         // carry: depth of the vertex in front of the batch
     // (the literal byte of a batch is fetched while the batch before it is worked on)
     uint32_t lb_next = 0, fl_next = 0;
@@ -998,13 +1001,13 @@ __device__ __attribute__((noinline)) void forward_body(const FullArrays g, const
                 lb_next = vn <= count ? in[bbase + vn - 1] : 0u;
             }
             const uint32_t need = (b0 + 64 + 258 < count ? b0 + 64 + 258 : count) + 1;
-            for (uint32_t j = inited + lane; j < need; j += 64) s.win[j & 511] = ~0ull;
+            for (uint32_t j = inited + lane; j < need; j += 64) g_full.win[j & 511] = ~0ull;
             inited = inited > need ? inited : need;
             if (em) {
                 const uint32_t ns = count - b0 < 64 ? count - b0 : 64;
                 for (uint32_t i = lane; i < ns * 30; i += 64) g_old.batch[i] = g.slots_()[(uint64_t)b0 * 30 + i];
             }
-            cin = (v >= 1 && v <= count) ? s.depths[lb] : 0u;   // the literal edge INTO v
+            cin = (v >= 1 && v <= count) ? g_full.depths[lb] : 0u;   // the literal edge INTO v
             if (WAVES > 1 && em) {
                 g_old.fw_cin[par][lane] = cin;
                 if (lane == 0) g_old.fw_carry[par] = carry;
@@ -1017,7 +1020,7 @@ __device__ __attribute__((noinline)) void forward_body(const FullArrays g, const
         uint64_t W; uint32_t Wd, D;
         uint32_t k = 0;
         for (;;) {
-            W = (uint32_t)lane < nv ? s.win[v & 511] : ~0ull;
+            W = (uint32_t)lane < nv ? g_full.win[v & 511] : ~0ull;
             Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
             D = minplus_scan(cin, Wd, carry, lane);
             const unsigned long long rest = k < 64 ? (em >> k) << k : 0ull;
@@ -1053,7 +1056,7 @@ __device__ __attribute__((noinline)) void forward_body(const FullArrays g, const
                     const uint32_t L = 3u + (uint32_t)lane + 64u * j;
                     if (bc[j] != ~0u) {
                         const uint64_t key = (uint64_t)(Dk + bc[j] + rc[j]) << 32 | (258u - L) << 8 | (bd[j] + 1u);
-                        __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_min(&g_full.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
             }
@@ -1146,19 +1149,19 @@ __device__ __forceinline__ void full_depths_update(int lane)
     for (uint32_t sym = lane; sym < 286; sym += 64) {
         const uint32_t len = s.ll[sym];
         if (!len) continue;
-        if (sym < 256) s.depths[sym] = (uint8_t)(len << 2);
+        if (sym < 256) g_full.depths[sym] = (uint8_t)(len << 2);
         else if (sym > 256) {
             const uint32_t dec = sym & 0xff, e = run_extra_bits(dec), base = 253 + run_base(dec);
-            for (uint32_t l = base; l < base + (1u << e); ++l) if (l != 253 + 258 || dec == 29) s.depths[l] = (uint8_t)((len + e) << 2);
+            for (uint32_t l = base; l < base + (1u << e); ++l) if (l != 253 + 258 || dec == 29) g_full.depths[l] = (uint8_t)((len + e) << 2);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     if (lane == 0) {
         const uint32_t a = s.ll[284], c = s.ll[285];
-        if (a && (!c || a > c)) s.depths[253 + 258] = (uint8_t)((a + 5) << 2);
-        else if (c) s.depths[253 + 258] = (uint8_t)(c << 2);
+        if (a && (!c || a > c)) g_full.depths[253 + 258] = (uint8_t)((a + 5) << 2);
+        else if (c) g_full.depths[253 + 258] = (uint8_t)(c << 2);
     }
-    if (lane < 30 && s.dl[lane]) s.depths[512 + lane] = (uint8_t)((s.dl[lane] + dist_extra_bits(lane)) << 2);
+    if (lane < 30 && s.dl[lane]) g_full.depths[512 + lane] = (uint8_t)((s.dl[lane] + dist_extra_bits(lane)) << 2);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 }
 
@@ -1219,8 +1222,8 @@ __device__ __attribute__((noinline)) Bits full_block(Bits b_, const FullArrays g
     FPROF(8);
     // resetGraph -> Depths.generalize (Depths.swift:88-98)
     for (uint32_t i = lane; i < 542; i += 64) {
-        const uint32_t x = s.depths[i], d = depth_default(i);
-        s.depths[i] = (uint8_t)((x & d) + ((x ^ d) >> 1));
+        const uint32_t x = g_full.depths[i], d = depth_default(i);
+        g_full.depths[i] = (uint8_t)((x & d) + ((x ^ d) >> 1));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     return b;
@@ -1281,7 +1284,7 @@ __global__ __launch_bounds__(WAVES * 64) void deflate_full_kernel(const DeflateJ
         put(s, b, 0x8b1f, 16, lane); put(s, b, 0x0008, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0xff00, 16, lane);
     }
     for (int i = lane; i <= (1 << HBITS); i += 64) g_sea.head[i] = NONE;
-    for (uint32_t i = lane; i < 542; i += 64) s.depths[i] = (uint8_t)depth_default(i);
+    for (uint32_t i = lane; i < 542; i += 64) g_full.depths[i] = (uint8_t)depth_default(i);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 
     uint32_t accS = 0, accI = 0;
@@ -2193,20 +2196,24 @@ __global__ __launch_bounds__(64) void dfl4_walk_kernel(const D3Stream *__restric
     const uint64_t rb = uni64(state->rb), re = uni64(state->re);
     const uint64_t E = n < re ? re : n;
     uint64_t w = uni64(state->w);
-    int count = (int)UNI(state->count);
+    uint32_t count = UNI(state->count);
     uint32_t off = 0, nblk = 0;                                // first term of the block being filled; blocks closed
-    for (int i = lane; i < count; i += 64) { const uint32_t t = state->terms[i]; g_wterms[i] = t; tbuf[i] = t; }
+    for (uint32_t i = (uint32_t)lane; i < count; i += 64) g_wterms[i] = state->terms[i];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    const int limit_terms = 2048;
-    auto unfilled = [&]() { return limit_terms - 1 - count; };
-    auto emit = [&](uint32_t t) { g_wterms[count] = t; if (lane == 0) tbuf[off + (uint32_t)count] = t; ++count; };
+    // A block closes when 2047 terms are queued (lazy: 2046 or 2047: a step may queue two), looked at before every step
+    // (DeflatorBuffers.Stream.swift:219, 277): its terms leave for global memory 64 at a time, its place goes into the list.
+    const uint32_t cap = lazy ? 2046u : 2047u;
     auto close = [&](bool final) {
-        if (lane == 0) { bd[4 + 2 * nblk] = off; bd[5 + 2 * nblk] = (uint32_t)count | (final ? 1u << 31 : 0u); }
-        off += (uint32_t)count; count = 0; nblk += 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        for (uint32_t i = (uint32_t)lane; i < count; i += 64) tbuf[off + i] = g_wterms[i];
+        if (lane == 0) { bd[4 + 2 * nblk] = off; bd[5 + 2 * nblk] = count | (final ? 1u << 31 : 0u); }
+        off += count; count = 0; nblk += 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // (every lane has read its terms before the next block's are queued)
     };
     if (n >= 3) {
         const uint64_t last_main = n - 4 + 1;                  // positions 0 .. n-4 are searched
         const uint64_t stop = re < last_main ? re : last_main; // tokens that start below `stop` are this round's
+        // the answers of 128 positions at a time (two per lane), fetched a batch ahead: a wave alone has nobody to hide a load behind
         auto ask = [&](uint64_t p, uint32_t &m, uint32_t &lit) {
             m = (p <= re && p < last_main) ? match[p - rb] : 0u;
             lit = p < n ? (uint32_t)in[p] : 0u;
@@ -2220,31 +2227,54 @@ __global__ __launch_bounds__(64) void dfl4_walk_kernel(const D3Stream *__restric
             else { ask(w + lane, mA, litA); ask(w + 64 + lane, mB, litB); }
             asked = w + 128;                                   // (the guess: the batch is used up to its end -- a run across it asks again)
             ask(asked + lane, nmA, nlA); ask(asked + 64 + lane, nmB, nlB);
+            // What a position would queue if the walk came by -- its literal, its match (LZ77.DeflatorTerm.init(run:distance:),
+            // DeflatorTerm.swift:34-56) -- is worked out for all 128 at once; the walk itself, one position after the other on the
+            // scalar unit, only picks: a run of positions without a match is one vector store of their literals.
+            auto mterm = [&](uint32_t m) -> uint32_t {
+                const uint32_t run = m >> 16, dist = m & 0xffff;
+                const uint32_t rd = run_decade(run ? run : 3u), dd = dist_decade(dist ? dist : 1u);
+                return dd << 27 | 0x100u | rd | dist_extra_value(dist, dd) << 14 | run_extra_value(run, rd) << 9;
+            };
+            const uint32_t tmA = mterm(mA), tmB = mterm(mB), tlA = 0xf8000000u | litA, tlB = 0xf8000000u | litB;
+            const uint32_t runA = mA >> 16, runB = mB >> 16;
+            const unsigned long long nzA = __ballot(runA != 0), nzB = __ballot(runB != 0);
             auto at = [&](uint32_t xa, uint32_t xb, uint32_t t) -> uint32_t {
                 return t < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)xa, (int)t) : (uint32_t)__builtin_amdgcn_readlane((int)xb, (int)(t - 64));
             };
             // ---- the parse: Stream.compress greedy (:209-252) / lazy (:268-323) over these 128 answers
+            const uint32_t avail = stop - w < 128 ? (uint32_t)(stop - w) : 128u;   // positions of this batch that are this round's
             uint32_t t = 0;
-            while (t < 128 && w + t < stop) {
-                if (!(unfilled() > (lazy ? 1 : 0))) close(false);
-                const uint32_t m = at(mA, mB, t);
-                const uint32_t lit = at(litA, litB, t);
-                if (!m) { emit(0xf8000000u | lit); t += 1; continue; }
-                uint32_t use_run = m >> 16, use_dist = m & 0xffff;
-                uint32_t adv = use_run;
+            while (t < avail) {
+                if (count >= cap) close(false);
+                // positions from t on without a match
+                uint32_t L;
+                if (t < 64) { const unsigned long long a = nzA >> t; L = a ? (uint32_t)__builtin_ctzll(a) : 64 - t + (nzB ? (uint32_t)__builtin_ctzll(nzB) : 64u); }
+                else { const unsigned long long b2 = nzB >> (t - 64); L = b2 ? (uint32_t)__builtin_ctzll(b2) : 128 - t; }
+                L = L < avail - t ? L : avail - t;
+                if (L) {
+                    L = L < cap - count ? L : cap - count;     // (the block closes in between: the next turn goes on)
+                    const uint32_t qa = (uint32_t)lane, qb = 64u + (uint32_t)lane;
+                    if (qa >= t && qa < t + L) g_wterms[count + qa - t] = tlA;
+                    if (qb >= t && qb < t + L) g_wterms[count + qb - t] = tlB;
+                    count += L; t += L;
+                    continue;
+                }
+                const uint32_t run = at(runA, runB, t);
                 if (lazy) {
-                    if (t + 1 >= 128) break;                   // (the answer for position w + t + 1: the next batch starts there)
-                    const uint32_t lm = at(mA, mB, t + 1);     // lazy match at a + 1 (:293-299)
-                    if ((lm >> 16) > use_run) {
-                        emit(0xf8000000u | lit);
-                        use_run = lm >> 16; use_dist = lm & 0xffff;
-                        adv = 1 + use_run;
+                    // the answer for position w + t + 1 is needed: the next batch starts there if it is not in this one
+                    if (t + 1 >= 128) break;
+                    // lazy match at a + 1 (:293-299); it exists only if that position is still searched
+                    const uint32_t lrun = at(runA, runB, t + 1);
+                    if (lrun > run) {
+                        const uint32_t a0 = at(tlA, tlB, t), a1 = at(tmA, tmB, t + 1);
+                        if (lane == 0) { g_wterms[count] = a0; g_wterms[count + 1] = a1; }
+                        count += 2; t += 1 + lrun;
+                        continue;
                     }
                 }
-                // LZ77.DeflatorTerm.init(run:distance:) (DeflatorTerm.swift:34-56)
-                const uint32_t rd = run_decade(use_run), dd = dist_decade(use_dist);
-                emit(dd << 27 | 0x100u | rd | dist_extra_value(use_dist, dd) << 14 | run_extra_value(use_run, rd) << 9);
-                t += adv;
+                const uint32_t a0 = at(tmA, tmB, t);
+                if (lane == 0) g_wterms[count] = a0;
+                count += 1; t += run;
             }
             w = uni64(w + t);
         }
@@ -2253,13 +2283,15 @@ __global__ __launch_bounds__(64) void dfl4_walk_kernel(const D3Stream *__restric
     if (!last) {
         // on with the next round: the unfinished block's terms and the position into the state
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        for (int i = lane; i < count; i += 64) state->terms[i] = g_wterms[i];
-        if (lane == 0) { state->w = w; state->count = (uint32_t)count; state->rb = re; state->re = re + D3_RV < E ? re + D3_RV : E; }
+        for (uint32_t i = (uint32_t)lane; i < count; i += 64) state->terms[i] = g_wterms[i];
+        if (lane == 0) { state->w = w; state->count = count; state->rb = re; state->re = re + D3_RV < E ? re + D3_RV : E; }
     } else if (n >= 3) {
         // epilogue: the positions still in the window pipeline become literals (:254-265, :331-342), then the final block
         for (uint64_t p = w; p < n; ++p) {
-            if (!(unfilled() > 0)) close(false);
-            emit(0xf8000000u | UNI(in[p]));
+            if (count >= 2047u) close(false);
+            const uint32_t t = 0xf8000000u | UNI(in[p]);
+            if (lane == 0) g_wterms[count] = t;
+            count += 1;
         }
         close(true);
     }
@@ -2497,7 +2529,7 @@ __device__ __forceinline__ unsigned long long d2_offers(const D2Arrays g, uint32
         const bool use = mine && r >= 3;
         if (use) {
             const uint32_t dec = dist_decade(dist);
-            const uint32_t key = (uint32_t)s.depths[512 + dec] << 20 | dec << 15 | dist;
+            const uint32_t key = (uint32_t)g_full.depths[512 + dec] << 20 | dec << 15 | dist;
             atomicMin(&g_ptab[ln * D2_PSTRIDE + (r < 66 ? r : 66u) - 3], key);
         }
         // vertices with a run beyond the table
@@ -2534,7 +2566,7 @@ __device__ __forceinline__ void d2_relax_long(const D2Arrays g, uint64_t vr, uin
     const uint32_t rem = count - vv;
     const uint32_t run = w & 0x1ff, dist = (w >> 9) & 0x7fff, dec = dist ? dist_decade(dist) : 0u;
     const uint32_t r = run < rem ? run : rem;
-    const uint32_t dcost = s.depths[512 + dec];
+    const uint32_t dcost = g_full.depths[512 + dec];
     unsigned long long m = __ballot((uint32_t)lane < cnt && r >= 3);
     uint32_t bc[4] = {~0u, ~0u, ~0u, ~0u}, bd[4] = {0, 0, 0, 0}, reach = 0;
     while (m) {
@@ -2557,7 +2589,7 @@ __device__ __forceinline__ void d2_relax_long(const D2Arrays g, uint64_t vr, uin
         const uint32_t L = 3u + (uint32_t)lane + 64u * j;
         if (bc[j] != ~0u) {
             const uint64_t key = (uint64_t)(Dk + bc[j] + rc[j]) << 32 | (258u - L) << 23 | (bd[j] + (1u << 15));
-            __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min(&g_full.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
@@ -2587,11 +2619,11 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
     DLds &s = g_lds;
     uint32_t rc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const uint32_t L = 3u + (uint32_t)lane + 64u * j; rc[j] = L <= 258 ? s.depths[253 + L] : 0u; }
+    for (int j = 0; j < 4; ++j) { const uint32_t L = 3u + (uint32_t)lane + 64u * j; rc[j] = L <= 258 ? g_full.depths[253 + L] : 0u; }
     // (packed groups: lane = 21 * (vertex of the group) + (length - 3))
     const uint32_t pq = (uint32_t)lane / 21, pl = (uint32_t)lane % 21;
-    const uint32_t rcp = s.depths[253 + 3 + pl];
-    if (lane == 0) s.win[0] = 0;                               // vertex 0: depth 0
+    const uint32_t rcp = g_full.depths[253 + 3 + pl];
+    if (lane == 0) g_full.win[0] = 0;                               // vertex 0: depth 0
     const int sh = (int)(vr0 & 63);
     const uint64_t qbase = vr0 >> 6;
     const uint32_t nb = ((uint32_t)sh + count + 64) >> 6;      // batches that hold the vertices 0 .. count (the last one: the end)
@@ -2629,7 +2661,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
         lb_next = lit_of(v + 64);
         r_em = j + 2 < nb ? g.emask[j + 2] : 0ull;
         r_bw = g.bwords[qbase + j + 2]; r_bb = g.bbase[qbase + j + 2];
-        const uint32_t cin = (v >= 1 && (uint32_t)v <= count) ? s.depths[lb] : 0u;     // the literal edge INTO v
+        const uint32_t cin = (v >= 1 && (uint32_t)v <= count) ? g_full.depths[lb] : 0u;     // the literal edge INTO v
         if (!em && base > pend && (uint32_t)(base + 63) < count) {
             // Literals only -- and so, in incompressible data, are the batches behind it: the whole run in one tight loop (a
             // literal load, a cost look-up and an add per batch; one sum over the wave at its end).
@@ -2646,7 +2678,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
                 for (uint32_t i = 1; i <= z; ++i) {
                     const uint32_t lbc = q0;
                     q0 = q1; q1 = q2; q2 = q3; q3 = lit_of(v + 64 * (int)(i + 4));
-                    acc += s.depths[lbc];
+                    acc += g_full.depths[lbc];
                 }
             }
             carry += wave_total(acc);
@@ -2671,7 +2703,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
         const uint32_t top = (uint32_t)(base + 64 + 258);
         const uint32_t need = (top < count ? top : count) + 1;
         if (need > inited + 512) inited = need - 512;          // (behind a stretch of literals: nothing older is alive)
-        for (uint32_t q = inited + lane; q < need; q += 64) s.win[q & 511] = ~0ull;
+        for (uint32_t q = inited + lane; q < need; q += 64) g_full.win[q & 511] = ~0ull;
         inited = inited > need ? inited : need;
         unsigned long long longm = 0;
         uint32_t cols = 0;
@@ -2683,7 +2715,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
 #ifdef SPNG_DEFLATE_PROF
         if (threadIdx.x == 0) g_prof[9] += __builtin_readcyclecounter() - o_t0;
 #endif
-        uint64_t W = act ? s.win[(uint32_t)v & 511] : ~0ull;
+        uint64_t W = act ? g_full.win[(uint32_t)v & 511] : ~0ull;
         uint32_t Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
         uint32_t D = minplus_scan(cin, Wd, carry, lane);
         uint32_t k = 0;
@@ -2720,7 +2752,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
 #endif
                 const uint32_t pk = *(const uint32_t *)((const uint8_t *)g_ptab + kk * (D2_PSTRIDE * 4) + rowc);
                 if (dirty) {
-                    W = act ? s.win[(uint32_t)v & 511] : ~0ull;
+                    W = act ? g_full.win[(uint32_t)v & 511] : ~0ull;
                     Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
                 }
                 const uint32_t k1 = kk + 1 < 63 ? kk + 1 : 63, k2 = kk + 2 < 63 ? kk + 2 : 63;
@@ -2736,7 +2768,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
                 if ((m3 & pqbit) && pk != ~0u) {
                     const uint32_t Dq = pq == 0 ? D0 : pq == 1 ? D1 : D2;
                     const uint64_t key = (uint64_t)(Dq + (pk >> 20) + rcp) << 32 | ((pk & 0xfffffu) + klo_c);
-                    __hip_atomic_fetch_min(&s.win[((uint32_t)(base + (int)kk) + ac) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_min(&g_full.win[((uint32_t)(base + (int)kk) + ac) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 {
                     const int reach = base + (int)kk + 2 + (int)cols + 2;
@@ -2770,7 +2802,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
 #pragma unroll
             for (int q = 0; q < 3; ++q) row[q] = ((uint32_t)lane < cols && kk + q < 64) ? g_ptab[(kk + q) * D2_PSTRIDE + lane] : ~0u;
             if (dirty) {
-                W = act ? s.win[(uint32_t)v & 511] : ~0ull;
+                W = act ? g_full.win[(uint32_t)v & 511] : ~0ull;
                 Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
                 if (kk + 3 - k <= 8) {
                     const uint32_t hi = kk + 2 < 63 ? kk + 2 : 63;
@@ -2796,7 +2828,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
                     if (pk != ~0u) {
                         const uint32_t L = 3u + (uint32_t)lane;
                         const uint64_t key = (uint64_t)(Dk + (pk >> 20) + rc[0]) << 32 | (258u - L) << 23 | ((pk & 0xfffffu) + (1u << 15));
-                        __hip_atomic_fetch_min(&s.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_min(&g_full.win[(vv + L) & 511], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     pend = (int)(vv + cols + 2) > pend ? (int)(vv + cols + 2) : pend;
                 }
@@ -2807,7 +2839,7 @@ __device__ __attribute__((noinline)) void d2_forward(const D2Arrays g_, const gb
             asm volatile("" ::: "memory");
         }
         if (dirty) {
-            W = act ? s.win[(uint32_t)v & 511] : ~0ull;
+            W = act ? g_full.win[(uint32_t)v & 511] : ~0ull;
             Wd = (uint32_t)(W >> 32) < DINF ? (uint32_t)(W >> 32) : DINF;
             D = minplus_scan(cin, Wd, carry, lane);
         }
@@ -2975,8 +3007,8 @@ __device__ __attribute__((noinline)) Bits d2_block(Bits b_, const D2Arrays g_, c
     FPROF(6);
     // resetGraph -> Depths.generalize (Depths.swift:88-98)
     for (uint32_t i = lane; i < 542; i += 64) {
-        const uint32_t x = s.depths[i], d = depth_default(i);
-        s.depths[i] = (uint8_t)((x & d) + ((x ^ d) >> 1));
+        const uint32_t x = g_full.depths[i], d = depth_default(i);
+        g_full.depths[i] = (uint8_t)((x & d) + ((x ^ d) >> 1));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     return b;
@@ -3024,9 +3056,9 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
             // Gzip.StreamHeader.write (Gzip.StreamHeader.swift:84-96); the trailer is appended by gzip.hip
             put(s, b, 0x8b1f, 16, lane); put(s, b, 0x0008, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0, 16, lane); put(s, b, 0xff00, 16, lane);
         }
-        for (uint32_t i = lane; i < 542; i += 64) s.depths[i] = (uint8_t)depth_default(i);
+        for (uint32_t i = lane; i < 542; i += 64) g_full.depths[i] = (uint8_t)depth_default(i);
     } else {
-        for (uint32_t i = lane; i < 542; i += 64) s.depths[i] = state->depths[i];
+        for (uint32_t i = lane; i < 542; i += 64) g_full.depths[i] = state->depths[i];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 
@@ -3090,7 +3122,7 @@ __global__ __launch_bounds__(64) void dfl2_parse_kernel(const D2Stream *__restri
     D2_PROF_PRINT();
     // the next round
     drain(s, b, b.total, lane);
-    for (uint32_t i = lane; i < 542; i += 64) state->depths[i] = s.depths[i];
+    for (uint32_t i = lane; i < 542; i += 64) state->depths[i] = g_full.depths[i];
     if (lane == 0) {
         state->acc = b.acc; state->nacc = b.nacc; state->total = b.total; state->overflow = b.overflow ? 1u : 0u;
         state->pos = pos; state->limit = limit; state->generic = generic ? 1u : 0u;

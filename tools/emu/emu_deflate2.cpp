@@ -90,9 +90,20 @@ int main(int argc, char **argv)
                 emu::launch(1, 256, [&] { dfl3_advance_kernel(&st, 1); });
                 if (blocks) {
                     emu::launch(1, 64, [&] { dfl4_walk_kernel(&st, par); });
-                    emu::launch(maxb, 64, [&] { dfl4_block_kernel(&st); });
+                    if (getenv("EMU_DUMP_TERMS")) {
+                        std::ofstream o(getenv("EMU_DUMP_TERMS"), std::ios::binary);
+                        const uint32_t nbk = bdesc[0]; uint32_t tot = 0;
+                        for (uint32_t k = 0; k < nbk; ++k) tot += bdesc[5 + 2 * k] & 0x7fffffffu;
+                        o.write((const char *)&nbk, 4); o.write((const char *)bdesc.data(), 4 * (4 + 2 * (size_t)nbk));
+                        o.write((const char *)&tot, 4); o.write((const char *)terms.data(), 4 * (size_t)tot);
+                        const uint32_t nm = (uint32_t)(n + 1); o.write((const char *)&nm, 4); o.write((const char *)match[par].data(), 4 * (size_t)nm);
+                    }
+                    // (the product launches the worst case of blocks -- the host does not know their number -- and the idle ones return at
+                    //  once; here only the ones the walk made, + 1 idle: a workgroup costs the emulator 64 fibers)
+                    const uint32_t grid = bdesc[0] + 1 < maxb ? bdesc[0] + 1 : maxb;
+                    emu::launch(grid, 64, [&] { dfl4_block_kernel(&st); });
                     emu::launch(1, 256, [&] { dfl4_scan_kernel(&st, maxb, &res); });
-                    emu::launch(maxb, 64, [&] { dfl4_place_kernel(&st, maxb); });
+                    emu::launch(grid, 64, [&] { dfl4_place_kernel(&st, maxb); });
                 } else emu::launch(1, 128, [&] { dfl3_parse_kernel(&st, &res, par); });
             }
             if (st.more && res.status != SPNG_NEED_MORE_INPUT) { printf("call %zu (more): status %d\n", call, res.status); return 1; }
