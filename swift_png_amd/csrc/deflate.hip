@@ -1507,6 +1507,10 @@ uint64_t deflate2_vertices(uint64_t n) { return ((n < D2_RV ? n : D2_RV) + 63) /
 // (121 KB: a search workgroup and ONE parse wave -- 38 KB -- share a CU, so that in batches of up to 256 streams the search of
 //  round r + 1 runs beside the parse of round r; 2^14 heads and 4 K of lead -- 144 KB -- measured the same on incompressible input)
 static constexpr uint32_t D3_R = 34816, D3_MIR = 320;           // ring positions (a multiple of 256), mirrored bytes
+// (levels 0-7 have no 38 KB parse wave to share the CU with -- the walk wave needs 8 KB --, and their searchers' batches differ
+//  much more in cost (64 to 100 candidates each): 8 K positions of lead instead of 2 K keep the inserter from waiting on the
+//  slowest batch and the other searchers from waiting on the inserter -- 139 KB)
+static constexpr uint32_t D3_R_FAST = 40960;
 static constexpr uint32_t D3_FAR = 40000;                       // where a head too old for the window is kept (+ 2^14 between two sweeps: < 2^16)
 #ifndef SPNG_D3_WAVES
 #define SPNG_D3_WAVES 16
@@ -1514,9 +1518,11 @@ static constexpr uint32_t D3_FAR = 40000;                       // where a head 
 #ifndef SPNG_D3_HBITS
 #define SPNG_D3_HBITS 13
 #endif
-struct D3Lds {
-    union { uint8_t in[D3_R + D3_MIR]; uint32_t in32[(D3_R + D3_MIR) / 4]; };
-    uint16_t link[D3_R];
+template <uint32_t R_>
+struct D3LdsT {
+    static constexpr uint32_t R = R_;                          // ring positions (a multiple of 256)
+    union { uint8_t in[R_ + D3_MIR]; uint32_t in32[(R_ + D3_MIR) / 4]; };
+    uint16_t link[R_];
     uint16_t head[(1u << SPNG_D3_HBITS) + 64];                  // (+ a spare slot for idle lanes)
     uint32_t cur[SPNG_D3_WAVES];                                // the batch each wave is at (~0: none any more)
     uint32_t staged, inserted, next, pad;                       // positions (relative to the warm-up's first) below which bytes / links stand; batches claimed
@@ -1533,20 +1539,26 @@ struct D3Lds {
 #define D3P_ADD(k) ((void)0)
 #define D3P_CNT(k, v) ((void)0)
 #endif
+typedef D3LdsT<D3_R> D3Lds;                                     // levels >= 8: 121 KB, beside a parse wave
+typedef D3LdsT<D3_R_FAST> D3LdsFast;                           // levels 0-7: 8 K positions of lead
 __shared__ __attribute__((aligned(16))) D3Lds g_d3;
+__shared__ __attribute__((aligned(16))) D3LdsFast g_d3f;
 
 // four / eight input bytes at ring offset `off` (any alignment; the mirror makes them contiguous)
-__device__ __forceinline__ uint32_t d3_u32(const D3Lds &s, uint32_t off)
+template <class L>
+__device__ __forceinline__ uint32_t d3_u32(const L &s, uint32_t off)
 {
     const uint32_t w = off >> 2;
     return __builtin_amdgcn_alignbyte(s.in32[w + 1], s.in32[w], off & 3);
 }
-__device__ __forceinline__ uint64_t d3_u64(const D3Lds &s, uint32_t off)
+template <class L>
+__device__ __forceinline__ uint64_t d3_u64(const L &s, uint32_t off)
 {
     const uint32_t w = off >> 2, a = s.in32[w], b = s.in32[w + 1], c = s.in32[w + 2];
     return (uint64_t)__builtin_amdgcn_alignbyte(c, b, off & 3) << 32 | __builtin_amdgcn_alignbyte(b, a, off & 3);
 }
-__device__ __forceinline__ uint32_t d3_common_prefix(const D3Lds &s, uint32_t q, uint32_t p, uint32_t limit)
+template <class L>
+__device__ __forceinline__ uint32_t d3_common_prefix(const L &s, uint32_t q, uint32_t p, uint32_t limit)
 {
     uint32_t i = 0;
     while (i + 8 <= limit) {
@@ -1574,7 +1586,8 @@ __device__ __forceinline__ uint32_t d3_common_prefix(const D3Lds &s, uint32_t q,
 #else
 #define D3_MEET() ((void)0)
 #endif
-__device__ __forceinline__ void d3_insert(D3Lds &s, uint32_t rel, uint32_t idx, uint32_t key, uint64_t p0, uint32_t pm, uint64_t n, bool sum, uint32_t &accS, uint32_t &accI, int lane)
+template <class L>
+__device__ __forceinline__ void d3_insert(L &s, uint32_t rel, uint32_t idx, uint32_t key, uint64_t p0, uint32_t pm, uint64_t n, bool sum, uint32_t &accS, uint32_t &accI, int lane)
 {
     const uint64_t p = p0 + lane;
     const bool live = p + 4 <= n;                              // the last three positions never start a match
@@ -1616,13 +1629,13 @@ __device__ __forceinline__ void d3_insert(D3Lds &s, uint32_t rel, uint32_t idx, 
 // One chunk [c0, c1) of a stream's positions on one workgroup.  rb: the round's first position (records are kept in round
 // coordinates); extra: the last `extra` positions are searched but not summed (the next chunk's: a lazy parse looks one ahead).  FULL: vinfo / bbase / bwords / pool (what dfl2_parse_kernel reads); else match[position - rb] = run << 16 | distance
 // (0: no run > 5).  temp: SPNG_D3_WAVES x 30 x 64 words of global scratch of this workgroup (FULL).
-template <bool FULL>
-__device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uint64_t rb, uint64_t c0, uint64_t c1, uint32_t extra, int attempts, int goal, uint32_t wmask,
+template <bool FULL, class L>
+__device__ __forceinline__ void d3_search_chunk(L &s, const gbyte *in, uint64_t n, uint64_t rb, uint64_t c0, uint64_t c1, uint32_t extra, int attempts, int goal, uint32_t wmask,
                                                 uint32_t *adlerS, uint32_t *adlerI, uint32_t *fail,
                                                 uint16_t *vinfo, uint64_t *bbase, uint32_t *bwords, uint32_t *pool, unsigned long long *pool_next, uint64_t pool_cap,
                                                 uint32_t *temp, uint32_t *match)
 {
-    D3Lds &s = g_d3;
+    constexpr uint32_t D3R = L::R;
     const int lane = threadIdx.x & 63, wave = (int)UNI(threadIdx.x >> 6);
     const uint64_t warm = (c0 >= 32768 ? c0 - 32768 : 0) & ~(uint64_t)255;       // first position entered into the window
     const uint32_t c0r = (uint32_t)(c0 - warm), c1r = (uint32_t)(c1 - warm);
@@ -1653,7 +1666,7 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
         auto put_step = [&](uint32_t sidx, uint32_t v) {       // 256 bytes into ring slot sidx (a multiple of 256)
             const uint32_t o = sidx + 4u * (uint32_t)lane;
             s.in32[o >> 2] = v;
-            if (o < D3_MIR) s.in32[(D3_R + o) >> 2] = v;
+            if (o < D3_MIR) s.in32[(D3R + o) >> 2] = v;
         };
         uint32_t staged = 0, sidx = 0;                         // bytes in the ring; the ring slot of the next step
         uint32_t q0 = fetch(0), q1 = fetch(256), q2 = fetch(512), q3 = fetch(768);
@@ -1664,24 +1677,24 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
         uint32_t iidx = 0;
         uint32_t pm = (uint32_t)((warm + (uint32_t)lane) % 65521);      // this lane's position in the batch at hand, mod 65521
         // one more step of 256 bytes into the ring -- never beyond what the slowest searcher still needs: the slot of position x
-        // is x + D3_R's, and a batch looks back 32767 positions
+        // is x + D3R's, and a batch looks back 32767 positions
         auto stage_step = [&]() {
             {
                 D3P_T0();
                 SpinGuard guard;
-                while (staged + 256 > c0r + 64u * smin + (D3_R - 32768)) {
+                while (staged + 256 > c0r + 64u * smin + (D3R - 32768)) {
                     uint32_t v = (uint32_t)lane < SPNG_D3_WAVES ? __hip_atomic_load(&s.cur[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
                                : lane == SPNG_D3_WAVES ? __hip_atomic_load(&s.next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0u;
 #pragma unroll
                     for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64); v = o < v ? o : v; }
                     smin = UNI(v);
-                    if (staged + 256 <= c0r + 64u * smin + (D3_R - 32768)) break;
+                    if (staged + 256 <= c0r + 64u * smin + (D3R - 32768)) break;
                     __builtin_amdgcn_s_sleep(4);
                     guard.tick();
                 }
                 D3P_ADD(0);
                 put_step(sidx, q0);
-                staged += 256; sidx = sidx + 256 >= D3_R ? 0 : sidx + 256;
+                staged += 256; sidx = sidx + 256 >= D3R ? 0 : sidx + 256;
                 q0 = q1; q1 = q2; q2 = q3; q3 = fetch(fetched); fetched += 256;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
                 if (lane == 0) __hip_atomic_store(&s.staged, staged, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1707,7 +1720,7 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
 #pragma unroll 1
             for (uint32_t k = 0; k < 256 && i + k < c1r; k += 64) {
                 const uint32_t rel = i + k;
-                const uint32_t key = key_next, nidx = iidx + 64 >= D3_R ? 0 : iidx + 64;
+                const uint32_t key = key_next, nidx = iidx + 64 >= D3R ? 0 : iidx + 64;
                 key_next = d3_u32(s, nidx + (uint32_t)lane);   // (keys travel a batch ahead: bytes below rel + 131, and i + 512 are staged)
                 d3_insert(s, rel, iidx, key, warm + rel, pm, n, rel + (uint32_t)lane >= c0r && rel + (uint32_t)lane < c1r - extra, accS, accI, lane);
                 iidx = nidx;
@@ -1748,7 +1761,7 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
         }
         D3P_T0();
         uint32_t p_hops = 0, p_cmp = 0;
-        const uint32_t rel = p0r + (uint32_t)lane, idx0 = UNI(p0r % D3_R) + (uint32_t)lane, idx = idx0 >= D3_R ? idx0 - D3_R : idx0;
+        const uint32_t rel = p0r + (uint32_t)lane, idx0 = UNI(p0r % D3R) + (uint32_t)lane, idx = idx0 >= D3R ? idx0 - D3R : idx0;
         const uint64_t p = warm + rel;
         const bool inchunk = rel < c1r, live = inchunk && p < last_main;
         const uint32_t key = d3_u32(s, idx);
@@ -1765,7 +1778,7 @@ __device__ __forceinline__ void d3_search_chunk(const gbyte *in, uint64_t n, uin
 #endif
             acc += d;
             if (acc > wmask || (!first && acc >= wmask)) break;
-            const uint32_t cidx = idx >= acc ? idx - acc : idx + D3_R - acc;
+            const uint32_t cidx = idx >= acc ? idx - acc : idx + D3R - acc;
             const uint32_t e = s.link[cidx];
             if (d3_u32(s, cidx) == key) {
                 // A run that does not exceed the longest one seen (FULL: of its decade) changes nothing -- only a strictly longer
@@ -1849,7 +1862,7 @@ __global__ __launch_bounds__(SPNG_D3_WAVES * 64) void dfl3_search_kernel(const D
     // DeflatorSearch.init(level:) (:13-35), full rows
     const int attempts = lv == 8 ? 14 : lv == 9 ? 20 : lv == 10 ? 30 : lv == 11 ? 60 : lv == 12 ? 100 : 0x7fffffff;
     const int goal = lv == 8 ? 20 : lv == 9 ? 32 : lv == 10 ? 50 : lv == 11 ? 80 : lv == 12 ? 133 : 258;
-    d3_search_chunk<true>((const gbyte *)uni64((uint64_t)st.src), n, rb, c0, c1, 0, attempts, goal, (1u << UNI(st.exponent)) - 1,
+    d3_search_chunk<true>(g_d3, (const gbyte *)uni64((uint64_t)st.src), n, rb, c0, c1, 0, attempts, goal, (1u << UNI(st.exponent)) - 1,
                           &state->adlerS, &state->adlerI, &state->fail,
                           (uint16_t *)uni64((uint64_t)(parity ? st.vinfo2 : st.vinfo)), (uint64_t *)uni64((uint64_t)(parity ? st.bbase2 : st.bbase)),
                           (uint32_t *)uni64((uint64_t)(parity ? st.bwords2 : st.bwords)), pool, pool_next, pool_cap,
@@ -1912,7 +1925,7 @@ __global__ __launch_bounds__(SPNG_D3_WAVES * 64) void dfl3_search_fast_kernel(co
     const int lv = level & 7;
     const int attempts = lv == 0 ? 1 : lv == 1 ? 2 : lv == 2 ? 4 : lv == 3 ? 40 : lv == 4 ? 20 : lv == 5 ? 40 : lv == 6 ? 64 : 100;
     const int goal = lv == 0 ? 6 : lv == 1 ? 8 : lv == 2 ? 10 : lv == 3 ? 24 : lv == 4 ? 32 : lv == 5 ? 54 : lv == 6 ? 80 : 160;
-    d3_search_chunk<false>((const gbyte *)uni64((uint64_t)st.src), n, rb, c0, c1, extra, attempts, goal, (1u << UNI(st.exponent)) - 1,
+    d3_search_chunk<false>(g_d3f, (const gbyte *)uni64((uint64_t)st.src), n, rb, c0, c1, extra, attempts, goal, (1u << UNI(st.exponent)) - 1,
                            &state->adlerS, &state->adlerI, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
                            (uint32_t *)uni64((uint64_t)st.match[parity]));
 }
