@@ -47,7 +47,7 @@ typedef U32u __attribute__((address_space(1))) gU32u;
 
 static constexpr int HBITS = 13;                 // bucket heads in LDS
 static constexpr uint32_t NONE = 0xffffffffu;
-static constexpr int OUTB = 8192;                // output staging ring (bytes, power of two)
+static constexpr int OUTB = 2048;                // output staging ring (bytes, power of two; at most half of it + the ~600 bytes of a block's tables stand undrained)
 
 // LZ77.Composites.swift:25-110 in closed form (table loads from HBM would sit on the serial path):
 // number of extra bits of a run / distance decade, and the extra-bit value of a run / distance.
@@ -1510,7 +1510,10 @@ static constexpr uint32_t D3_R = 34816, D3_MIR = 320;           // ring position
 // (levels 0-7 have no 38 KB parse wave to share the CU with -- the walk wave needs 8 KB --, and their searchers' batches differ
 //  much more in cost (64 to 100 candidates each): 8 K positions of lead instead of 2 K keep the inserter from waiting on the
 //  slowest batch and the other searchers from waiting on the inserter -- 139 KB)
-static constexpr uint32_t D3_R_FAST = 40960;
+#ifndef SPNG_D3_R_FAST
+#define SPNG_D3_R_FAST 40960
+#endif
+static constexpr uint32_t D3_R_FAST = SPNG_D3_R_FAST;
 static constexpr uint32_t D3_FAR = 40000;                       // where a head too old for the window is kept (+ 2^14 between two sweeps: < 2^16)
 #ifndef SPNG_D3_WAVES
 #define SPNG_D3_WAVES 16

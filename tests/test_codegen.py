@@ -128,9 +128,18 @@ def test_deflate_kernel_resources():
     parse = [v for k, v in table.items() if "dfl2_parse_kernel" in k]
     parse3 = [v for k, v in table.items() if "dfl3_parse_kernel" in k]
     assert len(search) == 2 and len(parse) == 1 and len(parse3) == 1
-    for v in search:
+    walk = [v for k, v in table.items() if "dfl4_walk_kernel" in k]
+    block = [v for k, v in table.items() if "dfl4_block_kernel" in k]
+    assert len(walk) == 1 and len(block) == 1
+    for k, v in table.items():
+        if "dfl3_search" not in k:
+            continue
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 and v["vgpr_count"] <= 128 and v["max_flat_workgroup_size"] == 1024
-        assert v["group_segment_fixed_size"] + parse[0]["group_segment_fixed_size"] <= 163840
+        if "fast" in k:     # levels 0-7: beside it a walk wave and a block wave of the round before
+            assert v["group_segment_fixed_size"] + walk[0]["group_segment_fixed_size"] + block[0]["group_segment_fixed_size"] <= 163840
+        else:               # levels >= 8: beside it one parse wave
+            assert v["group_segment_fixed_size"] + parse[0]["group_segment_fixed_size"] <= 163840
+    assert block[0]["group_segment_fixed_size"] <= 10752 and block[0]["private_segment_fixed_size"] <= 64      # fifteen block waves per CU
     # (scratch: 384 bytes, the by-value argument structs of the non-inlined passes at their call sites -- a few per block -- and
     #  callee-saved registers; nothing inside the passes' loops)
     assert parse[0]["group_segment_fixed_size"] <= 40960 and parse[0]["private_segment_fixed_size"] <= 512 and parse[0]["max_flat_workgroup_size"] == 64
