@@ -42,7 +42,7 @@ DEPTH, CHANNELS = 8, 4
 MPIX = W * H / 1e6
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 STAGES = ("pinf_find", "pinf_decode", "pinf_resolve", "inflate", "unfilter")
-PMC_FILE = "r04_pmc_traffic.json"      # rocprofv3 --pmc passes of this very workload (tools/final_run.sh), committed
+PMC_FILE = "r05_pmc_traffic.json"      # rocprofv3 --pmc passes of this very workload (tools/final_run.sh), committed
 
 
 def build_inputs(session, unique: int, threads: int, encoder: str):

@@ -118,6 +118,17 @@ def run_encode(args, torch, dist, spng, s, rank, world, rasters_kind="random"):
                     "frac_of_hbm_peak": round((n * U + total_c) / (prof["deflate"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)},
     }
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    # HBM traffic of the deflate kernels from the committed rocprofv3 --pmc passes of this workload's deflate step (1024 random
+    # 64 MiB streams at level 9: profiles/r05_pmc_encode.json, tools/final_run.sh); FETCH_SIZE x 2 as on the decode side
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.loads((ROOT / "profiles" / "r05_pmc_encode.json").read_text())
+        if rasters_kind == "random" and args.level == 9 and pmc.get("streams") == args.images and dom == "deflate":
+            traffic = int(pmc["deflate_hbm_bytes_per_step"])
+            traffic_src = "profiles/r05_pmc_encode.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same 1024 x 64 MiB level-9 deflate, not measured in this run)"
+            kernels["deflate"]["traffic_by_kernel"] = pmc.get("kernels")
+    except (OSError, KeyError, ValueError):
+        pass
     # the two kernels of a round (both inside "deflate", at every level since round 5): the chip-wide match search reads U, the
     # one-wave-per-stream parse reads U (levels 0-7: and the search's 4 bytes per position) and writes C
     kernels["deflate"]["search_ms"] = round(prof["dfl_search"], 3)
@@ -132,8 +143,8 @@ def run_encode(args, torch, dist, spng, s, rank, world, rasters_kind="random"):
                    "unique_images": unique,
                    "compressed_ratio": round(n * U / total_c, 4)},
         "roofline": {"bound": "hbm", "kernel": dom + "_kernel", "achieved": kernels[dom]["gbps"], "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None,
-                     "ms_per_launch": kernels[dom]["ms_per_step"]},
+                     "unit": "GB/s", "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": traffic,
+                     "ms_per_launch": kernels[dom]["ms_per_step"], **({"traffic_source": traffic_src} if traffic_src else {})},
         "kernels": kernels,
     }
     if world == 1 and not args.no_cpu_baseline:

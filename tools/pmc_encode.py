@@ -1,0 +1,35 @@
+"""Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/probe_deflate2.py (PROBE_WHICH=random PROBE_N=<streams>: a
+warm-up call and a timed one of spng_deflate_batch at level 9 over <streams> random 64 MiB buffers -- the deflate step of
+BASELINE configs[3]) into profiles/r05_pmc_encode.json, which bench_encode.py reads `encode.roofline.traffic` from.
+
+    python tools/pmc_encode.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <streams> <out.json>
+
+Units KiB; FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for gfx950 (16-byte-per-lane reads); per step = the sums / 2."""
+import csv, glob, json, re, sys
+
+
+def collect(d, counter):
+    out = {}
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter or "dfl" not in row["Kernel_Name"]:
+                continue
+            name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void spng::", "").replace("spng::", "")
+            e = out.setdefault(name, [0.0, 0])
+            e[0] += float(row["Counter_Value"]); e[1] += 1
+    return out
+
+
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+streams, dst = int(sys.argv[3]), sys.argv[4]
+kernels, total = {}, 0
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, [0, 0]), write.get(k, [0, 0])
+    b = int((2 * f[0] + w[0]) * 1024 / 2)
+    kernels[k] = {"FETCH_SIZE_KiB_per_step": f[0] / 2, "WRITE_SIZE_KiB_per_step": w[0] / 2, "launches_per_step": f[1] // 2, "hbm_bytes_per_step": b}
+    total += b
+doc = {"note": "rocprofv3 --kernel-trace --pmc <counter> -- python tools/probe_deflate2.py (PROBE_WHICH=random, level 9): one counter per pass; "
+               "a warm-up call and a timed call, figures per call; FETCH_SIZE x 2", "streams": streams, "kernels": kernels,
+       "deflate_hbm_bytes_per_step": total}
+json.dump(doc, open(dst, "w"), indent=1)
+print(json.dumps(doc, indent=1))

@@ -1,7 +1,7 @@
 """Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one bench.py step into
-profiles/r04_pmc_traffic.json (the file bench.py reads `roofline.traffic` / `kernels.*.traffic` from).
+profiles/r05_pmc_traffic.json (the file bench.py reads `roofline.traffic` / `kernels.*.traffic` from).
 
-    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <kind> <images> <unique> <out.json>
+    python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <kind> <images> <unique> <out.json> [<decode steps in the run>]
 
 The passes run `python bench.py --steps 1 --warmup 0 --no-swiftpng --no-cpu-baseline --no-extras [--streams <kind>]`, i.e. the very
 workload of the headline line, one decode step; every launch of a kernel inside that step is summed ("per launch" =
@@ -33,6 +33,12 @@ def collect(d, counter):
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 kind, images, unique, dst = sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+# (round 5: the passes run a warm-up step and a timed one -- the first call of a context sizes its token pool differently --, so
+#  the sums are over `nsteps` decode steps and the figures per step are the sums divided by it; `launches` likewise)
+nsteps = int(sys.argv[7]) if len(sys.argv) > 7 else 1
+for tab in (fetch, write):
+    for e in tab.values():
+        e["value"] /= nsteps; e["launches"] = round(e["launches"] / nsteps)
 doc = json.load(open(dst)) if os.path.exists(dst) else {
     "note": "rocprofv3 --kernel-trace --pmc <counter> -- python bench.py --steps 1 --warmup 0 --no-swiftpng --no-cpu-baseline "
             "[--streams <kind>]; one counter per pass; units KiB; FETCH_SIZE x 2 (MI355X_MICROARCH.md, gfx950); summed over "
