@@ -525,9 +525,10 @@ def run_scanline_formats(torch, spng, s, n=256):
         U = spng.inflated_size(W, H, depth, ch, False)
         S = spng.storage_size(W, H, depth, ch)
         unique = 4
-        base = [synth.image(500 + k, W, H) for k in range(unique)]
+        base = [synth.image(500 + k, W, H).reshape(H, W, 4) for k in range(unique)]
         if depth == 8:
-            srcs = [s.to_device(im[..., :3].tobytes()) for im in base]
+            import numpy as np
+            srcs = [s.to_device(np.ascontiguousarray(im[..., :3]).tobytes()) for im in base]
         else:
             import numpy as np
             srcs = [s.to_device(np.repeat(im[..., :3], 2, axis=-1).tobytes()) for im in base]   # (big-endian samples v << 8 | v)

@@ -147,7 +147,10 @@ __device__ void filter_row_fast(const uint8_t *cur, const uint8_t *up, uint32_t 
     for (int f = 1; f < 5; ++f) if (sc[f] < minimum) { minimum = sc[f]; best = f; }   // first strict minimum
     if (lane == 0) out[0] = (uint8_t)best;
     cz = cw = uz = uw = 0;
-    for (uint32_t it = 0; it < steps; ++it) {
+    const uint32_t sft = UNI((uint32_t)((uintptr_t)(out + 1) & 15));     // the row's data starts this far behind a 16-byte boundary
+    uint32_t carry[4] = {0, 0, 0, 0};
+    const uint32_t steps2 = (pitch + 16) / 1024 + ((pitch + 16) % 1024 ? 1 : 0);   // (one unit more: the row's tail sits in the lane behind its last)
+    for (uint32_t it = 0; it < steps2; ++it) {
         const uint32_t j = (it * 64 + lane) * 16;
         const bool live = j < pitch;
         u32x4 x = {0, 0, 0, 0}, b = {0, 0, 0, 0};
@@ -157,6 +160,7 @@ __device__ void filter_row_fast(const uint8_t *cur, const uint8_t *up, uint32_t 
         cz = (uint32_t)__builtin_amdgcn_readlane((int)x.z, 63); cw = (uint32_t)__builtin_amdgcn_readlane((int)x.w, 63);
         uz = (uint32_t)__builtin_amdgcn_readlane((int)b.z, 63); uw = (uint32_t)__builtin_amdgcn_readlane((int)b.w, 63);
         const u32x4 a = shifted<BPP>(x, pz, pw), c = shifted<BPP>(b, qz, qw);
+        uint32_t rr[4] = {0, 0, 0, 0};
         if (live) {
             const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, as[4] = {a.x, a.y, a.z, a.w};
             const uint32_t bs[4] = {b.x, b.y, b.z, b.w}, cs[4] = {c.x, c.y, c.z, c.w};
@@ -170,8 +174,38 @@ __device__ void filter_row_fast(const uint8_t *cur, const uint8_t *up, uint32_t 
                 else if (best == 4) pred = paeth8(as[k], bs[k], cs[k]);
                 r[k] = sub8(xs[k], pred);
             }
-            u32x4 v; v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3];
-            ((U128u *)(out + 1 + j))->v = v;
+            rr[0] = r[0]; rr[1] = r[1]; rr[2] = r[2]; rr[3] = r[3];
+        }
+        // ---- the store.  The scanline stream puts a row pitch + 1 bytes behind the one before, so a lane's 16 bytes never start on
+        // a 16-byte boundary: stored as they are, every 128-byte line is written in pieces by two instructions (the pattern that
+        // cost the unfilter kernel a third of its bandwidth).  Instead every lane stores the ALIGNED 16 bytes that end
+        // inside its own: the last `sft` bytes of the lane above (DPP; lane 63 of the step before for lane 0) and its own first
+        // 16 - sft.  The row's first and last partial units -- shared with the neighbouring rows, other waves' -- go byte by byte.
+        {
+            const uint32_t p0 = lane_above(rr[0], carry[0]), p1 = lane_above(rr[1], carry[1]), p2 = lane_above(rr[2], carry[2]), p3 = lane_above(rr[3], carry[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) carry[k] = (uint32_t)__builtin_amdgcn_readlane((int)rr[k], 63);
+            if (sft == 0) {
+                if (live) ((U128u *)(out + 1 + j))->v = u32x4{rr[0], rr[1], rr[2], rr[3]};
+            } else {
+                // X = the 32 bytes (lane above : mine); the unit = X shifted right by 16 - sft bytes
+                const uint32_t X[9] = {p0, p1, p2, p3, rr[0], rr[1], rr[2], rr[3], 0u};
+                const uint32_t a = (16 - sft) >> 2, b = (16 - sft) & 3;          // dwords, bytes (wave-uniform)
+                u32x4 u;
+                auto pick = [&](int aa) {
+                    u.x = __builtin_amdgcn_alignbyte(X[aa + 1], X[aa], b); u.y = __builtin_amdgcn_alignbyte(X[aa + 2], X[aa + 1], b);
+                    u.z = __builtin_amdgcn_alignbyte(X[aa + 3], X[aa + 2], b); u.w = __builtin_amdgcn_alignbyte(X[aa + 4], X[aa + 3], b);
+                };
+                if (a == 0) pick(0); else if (a == 1) pick(1); else if (a == 2) pick(2); else pick(3);
+                // the unit ends at row byte j + 16 - sft, i.e. it holds row bytes [j - sft, j + 16 - sft)
+                if (j == 0) {
+                    // (the row's first unit: its first sft - 1 bytes are the row above's, then the filter byte, stored by lane 0 above)
+                    for (uint32_t k = 0; k < 16 - sft; ++k) out[1 + k] = (uint8_t)(rr[k >> 2] >> (8 * (k & 3)));
+                } else if (j <= pitch) {
+                    if (j < pitch) *(u32x4 *)(out + 1 + j - sft) = u;
+                    else for (uint32_t k = 0; k < sft; ++k) out[1 + pitch - sft + k] = (uint8_t)(X[(16 - sft + k) >> 2] >> (8 * ((16 - sft + k) & 3)));   // the row's last sft bytes: the lane behind the last one
+                }
+            }
         }
     }
 }
