@@ -192,6 +192,18 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackJob *__restrict__ j
         }
         uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};               // the storage bytes of up to four pixels (<= 32), in memory order
         uint32_t at = 0;
+        const bool rgb_fast = TB == 8 && depth == 8 && ch == 3 && !job.indexed && job.layout == 0 && ((uintptr_t)job.pixels & 3) == 0;
+        if (rgb_fast && m == 4) {
+            // [RGBA<UInt8>] -> rgb8 / bgr8: four pixels = one 16-byte load, twelve bytes out (alpha dropped)
+            v4u v = ((const PV4 *)((const uint32_t *)in + i0))->v;
+            if (job.bgr) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = (v[k] & 0xff00ff00u) | (v[k] >> 16 & 0xff) | (v[k] & 0xff) << 16;
+            }
+            w[0] = (v[0] & 0x00ffffffu) | v[1] << 24;
+            w[1] = (v[1] >> 8 & 0xffffu) | v[2] << 16;
+            w[2] = (v[2] >> 16 & 0xffu) | v[3] << 8;
+        } else
         for (uint32_t k = 0; k < m; ++k) {
             const uint64_t i = i0 + k;
             uint32_t r, g, b, a = TMAX;
