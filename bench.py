@@ -543,10 +543,14 @@ def run_scanline_formats(torch, spng, s, n=256):
             fd[j] = spng.ImageDesc(None, 0, d_rows.data_ptr() + j * U, U, d_sto.data_ptr() + j * S, W, H, depth, ch, 0, 0, 0)
             ud[j] = spng.ImageDesc(None, 0, d_rows.data_ptr() + j * U, U, d_back.data_ptr() + j * S, W, H, depth, ch, 0, 0, 0)
         dres = s.empty(m * ctypes.sizeof(spng.Result))
+        torch.cuda.synchronize()                               # (the fills above ran on torch's stream, the kernels run on the context's)
         assert s.lib.spng_filter_batch(s.ctx, fd, m, ctypes.c_void_p(dres.data_ptr()), None) == 0
         assert s.lib.spng_unfilter_batch(s.ctx, ud, m, None, ctypes.c_void_p(dres.data_ptr()), None) == 0
         torch.cuda.synchronize()
-        assert torch.equal(d_back, d_sto), f"{name}: defiltered rasters differ from their sources"
+        if not torch.equal(d_back, d_sto):
+            d = (d_back != d_sto).nonzero()[:, 0]
+            raise AssertionError(f"{name}: defiltered rasters differ from their sources: {len(d)} bytes, first at image {int(d[0]) // S} row "
+                                 f"{int(d[0]) % S // (W * ch * (depth // 8))} byte {int(d[0]) % (W * ch * (depth // 8))}, last at image {int(d[-1]) // S}")
         s.profile(True)
         for _ in range(3):
             assert s.lib.spng_filter_batch(s.ctx, fd, m, ctypes.c_void_p(dres.data_ptr()), None) == 0
@@ -604,6 +608,7 @@ def run_pixels_to_file(torch, spng, s, n, size, level=9):
             cdescs[j] = spng.ChunkingDesc(d_z.data_ptr() + j * cap, res[j].written, d_file.data_ptr() + j * fcap, fcap, 65536)
         assert s.lib.spng_write_idat_batch(s.ctx, cdescs, n, None, cres) == 0
 
+    torch.cuda.synchronize()                                   # (the fills ran on torch's stream, the kernels run on the context's)
     step()
     torch.cuda.synchronize()
     s.profile(True)
@@ -630,6 +635,7 @@ def run_pixels_to_file(torch, spng, s, n, size, level=9):
         bd = (spng.PackDesc * m)()
         for j in range(m):
             bd[j] = spng.PackDesc(big.data_ptr() + j * (1 << 26), out.data_ptr() + j * 4096 * 4096 * ch, None, 4096, 4096, 0, 8, ch, 0, 0, 8, spng.TARGET_RGBA)
+        torch.cuda.synchronize()
         assert s.lib.spng_pack_batch(s.ctx, bd, m) == 0
         torch.cuda.synchronize()
         s.profile(True)
