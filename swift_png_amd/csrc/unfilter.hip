@@ -175,6 +175,88 @@ __device__ __forceinline__ uint32_t paeth_pk(uint32_t a, uint32_t b, uint32_t c)
     return (bc & nota) | (a & ~nota);
 }
 
+// ---- reconstruction of one tile: 3 or 6 bytes per unit, a unit in one or two dwords (round 5) ----------------------------------
+// The byte-wise form above spends ~40 VALU operations and two LDS accesses per BYTE.  Here a lane takes 48 bytes of its row per
+// step (three aligned ds_read_b128: 16 RGB8 or 8 RGB16 units), cuts them into units with v_alignbyte -- an RGB8 unit rides in the
+// low three bytes of a dword, an RGB16 unit in one and a half, the spare byte(s) carry a neighbour's bytes and are never looked
+// at: every operation below is byte-wise or per 16-bit half -- runs the dword arithmetic of the 4- and 8-byte kernel on them
+// (~50 operations per dword: see phase_pk), and packs the results with v_perm.  The row above still arrives by DPP, one unit late.
+template <int BPP> struct Pu {
+    static constexpr int DW = (BPP + 3) / 4;             // dwords a unit rides in
+    static constexpr int G = 48 / BPP;                   // units per step
+};
+
+template <int BPP, int P, bool PAETH>
+__device__ __forceinline__ void reconstruct_packed(uint8_t *tile, int rowb, int lane, uint32_t ft,
+                                                   uint32_t (&o)[Pu<BPP>::DW], uint32_t (&bprev)[Pu<BPP>::DW])
+{
+    constexpr int DW = Pu<BPP>::DW, G = Pu<BPP>::G, STEPS = P * BPP / 48;
+    static_assert(P * BPP % 48 == 0 && (BPP == 3 || BPP == 6), "a tile row is a whole number of 48-byte steps");
+    constexpr uint32_t M = 0x00ff00ffu, SEL_LO = 0x0c020c00u, SEL_HI = 0x0c030c01u;
+    const uint32_t m_sub = ft == 1 ? ~0u : 0u, m_up = ft == 2 ? ~0u : 0u, m_avg = ft == 3 ? ~0u : 0u, m_pae = ft == 4 ? ~0u : 0u;
+    uint8_t *mine = tile + (1 + lane) * rowb;
+    uint32_t a_lo[DW], a_hi[DW], c_lo[DW], c_hi[DW];
+#pragma unroll
+    for (int d = 0; d < DW; ++d) { a_lo[d] = o[d] & M; a_hi[d] = (o[d] >> 8) & M; c_lo[d] = bprev[d] & M; c_hi[d] = (bprev[d] >> 8) & M; }
+    // unit j of the twelve dwords w: dword d of it (the bytes past the unit's end are whatever follows)
+    auto cut = [](const uint32_t (&w)[12], int j, int d) -> uint32_t {
+        const int at = BPP * j + 4 * d, k = at >> 2, sh = at & 3;
+        if (sh == 0) return w[k];
+        return k + 1 < 12 ? __builtin_amdgcn_alignbyte(w[k + 1], w[k], (uint32_t)sh) : w[k] >> (8 * sh);
+    };
+    u32x4 xa[3], xb[3], ta[3], tb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { xa[i] = *(const u32x4 *)(mine + 16 * i); ta[i] = *(const u32x4 *)(tile + 16 * i); }
+#pragma unroll
+    for (int g = 0; g < STEPS; ++g) {
+        if (g + 1 < STEPS) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { xb[i] = *(const u32x4 *)(mine + 48 * (g + 1) + 16 * i); tb[i] = *(const u32x4 *)(tile + 48 * (g + 1) + 16 * i); }
+        }
+        const uint32_t w[12] = {xa[0].x, xa[0].y, xa[0].z, xa[0].w, xa[1].x, xa[1].y, xa[1].z, xa[1].w, xa[2].x, xa[2].y, xa[2].z, xa[2].w};
+        const uint32_t t[12] = {ta[0].x, ta[0].y, ta[0].z, ta[0].w, ta[1].x, ta[1].y, ta[1].z, ta[1].w, ta[2].x, ta[2].y, ta[2].z, ta[2].w};
+        uint32_t v[G][DW];
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+#pragma unroll
+            for (int d = 0; d < DW; ++d) {
+                // (lane 0: the row above the band, straight out of the tile's first LDS row -- its window is not skewed)
+                const uint32_t b = from_lane_above(o[d], cut(t, j, d));
+                uint32_t p = (o[d] & m_sub) | (b & m_up) | (__builtin_amdgcn_lerp(o[d], b, 0u) & m_avg);
+                const uint32_t b_lo = __builtin_amdgcn_perm(0u, b, SEL_LO), b_hi = __builtin_amdgcn_perm(0u, b, SEL_HI);
+                if (PAETH) p |= (paeth_pk(a_lo[d], b_lo, c_lo[d]) | paeth_pk(a_hi[d], b_hi, c_hi[d]) << 8) & m_pae;
+                const uint32_t x = cut(w, j, d);
+                const uint32_t r = ((x & 0x7f7f7f7fu) + (p & 0x7f7f7f7fu)) ^ ((x ^ p) & 0x80808080u);
+                o[d] = r;
+                v[j][d] = r;
+                c_lo[d] = b_lo; c_hi[d] = b_hi;
+                a_lo[d] = __builtin_amdgcn_perm(0u, r, SEL_LO); a_hi[d] = __builtin_amdgcn_perm(0u, r, SEL_HI);
+                bprev[d] = b;
+            }
+        }
+        uint32_t r[12];
+        if (BPP == 3) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                              // four units = three dwords
+                r[3 * q + 0] = __builtin_amdgcn_perm(v[4 * q + 1][0], v[4 * q + 0][0], 0x04020100u);
+                r[3 * q + 1] = __builtin_amdgcn_perm(v[4 * q + 2][0], v[4 * q + 1][0], 0x05040201u);
+                r[3 * q + 2] = __builtin_amdgcn_perm(v[4 * q + 3][0], v[4 * q + 2][0], 0x06050402u);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                              // two units = three dwords
+                r[3 * q + 0] = v[2 * q][0];
+                r[3 * q + 1] = __builtin_amdgcn_perm(v[2 * q + 1][0], v[2 * q][DW - 1], 0x05040100u);
+                r[3 * q + 2] = __builtin_amdgcn_perm(v[2 * q + 1][DW - 1], v[2 * q + 1][0], 0x05040302u);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *(u32x4 *)(mine + 48 * g + 16 * i) = u32x4{r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { xa[i] = xb[i]; ta[i] = tb[i]; }
+    }
+}
+
 template <int BPP>
 __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob *__restrict__ jobs,
                                                                      const spng_result *__restrict__ results,
@@ -279,9 +361,13 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
     for (uint32_t band = wave; band < nbands; band += NW) {
         const uint32_t row = band * 64 + lane;
         const uint32_t ft = row < rows ? job.in[(uint64_t)row * job.in_stride] : 0u;
-        uint32_t o[BPP], bprev[BPP];
+        constexpr bool PACKED = BPP == 3 || BPP == 6;          // (a unit in dwords: reconstruct_packed)
+        constexpr int NS = PACKED ? (BPP + 3) / 4 : BPP;
+        const bool any_pae = __any(ft == 4);                   // no Paeth row in this band: skip its arithmetic
+        (void)any_pae;
+        uint32_t o[NS], bprev[NS];
 #pragma unroll
-        for (int k = 0; k < BPP; ++k) { o[k] = 0; bprev[k] = 0; }
+        for (int k = 0; k < NS; ++k) { o[k] = 0; bprev[k] = 0; }
 
         for (uint32_t T = 0; T < ntiles; ++T) {
             if (!staged) { wait_ready(band, T); issue(band, T); }
@@ -316,7 +402,12 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
 
             const int64_t ux0 = (int64_t)T * C::P - lane;
 #ifndef SPNG_UNF_NOCOMPUTE        // tuning builds only: measure the memory pipeline alone
-            reconstruct_generic<BPP, C::P>(tile, C::ROWB, lane, ft, ux0, o, bprev);
+            if constexpr (PACKED) {
+                (void)ux0;
+                if (any_pae) reconstruct_packed<BPP, C::P, true>(tile, C::ROWB, lane, ft, o, bprev);
+                else         reconstruct_packed<BPP, C::P, false>(tile, C::ROWB, lane, ft, o, bprev);
+            } else
+                reconstruct_generic<BPP, C::P>(tile, C::ROWB, lane, ft, ux0, o, bprev);
 #endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 

@@ -50,6 +50,12 @@ CASES = [
     ("rgba8 pieces only where None / Sub allow", 200, 400, 4, 8, 32, [0] + [4] * 150 + [1] + [3] * 90),
     ("gray8", 500, 200, 1, 8, 64, _f(6, 53)), ("va8", 500, 200, 2, 8, 64, _f(7, 53)), ("rgb8", 500, 200, 3, 8, 32, _f(8, 53)),
     ("rgb16", 301, 170, 3, 16, 64, _f(9, 53)),
+    # the packed form of the 3- and 6-byte pixels (round 5): every filter alone, widths around the 48-byte steps and 192-byte tiles
+    ("rgb8 sub", 70, 10, 3, 8, 64, [1]), ("rgb8 up", 70, 10, 3, 8, 64, [0, 2]), ("rgb8 average", 70, 10, 3, 8, 64, [0, 3]),
+    ("rgb8 paeth", 70, 10, 3, 8, 64, [1, 4]), ("rgb16 paeth", 70, 10, 3, 16, 64, [1, 4]), ("rgb16 average", 33, 70, 3, 16, 64, [3, 3, 1]),
+    ("rgb8 one pixel", 1, 1, 3, 8, 64, [4]), ("rgb8 sixteen pixels", 16, 3, 3, 8, 64, [4, 3, 4]), ("rgb8 seventeen pixels", 17, 130, 3, 8, 64, _f(10, 130)),
+    ("rgb8 wide, three bands", 1500, 150, 3, 8, 64, _f(11, 150)), ("rgb16 wide, pieces", 900, 200, 3, 16, 32, _f(12, 61)),
+    ("rgb8 no paeth row in a band", 300, 140, 3, 8, 128, [1, 2, 3, 0, 2] * 20 + [4] * 40),
 ]
 
 
