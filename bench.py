@@ -302,6 +302,11 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_decode_only = float(t.item())
     total_c = sum(C[k] for k in job.src)
+    # what the pipeline moves BY DESIGN besides C and U: the token pages its decode stage writes and its resolve stage reads (figures
+    # of the step's last call, scaled to the step when the shard went through in several calls)
+    glo, ghi = [g for g in job.groups if g[1] > g[0]][-1]
+    tok_pages, tok_blocks, _ = s.token_stats()
+    tok_step = int(tok_pages * n / (ghi - glo)) if fast else 0
     del ref, gathered, d_streams
     job.d_rows = job.d_out = job.dres = None                  # (the slabs go back to the allocator before the next workload)
     torch.cuda.empty_cache()
@@ -311,7 +316,8 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
     launches = {k: max(1, round(prof[k][1] / args.steps) - (1 if k.startswith("pinf_") else 0)) for k in STAGES}
     alg = {"pinf_find": 0, "pinf_decode": total_c, "pinf_resolve": n * U,
            "inflate": 0 if fast == n else total_c + n * U, "unfilter": n * (U + S)}
-    return {"dt": dt, "n": n, "weak": weak, "per_step_ms": per_step, "launches": launches, "alg": alg, "total_c": total_c, "U": U, "S": S,
+    design = {"pinf_decode": total_c + tok_step, "pinf_resolve": tok_step + n * U, "unfilter": n * (U + S)} if tok_step else {}
+    return {"design": design, "token_bytes": tok_step, "dt": dt, "n": n, "weak": weak, "per_step_ms": per_step, "launches": launches, "alg": alg, "total_c": total_c, "U": U, "S": S,
             "fast": fast, "gather": bool(do_gather), "gather_error": gather_error, "hi_lo": hi - lo, "dt_decode_only": dt_decode_only,
             "groups": len(job.groups),
             "ratio": round(U * unique / sum(C), 3), "streams": streams, "images": images, "rows": rows}
@@ -333,6 +339,12 @@ def kernel_report(m, traffic):
             e["frac_of_hbm_peak"] = round(e["gbps"] / HBM_PEAK_GBPS, 4)
         if k in traffic:
             e["traffic"] = traffic[k]
+        if m.get("design", {}).get(k):
+            # bytes the stage moves by design: with the token stream (decode: C read + tokens written; resolve: tokens read + U
+            # written) -- traffic above THIS is wasted, not traffic above the algorithmic C / U
+            e["design_bytes"] = m["design"][k]
+            if k in traffic and traffic[k]:
+                e["traffic_over_design"] = round(traffic[k] / m["design"][k], 3)
         rep[k] = e
     return rep
 

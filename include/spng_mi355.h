@@ -167,6 +167,11 @@ enum { SPNG_K_INFLATE = 0,          /* the serial inflate kernel (streams the pa
        SPNG_K_COUNT = 16 };
 int32_t spng_profile(spng_ctx *ctx, int enable);                /* enable/disable + reset counters  */
 int32_t spng_profile_get(spng_ctx *ctx, int kernel, double *total_ms, uint64_t *launches);
+/* Token volume of the most recent parallel-inflate call whose figures have come back (they travel behind its kernels; this call
+ * waits for the context's stream): bytes of the 64 KiB token pages its segments took -- what pinf2_decode writes and pinf2_resolve
+ * reads by design, rounded up to pages --, the DEFLATE blocks it decoded, and whether a pass found the pool empty.  No reference
+ * counterpart (measurement: bench.py's per-kernel design bytes).  Any pointer may be NULL. */
+int32_t spng_token_stats(spng_ctx *ctx, uint64_t *page_bytes, uint64_t *blocks, int32_t *ran_dry);
 
 /* ---- decode: device batch entry points (asynchronous on the context's stream) -------------- */
 /* replaces LZ77.Inflator.push/pull over whole streams: LZ77.Inflator.swift:30-61,

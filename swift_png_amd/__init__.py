@@ -50,7 +50,7 @@ INFLATE_AUTO, INFLATE_SERIAL = 0, 1
 EXPORTS = [
     "spng_version", "spng_status_string", "spng_last_error_string", "spng_inflated_size",
     "spng_storage_size", "spng_create", "spng_destroy", "spng_stream", "spng_sync", "spng_profile",
-    "spng_profile_get", "spng_configure", "spng_inflate_batch", "spng_inflate_resume_batch", "spng_unfilter_batch",
+    "spng_profile_get", "spng_token_stats", "spng_configure", "spng_inflate_batch", "spng_inflate_resume_batch", "spng_unfilter_batch",
     "spng_unfilter_resume_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
     "spng_lex_batch", "spng_write_idat_batch", "spng_crc32", "spng_unpack_batch", "spng_unpack", "spng_unpack_as", "spng_pack_batch", "spng_pack_as", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
@@ -206,6 +206,7 @@ def load_library():
     lib.spng_configure.argtypes = [vp, ctypes.c_int, ctypes.c_int64]
     lib.spng_profile.argtypes = [vp, ctypes.c_int]
     lib.spng_profile_get.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(u64)]
+    lib.spng_token_stats.argtypes = [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_int32)]
     lib.spng_inflate_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), u32, vp, rp]
     lib.spng_inflate_resume_batch.argtypes = [vp, ctypes.POINTER(StreamDesc), ctypes.POINTER(ctypes.c_uint64), u32, vp, rp]
     lib.spng_unfilter_batch.argtypes = [vp, ctypes.POINTER(ImageDesc), u32, vp, vp, rp]
@@ -350,6 +351,12 @@ class Session:
         ms, n = ctypes.c_double(0), ctypes.c_uint64(0)
         _check(self.lib, self.lib.spng_profile_get(self.ctx, kernel, ctypes.byref(ms), ctypes.byref(n)))
         return ms.value, n.value
+
+    def token_stats(self):
+        """(bytes of token pages, DEFLATE blocks, ran dry) of the most recent parallel-inflate call read back."""
+        b, k, d = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_int32(0)
+        _check(self.lib, self.lib.spng_token_stats(self.ctx, ctypes.byref(b), ctypes.byref(k), ctypes.byref(d)))
+        return b.value, k.value, bool(d.value)
 
     def to_device(self, data):
         t = self.torch

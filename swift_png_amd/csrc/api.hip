@@ -311,6 +311,19 @@ int32_t spng_profile(spng_ctx *c, int enable)
     return SPNG_DONE;
 }
 
+int32_t spng_token_stats(spng_ctx *c, uint64_t *page_bytes, uint64_t *blocks, int32_t *ran_dry)
+{
+    if (!c) return SPNG_E_ARGUMENT;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint32_t *h = c->h_pool_used;                          // {pages, ran dry, blocks} of the last batch read back
+    if (page_bytes) *page_bytes = h ? (uint64_t)h[0] << 16 : 0;
+    if (ran_dry) *ran_dry = h ? (int32_t)h[1] : 0;
+    if (blocks) *blocks = h ? h[2] : 0;
+    return SPNG_DONE;
+}
+
 int32_t spng_profile_get(spng_ctx *c, int kernel, double *total_ms, uint64_t *launches)
 {
     if (!c || kernel < 0 || kernel >= SPNG_K_COUNT) return SPNG_E_ARGUMENT;

@@ -89,6 +89,20 @@ def test_pipeline_takes_swiftpng_made_streams(gpu):
     assert bytes(outs[0][:len(d)].cpu().numpy()) == d
 
 
+def test_token_stats_of_the_last_call(gpu):
+    """spng_token_stats: the 64 KiB token pages the last parallel-inflate call took cover its tokens (a literal is one halfword,
+    a back-reference two: at least the bytes of a stream of literals), and its blocks were counted."""
+    s = gpu.load()
+    d = np.random.default_rng(9).integers(0, 256, 3 << 20, dtype=np.uint8).tobytes()     # nothing to match: ~3 Mi literals
+    z = zlib.compress(d, 6)
+    outs, res = s.inflate_batch([s.to_device(z)], [len(d) + 64])
+    assert res[0].status == 0 and res[0].reserved == 1
+    page_bytes, blocks, dry = s.token_stats()
+    assert not dry and blocks >= 1
+    assert 2 * len(d) <= page_bytes <= 2 * len(d) + 65536 * (len(z) // 16384 + 64)      # (a page per segment may stay partly empty)
+    assert page_bytes % 65536 == 0
+
+
 def test_pipeline_batch_of_ragged_streams(gpu):
     """one call, streams from 0 bytes to MiBs, valid and not: the pipeline's verdicts never differ from zlib's"""
     s = gpu.load()
