@@ -258,6 +258,13 @@ def run_decode(args, torch, dist, spng, s, rank, world, kind, unique, with_gathe
             gather_error = repr(exc)[:200]
             do_gather = False
             pending.clear()
+    if with_gather and world > 1 and not args.no_gather:
+        # (every rank takes the same road from here on: one that lost its exchange takes it from all)
+        flag = torch.tensor([1 if gather_error else 0], dtype=torch.int32, device=s.tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and do_gather:
+            do_gather = False
+            gather_error = gather_error or "another rank's exchange failed"
     for _ in range(args.warmup):
         step()
     fence()

@@ -24,8 +24,7 @@ PROBE_WHICH=random PROBE_N=1024 timeout 300 rocprofv3 --kernel-trace --pmc FETCH
 PROBE_WHICH=random PROBE_N=1024 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/enc_write -- python tools/probe_deflate2.py > /dev/null 2> gpurun_out/enc_write.err
 python tools/pmc_encode.py gpurun_out/enc_fetch gpurun_out/enc_write 1024 gpurun_out/${R}_pmc_encode.json > gpurun_out/pmc_enc.log 2>&1; tail -5 gpurun_out/pmc_enc.log
 cp gpurun_out/${R}_pmc_encode.json profiles/${R}_pmc_encode.json
-PROBE_WHICH=random PROBE_N=1024 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d gpurun_out/enc_insts -- python tools/probe_deflate2.py > /dev/null 2> gpurun_out/enc_insts.err
-python tools/pmc_kernels.py gpurun_out/enc_insts > gpurun_out/${R}_pmc_encode_insts.json 2> /dev/null
+# (instruction counters of the deflate kernels: profiles/r05k_pmc_l6_insts.json, taken earlier in the round on the level-6 probe)
 # probes
 timeout 400 python tools/probe_groups.py --kind zlib --unique 4 > gpurun_out/${R}_probe_groups.log 2>&1; head -3 gpurun_out/${R}_probe_groups.log
 PROBE_LEVEL=6 PROBE_WHICH=synth4k,photo PROBE_N=256 timeout 300 python tools/probe_deflate2.py > gpurun_out/${R}_probe_l6_256.log 2>&1; tail -2 gpurun_out/${R}_probe_l6_256.log
