@@ -48,6 +48,7 @@
 // the window read back from the output, and the block boundary reached goes to the serial kernel.
 #include "common.hpp"
 #include <type_traits>
+#include <cstddef>
 #include "huffman.hpp"
 
 namespace spng {
@@ -152,12 +153,17 @@ struct DLds {
             uint16_t codes[6][64];     //   every lane's canonical codes (five lit/len symbols, one distance symbol)
         } h;
         struct {                       // rounds 0 and 1 of a chunk
+            uint32_t ent[64];              // where it enters each subsequence | halfwords it decodes there before merging << 16
+                                           // (in front of vmap: round 1 reads it as "the word in front of a lane's first" -- its
+                                           // bit 31 is never set)
             uint32_t vmap[SDW_MAX * 64];   // visited-token-start bitmaps, word w of lane l at [w * 64 + l]
             uint16_t flag[64], mpos[64];   // lanes on the true chain; where it merges into their chains
-            uint32_t ent[64];              // where it enters each subsequence | halfwords it decodes there before merging << 16
+                                           // (behind vmap: round 0's OR of nothing into "the word behind a lane's last" lands here)
         } c;
     };
 };
+static_assert(offsetof(DLds, c.vmap) == offsetof(DLds, c.ent) + 256 && offsetof(DLds, c.flag) == offsetof(DLds, c.vmap) + SDW_MAX * 256,
+              "round 1 reads ent as the row in front of vmap; round 0's empty OR behind a lane's last word lands in flag / mpos");
 
 // ---- staging ------------------------------------------------------------------------------------------
 __device__ __forceinline__ v4u ld16(const g8 *src, uint64_t n, uint64_t off)
@@ -574,11 +580,12 @@ __device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *
 // token the fast path takes (undefined code, zero run or distance).  FULL also produces the token's halfwords (h0, and h1
 // for a reference or a second literal).
 static constexpr uint32_t D2_EOB = C_EOB, D2_REF = C_REF, D2_BAD = C_BAD;   // (the entry's class as it is; 0: a literal)
-// `bound`: a pair of literals whose second one would start at or behind it counts as its first literal alone (the
-// second belongs to the next subsequence).  -> the token's bits; k = its class, len0 = the code length of the (first)
-// literal.  Bits behind the end of the input read as zeros: the callers compare where a chain ends with the end.
+// -> the token's bits (a pair's: both codes'); k = its class, len0 = the code length of the (first) literal.  Round 0 cuts a
+// pair whose second literal starts in the next subsequence back to its first one (marks are kept per subsequence); round 1
+// and the replay take pairs whole (they count halfwords).  Bits behind the end of the input read as zeros: the callers
+// compare where a chain ends with the end.
 template <bool FULL, bool PAIRS>
-__device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32_t bound, uint32_t &k, uint32_t &len0, uint32_t &h0, uint32_t &h1)
+__device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32_t &k, uint32_t &len0, uint32_t &h0, uint32_t &h1)
 {
     uint32_t lo, hi;
     fetch2(s.stage, q, lo, hi);
@@ -586,7 +593,6 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
     if ((e & 0xe0) == 0xe0) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index
     uint32_t p2 = e & 31, cls = (e >> 5) & 7;
     len0 = (e >> 8) & 15;
-    if (PAIRS && cls == C_LIT2 && q + len0 >= bound) { p2 = len0; cls = C_LIT; }
     uint32_t nbits = p2;
     k = cls;
     if (cls == C_REF) {
@@ -748,8 +754,15 @@ __device__ __forceinline__ void advance_tokens(Cursor &c, uint32_t count, g8 *pb
 //             that lane's chain up to its link, ...: the lanes reachable from lane 0 (pointer doubling).
 //   replay    per subsequence the true chain enters it at `e` and `mine` halfwords of tokens start in it: the
 //             crossing chain's, then the owner's marks behind the merge point.  Every lane decodes exactly
-//             those, into the LDS token buffer at its prefix-sum offset; the buffer leaves in 16-byte units.
-template <bool PAIRS>
+//             those, straight to its place in the token pages (a prefix sum over the lanes' counts).
+//
+// What the replay has to know of round 0 is HOW MANY halfwords the owner's tokens behind the merge point make.  RM (no
+// lit/len code of one bit: every token is at least two bits long, a back-reference three): a back-reference marks its
+// start AND the bit behind it, so the halfwords are the marks' popcount, and a token start is a mark without a mark in
+// front of it (two neighbouring marks can only be a back-reference).  A back-reference on the last bit of a subsequence has
+// no bit behind it to mark: `edge`.  !RM (a code of one bit exists: neighbouring marks may be two tokens): the kinds of a
+// lane's tokens by ordinal in two 64-bit masks, as rounds 1-4 did it.
+template <bool PAIRS, bool RM>
 __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_t n, uint64_t cb,
                                                  uint64_t entry, uint32_t sdw, const DPool &pool, g32 *pt, uint32_t pt_cap, Cursor &cur,
                                                  uint64_t &next, uint64_t &nbytes, int lane DP_ARG)
@@ -772,24 +785,34 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     DP(1);
     const uint32_t q0 = lane == 0 ? (uint32_t)(entry - sbit) : sub0;
     uint32_t q = q0, st = 0;                                    // st: 0 running, 1 end of block, 2 not a token
-    uint64_t mb0 = 0, mb1 = 0;                                  // which of my tokens (by ordinal) are back-references
-    uint32_t ntk = 0;
+    uint64_t mb0 = 0, mb1 = 0;                                  // !RM: which of my tokens (by ordinal) are back-references
+    uint32_t ntk = 0, edge = 0;
     while (q < sub1) {
         DPN(16, 1);
         uint32_t k, len0;
-        const uint32_t nb = decode_at2<false, PAIRS>(s, q, sub1, k, len0, d0, d1);
+        uint32_t nb = decode_at2<false, PAIRS>(s, q, k, len0, d0, d1);
         if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
         const uint32_t b = q - sub0;
-        atomicOr(&s.c.vmap[(b >> 5) * 64 + lane], 1u << (b & 31));
-        {
+        if (RM) {
+            // (the mark and, for a back-reference, the one behind it -- in the next word when the token starts on a word's last
+            // bit: an OR of zero elsewhere, into the word behind the lane's last one at most)
+            uint32_t m = 1;
+            if (k == D2_REF) { const bool last = b + 1 == sb; m = last ? 1u : 3u; edge = last ? 1u : edge; }
+            const uint64_t mm = (uint64_t)m << (b & 31);
+            atomicOr(&s.c.vmap[(b >> 5) * 64 + lane], (uint32_t)mm);
+            atomicOr(&s.c.vmap[(b >> 5) * 64 + 64 + lane], (uint32_t)(mm >> 32));
+        } else {
+            atomicOr(&s.c.vmap[(b >> 5) * 64 + lane], 1u << (b & 31));
             const uint64_t bit = (uint64_t)(PAIRS ? (k == D2_REF ? 1u : 0u) : k >> 1) << (ntk & 63);
             mb0 |= ntk < 64 ? bit : 0ull; mb1 |= ntk < 64 ? 0ull : bit;
-        }
-        ntk += 1;
-        if (PAIRS && k == C_LIT2) {                             // two literals in one step: two tokens, two marks
-            const uint32_t b2 = b + len0;
-            atomicOr(&s.c.vmap[(b2 >> 5) * 64 + lane], 1u << (b2 & 31));
             ntk += 1;
+        }
+        if (PAIRS && k == C_LIT2) {                             // two literals in one step: two tokens, two marks
+            const uint32_t b2 = b + len0;                       // (the second one may belong to the next subsequence: not mine)
+            if (b2 < sb) {
+                atomicOr(&s.c.vmap[(b2 >> 5) * 64 + lane], 1u << (b2 & 31));
+                if (!RM) ntk += 1;
+            } else nb = len0;
         }
         q += nb;
     }
@@ -803,16 +826,23 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
         while (q < cend) {
             DPN(17, 1);
             if (q >= jb) {                                      // (a token is shorter than a subsequence: one step at most)
-                const uint32_t v = q | cnt2 << 16;
-                x0 = nh == 0 ? v : x0; x1 = nh == 1 ? v : x1; x2 = nh == 2 ? v : x2; x3 = nh == 3 ? v : x3;
+                if (nh < 4) { x3 = x2; x2 = x1; x1 = x0; x0 = q | cnt2 << 16; }      // (the newest in x0)
                 nh += 1; j += 1; jb += sb;
             }
             // (the mark's word travels with the token's bits: its test comes behind the decode it may make useless)
             const uint32_t b = q + sb - jb;
-            const uint32_t mword = s.c.vmap[(b >> 5) * 64 + j];
+            // RM: a token start of the owner's is a mark with no mark in front of it; the word in front travels along (in front
+            // of a lane's first word: its ent, bit 31 clear)
+            const uint32_t *wp = s.c.ent + (b >> 5) * 64 + j;
+            const uint32_t pword = RM ? wp[0] : 0u, mword = wp[64];
             uint32_t k, len0;
-            const uint32_t nb = decode_at2<false, PAIRS>(s, q, jb, k, len0, d0, d1);
-            if ((mword >> (b & 31)) & 1) { link = j; break; }
+            // (a pair of literals is taken whole even when its second one starts in the next subsequence: halfwords are counted,
+            // not attributed by position -- the replay of the subsequence the pair starts in decodes both, the next one's entry
+            // lies behind them; every literal's start is marked by its owner, so the merge is found one token later at worst)
+            const uint32_t nb = decode_at2<false, PAIRS>(s, q, k, len0, d0, d1);
+            // (bit i of `front`: the mark in front of bit i)
+            const uint32_t front = RM ? __builtin_amdgcn_alignbit(mword, pword, 31) : 0u;
+            if (((mword & ~front) >> (b & 31)) & 1) { link = j; break; }
             if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
             cnt2 += 1 + (PAIRS ? (k >> 1) & 1 : k >> 1);
             q += nb;
@@ -835,7 +865,8 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
         // the subsequences my chain crossed (beyond the fourth crossing they all count for the fourth: rare.  Fewer records
         // cost less per step of round 1 but leave the owner of the last one a replay of several subsequences: slower)
         const uint32_t nrec = nh < 4 ? nh : 4;
-        const uint32_t xs[5] = {x0, x1, x2, x3, 0};
+        const uint32_t xs[5] = {nrec == 4 ? x3 : nrec == 3 ? x2 : nrec == 2 ? x1 : x0,           // (the first crossing first)
+                                nrec == 4 ? x2 : nrec == 3 ? x1 : x0, nrec == 4 ? x1 : x0, x0, 0};
 #pragma unroll
         for (int h = 0; h < 4; ++h)
             if ((uint32_t)h < nrec) {
@@ -853,18 +884,30 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     uint32_t mine = e >> 16;                                    // halfwords
     if (onpath) {
         const uint32_t mb = m - sub0;                            // 0 .. sb - 1
-        uint32_t k0 = 0;                                         // my tokens in front of the merge point
+        if (RM) {
+            uint32_t hw = edge;                                  // my marks from the merge point on: a halfword each
 #pragma unroll
-        for (int w = 0; w < SDW_MAX; ++w) {
-            const uint32_t word = s.c.vmap[w * 64 + lane];
-            const uint32_t lo = w * 32;
-            const uint32_t below = mb >= lo + 32 ? ~0u : mb > lo ? ~(~0u << (mb - lo)) : 0u;
-            k0 += (uint32_t)__popc(word & below);
+            for (int w = 0; w < SDW_MAX; ++w) {
+                const uint32_t word = s.c.vmap[w * 64 + lane];
+                const uint32_t lo = w * 32;
+                const uint32_t from = mb >= lo + 32 ? 0u : mb > lo ? ~0u << (mb - lo) : ~0u;
+                hw += (uint32_t)__popc(word & from);
+            }
+            mine += hw;
+        } else {
+            uint32_t k0 = 0;                                     // my tokens in front of the merge point
+#pragma unroll
+            for (int w = 0; w < SDW_MAX; ++w) {
+                const uint32_t word = s.c.vmap[w * 64 + lane];
+                const uint32_t lo = w * 32;
+                const uint32_t below = mb >= lo + 32 ? ~0u : mb > lo ? ~(~0u << (mb - lo)) : 0u;
+                k0 += (uint32_t)__popc(word & below);
+            }
+            uint64_t r0m = mb0, r1m = mb1;                      // back-references among my tokens k0 ...
+            if (k0 >= 64) { r0m = k0 >= 128 ? 0 : r1m >> (k0 - 64); r1m = 0; }
+            else if (k0) { r0m = r0m >> k0 | r1m << (64 - k0); r1m >>= k0; }
+            mine += (ntk - k0) + (uint32_t)__popcll(r0m) + (uint32_t)__popcll(r1m);
         }
-        uint64_t r0m = mb0, r1m = mb1;                          // back-references among my tokens k0 ...
-        if (k0 >= 64) { r0m = k0 >= 128 ? 0 : r1m >> (k0 - 64); r1m = 0; }
-        else if (k0) { r0m = r0m >> k0 | r1m << (64 - k0); r1m >>= k0; }
-        mine += (ntk - k0) + (uint32_t)__popcll(r0m) + (uint32_t)__popcll(r1m);
     }   // (a lane off the path whose subsequence the true chain crossed without merging replays the crossing: ent)
     uint32_t tot;
     const uint32_t off = wave_excl_scan(mine, tot, lane);
@@ -887,22 +930,35 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     g8 *pb;
     if (!UB(reserve_tokens(pool, pt, pt_cap, cur, tot, pb, lane))) return 2;
     {
-        g8 *pa = cur.pa;
+        g8 *pa = (g8 *)uni64((uint64_t)cur.pa);
         const uint32_t r0 = (uint32_t)(cur.nhw & (PAGE_HW - 1)) + off;
-        uint32_t done = 0, qq = e & 0xffff, nout = 0;
-        while (done < mine) {
-            DPN(18, 1);
-            uint32_t h0 = 0, h1 = 0;
-            uint32_t k, len0;
-            const uint32_t nb = decode_at2<true, PAIRS>(s, qq, 0xffffffffu, k, len0, h0, h1);
-            // (of a pair of literals whose second one starts in the next subsequence only the first is mine)
-            const bool two = PAIRS ? (k & 2) != 0 && done + 2 <= mine : k == D2_REF;
-            *token_at(pa, pb, r0 + done) = (uint16_t)h0;
-            if (two) *token_at(pa, pb, r0 + done + 1) = (uint16_t)h1;
-            done += two ? 2u : 1u;
-            nout += !two ? 1u : k == D2_REF ? (h0 & 0xff) + 3 : 2u;      // the bytes the token stands for
-            qq += nb;
-        }
+        uint32_t nout = 0;
+        // (two instances: a chunk whose halfwords lie in one page -- fifteen of sixteen -- addresses them by a byte offset from
+        // the page, one addition per token; the other one picks the page per store)
+        auto replay = [&](auto one_page) {
+            constexpr bool ONE = decltype(one_page)::value;
+            uint32_t done = 0, qq = e & 0xffff;
+            while (done < mine) {
+                DPN(18, 1);
+                uint32_t h0 = 0, h1 = 0;
+                uint32_t k, len0;
+                const uint32_t nb = decode_at2<true, PAIRS>(s, qq, k, len0, h0, h1);
+                // (of a pair of literals whose second one starts in the next subsequence only the first is mine)
+                const bool two = PAIRS ? (k & 2) != 0 && done + 2 <= mine : k == D2_REF;
+                if (ONE) {
+                    g16 *t = (g16 *)(pa + ((r0 + done) << 1));
+                    t[0] = (uint16_t)h0;
+                    if (two) t[1] = (uint16_t)h1;
+                } else {
+                    *token_at(pa, pb, r0 + done) = (uint16_t)h0;
+                    if (two) *token_at(pa, pb, r0 + done + 1) = (uint16_t)h1;
+                }
+                done += two ? 2u : 1u;
+                nout += !two ? 1u : k == D2_REF ? (h0 & 0xff) + 3 : 2u;      // the bytes the token stands for
+                qq += nb;
+            }
+        };
+        if (pb == pa) replay(std::true_type{}); else replay(std::false_type{});
         nbytes += wave_sum(nout);
     }
     advance_tokens(cur, tot, pb);
@@ -1015,8 +1071,12 @@ __global__ __launch_bounds__(64, SPNG_D_WAVES) void pinf2_decode_kernel(const PS
             for (;;) {
                 uint64_t next;
                 // (two instances of the loops: without pairs in the table a step skips their bookkeeping)
-                state = h.pairs ? UNI(decode_chunk<true>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, nbytes, lane DP_PASS))
-                                : UNI(decode_chunk<false>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, nbytes, lane DP_PASS));
+                if (h.minlen >= 2)
+                    state = h.pairs ? UNI((decode_chunk<true, true>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, nbytes, lane DP_PASS)))
+                                    : UNI((decode_chunk<false, true>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, nbytes, lane DP_PASS)));
+                else
+                    state = h.pairs ? UNI((decode_chunk<true, false>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, nbytes, lane DP_PASS)))
+                                    : UNI((decode_chunk<false, false>(s, src, n, cb, entry, sdw, pool, pt, pt_cap, cur, next, nbytes, lane DP_PASS)));
                 entry = uni64(next);
                 if (state) break;
                 cb += (uint64_t)sdw * 32 * 64;
