@@ -58,6 +58,18 @@ namespace spng {
 #else
 #define AS_GLOBAL __attribute__((address_space(1)))
 #endif
+// a product of two values below 2^24: v_mul_u32_u24 is full rate, v_mul_lo_u32 -- what the compiler picks even for operands it
+// knows to be small -- a quarter of it
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b)
+{
+#ifdef SPNG_EMU
+    return (a & 0xffffffu) * (b & 0xffffffu);
+#else
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
 typedef uint32_t v4u __attribute__((vector_size(16)));
 struct __attribute__((packed)) PV4 { v4u v; };
 typedef uint8_t AS_GLOBAL g8;
@@ -162,6 +174,10 @@ struct DLds {
         } c;
     };
 };
+// The token loops count their bit positions from the start of DLds, not of stage: position >> 3 & ~3 is then the LDS address of
+// the dword a token starts in as it stands (one instruction less per token step), and positions still fit 16 bits.
+static constexpr uint32_t QB = (uint32_t)offsetof(DLds, stage) * 8;
+static_assert(QB % 32 == 0 && QB + (SDW_MAX * 64 + 3) * 32 + 64 < 65536, "biased positions: dword-aligned, 16 bits");
 static_assert(offsetof(DLds, c.vmap) == offsetof(DLds, c.ent) + 256 && offsetof(DLds, c.flag) == offsetof(DLds, c.vmap) + SDW_MAX * 256,
               "round 1 reads ent as the row in front of vmap; round 0's empty OR behind a lane's last word lands in flag / mpos");
 
@@ -274,7 +290,7 @@ __device__ __forceinline__ bool finish_root(uint32_t *lut, uint32_t &used, uint3
 }
 
 // The code-length code (readBlockTables, InflatorBuffers.Stream.swift:144-190): 19 lengths of <= 7 bits.  Lane
-// i < 19 holds the length of symbol i.  Builds the 2^7-entry LUT (entry = code length | symbol << 16).
+// i < 19 holds the length of symbol i.  Builds the 2^7-entry LUT (entry = code length | extra bits << 4 | repeat base << 8 | symbol << 16).
 // false: not a complete code (HuffmanTree.swift:80-108).
 __device__ __forceinline__ bool build_clut(DLds &s, uint32_t mylen, int lane)
 {
@@ -293,7 +309,10 @@ __device__ __forceinline__ bool build_clut(DLds &s, uint32_t mylen, int lane)
     s.h.clut[lane] = 0; s.h.clut[64 + lane] = 0;
     WSYNC();
     // (built indexed by the code MSB first -- a code's entries are neighbours -- and turned round at the end: finish_root)
-    if (lane < 19 && mylen) s.h.clut[(s.h.cl[mylen] + before) << (MB - mylen)] = mylen | (uint32_t)lane << 16;
+    // (entry: code length | extra bits << 4 | smallest repeat count << 8 | symbol << 16 -- decode_lengths2 adds, it does not decide)
+    if (lane < 19 && mylen)
+        s.h.clut[(s.h.cl[mylen] + before) << (MB - mylen)] =
+            mylen | (lane < 16 ? 0u : lane == 16 ? 2u : lane == 17 ? 3u : 7u) << 4 | (lane < 16 ? 1u : lane == 18 ? 11u : 3u) << 8 | (uint32_t)lane << 16;
     WSYNC();
     uint32_t none = 0;
     finish_root<MB>(s.h.clut, none, 0, false, lane);
@@ -320,9 +339,8 @@ __device__ __attribute__((always_inline)) bool decode_lengths2(DLds &s, uint32_t
         const uint32_t w = q >> 5;
         const uint32_t bits = __builtin_amdgcn_alignbit(s.stage[w + 1], s.stage[w], q);
         const uint32_t e = s.h.clut[bits & ((1u << MB) - 1)];
-        const uint32_t len = e & 15, sym = e >> 16;
-        const uint32_t extra = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
-        const uint32_t rep = sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + ((bits >> len) & ((1u << extra) - 1));
+        const uint32_t len = e & 15, sym = e >> 16, extra = (e >> 4) & 15;
+        const uint32_t rep = ((e >> 8) & 0xff) + ((bits >> len) & ((1u << extra) - 1));
         const uint32_t nb = len + extra;                      // 1 .. 14
         // the chain through this window, and how many lengths it stands for.  A dependent scalar step per symbol is what
         // this loop would cost (~14 per window); three rounds of pointer doubling first, and a step covers eight symbols:
@@ -576,7 +594,7 @@ __device__ __attribute__((always_inline)) bool parse_header2(DLds &s, const g8 *
 }
 
 // ---- per-lane token decoding ----------------------------------------------------------------------------
-// decodes the token that starts at staged bit q: kind 0 literal, 2 back-reference, 6 two literals, 1 end of block, 3 not a
+// decodes the token that starts at bit q of the staged data (counted from the start of DLds: QB): kind 0 literal, 2 back-reference, 6 two literals, 1 end of block, 3 not a
 // token the fast path takes (undefined code, zero run or distance).  FULL also produces the token's halfwords (h0, and h1
 // for a reference or a second literal).
 static constexpr uint32_t D2_EOB = C_EOB, D2_REF = C_REF, D2_BAD = C_BAD;   // (the entry's class as it is; 0: a literal)
@@ -588,7 +606,12 @@ template <bool FULL, bool PAIRS>
 __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32_t &k, uint32_t &len0, uint32_t &h0, uint32_t &h1)
 {
     uint32_t lo, hi;
-    fetch2(s.stage, q, lo, hi);
+    {   // (q counts from the start of s: QB)
+        const uint32_t *w = (const uint32_t *)((const uint8_t *)&s + ((q >> 3) & ~3u));
+        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+        lo = __builtin_amdgcn_alignbit(d1, d0, q);
+        hi = __builtin_amdgcn_alignbit(d2, d1, q);
+    }
     uint32_t e = s.lit[lo & ((1 << LB) - 1)];
     if ((e & 0xe0) == 0xe0) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index
     uint32_t p2 = e & 31, cls = (e >> 5) & 7;
@@ -596,7 +619,7 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
     uint32_t nbits = p2;
     k = cls;
     if (cls == C_REF) {
-        const uint32_t b2 = (uint32_t)(((uint64_t)hi << 32 | lo) >> p2);
+        const uint32_t b2 = __builtin_amdgcn_alignbit(hi, lo, p2);       // (p2 <= 31: one full-rate instruction, not a 64-bit shift)
         uint32_t d = s.dist[b2 & ((1 << DB) - 1)];
         if (d & 0x80) d = s.ext[(d >> 16) + ((b2 >> DB) & ((1u << ((d >> 8) & 15)) - 1))];
         nbits = p2 + (d & 31);
@@ -773,8 +796,9 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     stage_bytes2(s.stage, src, n, sbyte, (int)((sdw * 64 + 3 + 3) & ~3u), lane);   // the chunk, the dword it may start in the middle of, a token's reach
     const uint64_t sbit = sbyte * 8;
     const uint64_t left = n * 8 - sbit;
-    const uint32_t lim = left > 0xffffffffull ? 0xffffffffu : (uint32_t)left;
-    const uint32_t off0 = (uint32_t)(cb - sbit), cend = off0 + chb;
+    // (positions inside the chunk: bits from sbit, + QB)
+    const uint32_t lim = left > 0xffffffffull - QB ? 0xffffffffu : (uint32_t)left + QB;
+    const uint32_t off0 = (uint32_t)(cb - sbit) + QB, cend = off0 + chb;
     const uint32_t sub0 = off0 + (uint32_t)lane * sb, sub1 = sub0 + sb;
 #pragma unroll
     for (int w = 0; w < SDW_MAX; ++w) s.c.vmap[w * 64 + lane] = 0;
@@ -783,7 +807,7 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     WSYNC();
     uint32_t d0, d1;
     DP(1);
-    const uint32_t q0 = lane == 0 ? (uint32_t)(entry - sbit) : sub0;
+    const uint32_t q0 = lane == 0 ? (uint32_t)(entry - sbit) + QB : sub0;
     uint32_t q = q0, st = 0;                                    // st: 0 running, 1 end of block, 2 not a token
     uint64_t mb0 = 0, mb1 = 0;                                  // !RM: which of my tokens (by ordinal) are back-references
     uint32_t ntk = 0, edge = 0;
@@ -919,7 +943,7 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     const unsigned long long endm = __ballot(onpath && link == 64);
     const int el = endm ? __ffsll((long long)endm) - 1 : 0;
     const uint32_t qe = (uint32_t)__shfl((int)q, el, 64), ste = endm ? (uint32_t)__shfl((int)st, el, 64) : 2u;
-    next = sbit + qe;
+    next = sbit + (qe - QB);
 #ifdef SPNG_EMU_TRACE
     if (ste == 2 && lane == 0) fprintf(stderr, "chunk cb %llu: path ends in a bad token (end lane %d, q %u)\n", (unsigned long long)cb, el, qe);
 #endif
@@ -1188,6 +1212,7 @@ static constexpr uint32_t BPT2 = TILE2 / RT2;        // of them per thread: byte
 static constexpr uint32_t HPT2 = 4096 / RT2;         // token halfwords per thread in a window of 4096
 static constexpr uint32_t EB2 = BPT2 < 8 ? BPT2 : 8; // bytes of a thread expanded together
 static constexpr uint32_t MAXM2 = 1024;              // back-references per tile
+static constexpr uint32_t RTAB2 = 259;               // reciprocals kept for the distances below it (a multiple of 16 bytes with the entry behind them)
 static constexpr uint32_t WINDOW2 = 32768;           // the DEFLATE window
 static constexpr uint32_t R2_DONE = 0x8000;          // state: R2_DONE | byte, or the tile index of an earlier byte
 static constexpr uint32_t PTC = 256;                 // page-table entries cached in LDS
@@ -1200,7 +1225,9 @@ template <bool MARK>
 struct RLds2T {
     typename RingOf<MARK>::T ring[WINDOW2];   // the last 32 KiB of output, at position mod 32 KiB
     uint16_t state[TILE2];
-    uint32_t rec[MAXM2 + 2][2];        // back-references of the tile: first byte | run << 16; distance ([0]: none, run 0; [last]: keeps what follows 16-byte aligned)
+    uint32_t rec[MAXM2 + 2][4];        // back-references of the tile: first byte | run << 16; distance; 1 / distance and half of it as floats
+                                       // (the period arithmetic of a run longer than its distance: worked out once per reference, not per byte)   ([0]: none, run 0)
+    uint32_t rtab[RTAB2 + 1][2];       // 1 / d and 0.5 / d as floats, d < RTAB2 (a run can only be longer than a distance below 258)
     uint32_t bitmap[TILE2 / 32];       // their first bytes
     uint16_t h0[RT2 + 8];              // every thread's first halfword (the second half of its neighbour's last reference)
     uint32_t pt[PTC];
@@ -1315,7 +1342,11 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
     }
     if (tid < (int)(TILE2 / 32)) s.bitmap[tid] = 0;
     if (tid < 3) s.again[tid] = 0;
-    if (tid == 0) { s.rec[0][0] = 0; s.rec[0][1] = 1; }
+    if (tid == 0) { s.rec[0][0] = 0; s.rec[0][1] = 1; s.rec[0][2] = 0; s.rec[0][3] = 0; }
+    for (uint32_t i = (uint32_t)tid; i <= RTAB2; i += RT2) {
+        const float rd = __builtin_amdgcn_rcpf((float)(i ? i : 1u));
+        s.rtab[i][0] = __builtin_bit_cast(uint32_t, rd); s.rtab[i][1] = __builtin_bit_cast(uint32_t, 0.5f * rd);
+    }
     __syncthreads();
     const uint32_t seg_first = UNI(st.seg_first), seg_count = UNI(st.seg_count);
     uint32_t sk = part ? UNI(part->seg) : 0;
@@ -1388,17 +1419,26 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                               !(tid == (int)RT2 - 1 && (hh[HPT2 - 1] & 0xC000) == 0x8000);
             if (front && !fits) { s.cut[0] = curb; s.cut[1] = (uint32_t)tid * HPT2; }
             if (fits) {
+                // (the distances and their reciprocals first, for every halfword whatever it is: the table reads travel together,
+                // ahead of the loop that is serial in curb)
+                uint32_t ddv[HPT2];
+                v2u rtv[HPT2];
+#pragma unroll
+                for (int j = 0; j < (int)HPT2; ++j) {
+                    const uint32_t h1 = j < (int)HPT2 - 1 ? hh[j < (int)HPT2 - 1 ? j + 1 : (int)HPT2 - 1] : hnext;
+                    ddv[j] = (((hh[j] >> 8) & 63) | (h1 & 0x1ff) << 6) + 1;
+                    rtv[j] = *(const v2u *)s.rtab[ddv[j] < RTAB2 ? ddv[j] : RTAB2];
+                }
 #pragma unroll
                 for (int j = 0; j < (int)HPT2; ++j) {
                     const uint32_t v = hh[j];
                     if (!(v & 0x8000)) { s.state[curb] = (uint16_t)(DONE | v); curb += 1; }
                     else if ((v & 0xC000) == 0x8000) {
                         const uint32_t len = (v & 0xff) + 3;
-                        const uint32_t h1 = j < (int)HPT2 - 1 ? hh[j < (int)HPT2 - 1 ? j + 1 : (int)HPT2 - 1] : hnext;
-                        const uint32_t dd = (((v >> 8) & 63) | (h1 & 0x1ff) << 6) + 1;
                         atomicOr(&s.bitmap[curb >> 5], 1u << (curb & 31));
-                        s.rec[curm + 1][0] = curb | len << 16;
-                        s.rec[curm + 1][1] = dd;
+                        v4u r4;
+                        r4[0] = curb | len << 16; r4[1] = ddv[j]; r4[2] = rtv[j][0]; r4[3] = rtv[j][1];
+                        *(v4u *)s.rec[curm + 1] = r4;
                         curb += len; curm += 1;
                     }
                 }
@@ -1439,7 +1479,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                 constexpr bool EARLY = decltype(early_c)::value;
 #pragma unroll
                 for (int part = 0; part < (int)(BPT2 / EB2); ++part) {
-                    uint32_t r0v[EB2], r1v[EB2];
+                    v4u recv[EB2];
 #pragma unroll
                     for (int kk = 0; kk < (int)EB2; ++kk) {
                         const int k = part * (int)EB2 + kk;
@@ -1447,23 +1487,31 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)srclo, (int)(row >> 1));
                         const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)srchi, (int)(row >> 1));
                         const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)srcbase, (int)(row >> 1));
-                        const unsigned long long mw = (unsigned long long)mhi << 32 | mlo;
-                        const uint32_t id = base + (uint32_t)__popcll(mw & ((2ull << lane) - 1));
-                        r0v[kk] = s.rec[id][0];                        // (no reference in front of this byte: entry 0, run 0)
-                        r1v[kk] = s.rec[id][1];
+                        // references that start at or in front of my byte: the row's bits up to my lane's -- v_mbcnt counts the
+                        // bits BELOW a lane's, so the row's word goes in shifted down by one and its bit 0 joins the base (scalar)
+                        const unsigned long long mw1 = ((unsigned long long)mhi << 32 | mlo) >> 1;
+                        const uint32_t id = __builtin_amdgcn_mbcnt_hi((uint32_t)(mw1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw1, base + (mlo & 1)));
+                        recv[kk] = *(const v4u *)s.rec[id];            // (no reference in front of this byte: entry 0, run 0)
                     }
                     uint32_t siv[EB2], farv[EB2];
 #pragma unroll
                     for (int kk = 0; kk < (int)EB2; ++kk) {
                         const int k = part * (int)EB2 + kk;
                         const uint32_t j = ((uint32_t)wave + NW2 * k) * 64 + (uint32_t)lane;
-                        const uint32_t startb = r0v[kk] & 0xffff, len = r0v[kk] >> 16, d = r1v[kk];
+                        const uint32_t startb = recv[kk][0] & 0xffff, len = recv[kk][0] >> 16, d = recv[kk][1];
                         uint32_t kk2 = j - startb;
                         const bool inside = kk2 < len;             // (the tokens taken cover bytes 0 .. tlen - 1 and nothing else)
                         // A run longer than its distance repeats its first `distance` bytes: a byte beyond the first
                         // period copies the period in front of the run (same value, chain one level deep instead of
-                        // run / distance levels).
-                        if (inside && kk2 >= d) kk2 -= d * (uint32_t)(((float)kk2 + 0.5f) * __builtin_amdgcn_rcpf((float)d));   // kk2 mod d (kk2 < 258: the quotient is exact)
+                        // run / distance levels).  kk2 mod d: the quotient floor((kk2 + 0.5) / d) by one fused multiply-add with the
+                        // reference's 1 / d and 0.5 / d (kk2 < 258, d <= kk2: (kk2 + 0.5) / d is 0.5 / 257 away from an integer at
+                        // least, the float error is 2^-22 of the value)
+                        if (inside && kk2 >= d) {
+                            // (the words copied out first: clang's __builtin_bit_cast of a vector ELEMENT reads element 0)
+                            const uint32_t rw = recv[kk][2], hw = recv[kk][3];
+                            const uint32_t quo = (uint32_t)__builtin_fmaf((float)kk2, __builtin_bit_cast(float, rw), __builtin_bit_cast(float, hw));
+                            kk2 -= mul24(d, quo);
+                        }
                         siv[kk] = inside ? startb - d + kk2 : 0x7fffffffu;                     // >= 0x80000000: before the tile
                         farv[kk] = s.ring[(rbase + siv[kk]) & (WINDOW2 - 1)];
                     }

@@ -88,10 +88,10 @@ def test_pipeline_kernel_resources():
     assert dec["vgpr_count"] <= 128                          # >= 4 waves per SIMD
     assert dec["private_segment_fixed_size"] == 0 and dec["vgpr_spill_count"] == 0
     res = _one(table, "pinf2_resolve_kernel")
-    assert res["group_segment_fixed_size"] <= 65536          # (static LDS) and two 512-thread workgroups per CU
+    assert res["group_segment_fixed_size"] <= 81920          # (static LDS) two 512-thread workgroups per CU (160 KB): 69.5 KB with four-word reference records + the reciprocal table
     assert res["vgpr_count"] <= 128 and res["private_segment_fixed_size"] == 0 and res["max_flat_workgroup_size"] == 512
     mark = [v for k, v in table.items() if "pinf2_resolve_kernel" in k and "ILj0ELb1E" in k]
-    assert len(mark) == 1 and mark[0]["group_segment_fixed_size"] <= 98304 and mark[0]["private_segment_fixed_size"] == 0   # (symbols: a 64 KiB ring)
+    assert len(mark) == 1 and mark[0]["group_segment_fixed_size"] <= 106496 and mark[0]["private_segment_fixed_size"] == 0   # (symbols: a 64 KiB ring; one workgroup per CU)
     find = _one(table, "pinf2_find_kernel")
     assert find["private_segment_fixed_size"] == 0 and find["group_segment_fixed_size"] <= 16384
     # LDS and global memory are reached with their own instructions
