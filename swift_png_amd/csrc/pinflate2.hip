@@ -115,6 +115,16 @@ struct DPool { uint8_t *base; uint32_t *next; uint32_t pages, pad; };   // next[
 #define HP(k)
 #endif
 
+// Emulator builds can count how often the rare paths of the decode rounds ran (tests/test_emu_pinflate.py asserts that its cases
+// reach every one of them): COV(k) is nothing in the product.
+#if defined(SPNG_EMU) && defined(SPNG_EMU_COV)
+static long g_cov[8];      // 0 reference on a subsequence's last bit, 1 reference on a word's last bit, 2 chunks with marks for references,
+                           // 3 chunks with kind masks, 4 pairs cut at a subsequence's end, 5 round-1 landings on a reference's second mark
+#define COV(k) __atomic_fetch_add(&g_cov[k], 1, __ATOMIC_RELAXED)
+#else
+#define COV(k) ((void)0)
+#endif
+
 // ---- per-wave LDS of find / decode ----------------------------------------------------------------------
 static constexpr uint32_t EXT = 480;                   // second-level table space, both codes together (zlib's bound for 286 symbols
                                                        // behind a 2^9 root is 340; distances behind a 2^8 root rarely need more than 130)
@@ -613,7 +623,7 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
         hi = __builtin_amdgcn_alignbit(d2, d1, q);
     }
     uint32_t e = s.lit[lo & ((1 << LB) - 1)];
-    if ((e & 0xe0) == 0xe0) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index
+    if (__builtin_expect((e & 0xe0) == 0xe0, 0)) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index (rare: out of line)
     uint32_t p2 = e & 31, cls = (e >> 5) & 7;
     len0 = (e >> 8) & 15;
     uint32_t nbits = p2;
@@ -621,7 +631,7 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
     if (cls == C_REF) {
         const uint32_t b2 = __builtin_amdgcn_alignbit(hi, lo, p2);       // (p2 <= 31: one full-rate instruction, not a 64-bit shift)
         uint32_t d = s.dist[b2 & ((1 << DB) - 1)];
-        if (d & 0x80) d = s.ext[(d >> 16) + ((b2 >> DB) & ((1u << ((d >> 8) & 15)) - 1))];
+        if (__builtin_expect((d & 0x80) != 0, 0)) d = s.ext[(d >> 16) + ((b2 >> DB) & ((1u << ((d >> 8) & 15)) - 1))];
         nbits = p2 + (d & 31);
         k |= (d >> 5) & 1;                                       // (not a usable distance: C_BAD)
         if (FULL) {
@@ -806,6 +816,7 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     s.c.ent[lane] = 0;
     WSYNC();
     uint32_t d0, d1;
+    if (lane == 0) COV(RM ? 2 : 3);
     DP(1);
     const uint32_t q0 = lane == 0 ? (uint32_t)(entry - sbit) + QB : sub0;
     uint32_t q = q0, st = 0;                                    // st: 0 running, 1 end of block, 2 not a token
@@ -815,13 +826,13 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
         DPN(16, 1);
         uint32_t k, len0;
         uint32_t nb = decode_at2<false, PAIRS>(s, q, k, len0, d0, d1);
-        if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
+        if (__builtin_expect((k & 1) != 0, 0)) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
         const uint32_t b = q - sub0;
         if (RM) {
             // (the mark and, for a back-reference, the one behind it -- in the next word when the token starts on a word's last
             // bit: an OR of zero elsewhere, into the word behind the lane's last one at most)
             uint32_t m = 1;
-            if (k == D2_REF) { const bool last = b + 1 == sb; m = last ? 1u : 3u; edge = last ? 1u : edge; }
+            if (k == D2_REF) { const bool last = b + 1 == sb; m = last ? 1u : 3u; edge = last ? 1u : edge; if (last) COV(0); else if ((b & 31) == 31) COV(1); }
             const uint64_t mm = (uint64_t)m << (b & 31);
             atomicOr(&s.c.vmap[(b >> 5) * 64 + lane], (uint32_t)mm);
             atomicOr(&s.c.vmap[(b >> 5) * 64 + 64 + lane], (uint32_t)(mm >> 32));
@@ -836,7 +847,7 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
             if (b2 < sb) {
                 atomicOr(&s.c.vmap[(b2 >> 5) * 64 + lane], 1u << (b2 & 31));
                 if (!RM) ntk += 1;
-            } else nb = len0;
+            } else { nb = len0; COV(4); }
         }
         q += nb;
     }
@@ -866,8 +877,9 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
             const uint32_t nb = decode_at2<false, PAIRS>(s, q, k, len0, d0, d1);
             // (bit i of `front`: the mark in front of bit i)
             const uint32_t front = RM ? __builtin_amdgcn_alignbit(mword, pword, 31) : 0u;
+            if (RM && ((mword & front) >> (b & 31)) & 1) COV(5);
             if (((mword & ~front) >> (b & 31)) & 1) { link = j; break; }
-            if (k & 1) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
+            if (__builtin_expect((k & 1) != 0, 0)) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
             cnt2 += 1 + (PAIRS ? (k >> 1) & 1 : k >> 1);
             q += nb;
         }

@@ -108,6 +108,33 @@ def test_emulated_pipeline_matches_zlib(emu, tmp_path, name, segment):
     assert r.stdout.startswith("ok:")
 
 
+def test_emulated_decode_reaches_its_rare_paths(tmp_path):
+    """Round 5's marks (a back-reference marks its start and the bit behind it) have corner cases of their own: a reference that
+    starts on the last bit of a subsequence (nothing behind it to mark) or of a bitmap word (the second mark goes into the next
+    word), a chain of round 1 that lands on a second mark (not a token start), a pair of literals cut at a subsequence's end, and
+    blocks with a one-bit code, which keep the kind masks.  A build with counters (-DSPNG_EMU_COV) says how often each ran over
+    the cases above: every one of them must have, with exact output."""
+    if not shutil.which("g++"):
+        pytest.skip("g++ not available")
+    out = tmp_path / "emu_cov"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DSPNG_EMU", "-DSPNG_EMU_COV", "-I" + os.path.join(ROOT, "tools", "emu"), "-x", "c++", "-fpermissive",
+                    "-Wno-attributes", "-w", "-o", str(out), os.path.join(ROOT, "tools", "emu", "emu_pinflate2.cpp")],
+                   check=True, capture_output=True, timeout=600)
+    total = [0] * 6
+    for name in ("zlib6", "zlib1", "text16", "text3", "deepdist"):
+        _, z, raw, fmt = next(c for c in CASES if c[0] == name)
+        (tmp_path / "z").write_bytes(z)
+        (tmp_path / "raw").write_bytes(raw)
+        r = subprocess.run([str(out), str(tmp_path / "z"), str(tmp_path / "raw"), str(fmt), "4096"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), (name, r.stdout[-300:], r.stderr[-300:])
+        cov = [ln for ln in r.stderr.splitlines() if ln.startswith("COV")]
+        assert cov, r.stderr[-300:]
+        total = [a + int(b) for a, b in zip(total, cov[-1].split()[1:])]
+    names = ("reference on a subsequence's last bit", "reference on a word's last bit", "chunks with reference marks", "chunks with kind masks",
+             "pairs cut at a subsequence's end", "landings on a second mark")
+    assert all(total), dict(zip(names, total))
+
+
 def test_emulated_pipeline_swiftpng_shaped_stream(emu, tmp_path):
     """the oracle's own level-6 deflate: a dynamic block every <= 2047 tokens, as PNG.Image.compress makes them"""
     import pnghelp as ph

@@ -19,9 +19,15 @@ static std::vector<uint8_t> slurp(const char *path)
     return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 }
 
+#ifdef SPNG_EMU_COV
+static void cov_print() { fprintf(stderr, "COV"); for (int i = 0; i < 6; ++i) fprintf(stderr, " %ld", spng::g_cov[i]); fprintf(stderr, "\n"); }
+#endif
 int main(int argc, char **argv)
 {
     if (argc < 5) { fprintf(stderr, "usage\n"); return 2; }
+#ifdef SPNG_EMU_COV
+    atexit(cov_print);
+#endif
     std::vector<uint8_t> src = slurp(argv[1]), want = slurp(argv[2]);
     const int format = atoi(argv[3]);
     uint64_t seg_bytes = strtoull(argv[4], nullptr, 10);
