@@ -703,7 +703,10 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
     // (pinflate2.hip, "Several workgroups per stream"): 16-bit symbols in c->d_sym, the windows in c->d_win.
     p.pmax = 0;
     if (p.internal && p.jobs.size() <= 384 && c->cfg[SPNG_CFG_RESOLVE_PARTS] != 1) {
-        uint32_t pm = (uint32_t)(768 / p.jobs.size());
+        // (512 workgroups in all: the marker parts run two to a CU -- pinflate2.hip, RGeo --, so that is one round of resident
+        // workgroups; 768 left half a round behind: 128 images 41.6 ms of resolve against 33.5, 1024 parts 34.2)
+        uint32_t pm = (uint32_t)(512 / p.jobs.size());
+        if (pm < 2) pm = 2;
         if (c->cfg[SPNG_CFG_RESOLVE_PARTS] > 1) pm = (uint32_t)c->cfg[SPNG_CFG_RESOLVE_PARTS];
         if (pm > 64) pm = 64;
         uint64_t syms = 0;

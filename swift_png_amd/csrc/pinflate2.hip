@@ -80,6 +80,13 @@ typedef uint32_t v2u __attribute__((vector_size(8)));
 struct __attribute__((packed)) PV2 { v2u v; };
 typedef PV2 AS_GLOBAL gPV2;
 
+// a condition that is rarely true in a token step (a code behind the root tables, the end of a block): its block goes out of line,
+// the common path falls through (a taken branch costs a wave more than the instructions it skips).  -DSPNG_NO_HINTS: A/B builds
+#ifdef SPNG_NO_HINTS
+#define RARE(c) (c)
+#else
+#define RARE(c) __builtin_expect((c), 0)
+#endif
 static constexpr int LB = 9, DB = 8, MB = 7;         // LUT index bits: lit/len, distance, code-length code
 #ifndef SPNG_SDW_MAX
 #define SPNG_SDW_MAX 9      // (17: 14.3 KB of LDS per wave, 11 waves per CU instead of 16: decode 291 ms instead of 206 -- the loops are latency-bound)
@@ -623,7 +630,7 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
         hi = __builtin_amdgcn_alignbit(d2, d1, q);
     }
     uint32_t e = s.lit[lo & ((1 << LB) - 1)];
-    if (__builtin_expect((e & 0xe0) == 0xe0, 0)) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index (rare: out of line)
+    if (RARE((e & 0xe0) == 0xe0)) e = s.ext[(e >> 16) + ((lo >> LB) & ((1u << ((e >> 8) & 15)) - 1))];      // a code longer than the root index (rare: out of line)
     uint32_t p2 = e & 31, cls = (e >> 5) & 7;
     len0 = (e >> 8) & 15;
     uint32_t nbits = p2;
@@ -631,7 +638,7 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
     if (cls == C_REF) {
         const uint32_t b2 = __builtin_amdgcn_alignbit(hi, lo, p2);       // (p2 <= 31: one full-rate instruction, not a 64-bit shift)
         uint32_t d = s.dist[b2 & ((1 << DB) - 1)];
-        if (__builtin_expect((d & 0x80) != 0, 0)) d = s.ext[(d >> 16) + ((b2 >> DB) & ((1u << ((d >> 8) & 15)) - 1))];
+        if (RARE((d & 0x80) != 0)) d = s.ext[(d >> 16) + ((b2 >> DB) & ((1u << ((d >> 8) & 15)) - 1))];
         nbits = p2 + (d & 31);
         k |= (d >> 5) & 1;                                       // (not a usable distance: C_BAD)
         if (FULL) {
@@ -826,7 +833,7 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
         DPN(16, 1);
         uint32_t k, len0;
         uint32_t nb = decode_at2<false, PAIRS>(s, q, k, len0, d0, d1);
-        if (__builtin_expect((k & 1) != 0, 0)) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
+        if (RARE((k & 1) != 0)) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
         const uint32_t b = q - sub0;
         if (RM) {
             // (the mark and, for a back-reference, the one behind it -- in the next word when the token starts on a word's last
@@ -879,7 +886,7 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
             const uint32_t front = RM ? __builtin_amdgcn_alignbit(mword, pword, 31) : 0u;
             if (RM && ((mword & front) >> (b & 31)) & 1) COV(5);
             if (((mword & ~front) >> (b & 31)) & 1) { link = j; break; }
-            if (__builtin_expect((k & 1) != 0, 0)) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
+            if (RARE((k & 1) != 0)) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
             cnt2 += 1 + (PAIRS ? (k >> 1) & 1 : k >> 1);
             q += nb;
         }
@@ -1219,12 +1226,18 @@ __global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ st
 #endif
 static constexpr uint32_t RT2 = SPNG_R_THREADS;      // threads per stream
 static constexpr uint32_t NW2 = RT2 / 64;            // (waves)
-static constexpr uint32_t TILE2 = 8192;              // output bytes resolved per step
-static constexpr uint32_t BPT2 = TILE2 / RT2;        // of them per thread: byte j of the tile belongs to thread j mod RT2
-static constexpr uint32_t HPT2 = 4096 / RT2;         // token halfwords per thread in a window of 4096
-static constexpr uint32_t EB2 = BPT2 < 8 ? BPT2 : 8; // bytes of a thread expanded together
-static constexpr uint32_t MAXM2 = 1024;              // back-references per tile
-static constexpr uint32_t RTAB2 = 259;               // reciprocals kept for the distances below it (a multiple of 16 bytes with the entry behind them)
+// The geometry of a step.  Whole streams and first parts (MARK = false): 8 KiB tiles, 61 KB of LDS, two workgroups per CU.  The
+// parts behind the first keep 16-bit SYMBOLS in ring and states -- a 64 KiB ring: with 8 KiB tiles 93 KB, ONE workgroup per CU,
+// half the waves -- so a batch with more marker parts than CUs takes 4 KiB tiles and windows of 2048
+// halfwords for them (BIG = false): 79 KB, two per CU (128 images: resolve 44.6 -> 33.5 ms).  A batch whose marker parts have a
+// CU each keeps the 8 KiB tiles (a tile's fixed costs -- scans, barriers -- are per tile: one 4K image 3.0 against 3.2 ms).
+template <bool BIG> struct RGeo {
+    static constexpr uint32_t TILE = BIG ? 8192 : 4096;              // output bytes resolved per step
+    static constexpr uint32_t BPT = TILE / RT2;                      // of them per thread: byte j of the tile belongs to thread j mod RT2
+    static constexpr uint32_t HPT = TILE / 2 / RT2;                  // token halfwords per thread in a window (of half a tile's bytes)
+    static constexpr uint32_t EB = BPT < 8 ? BPT : 8;                // bytes of a thread expanded together
+    static constexpr uint32_t MAXM = TILE / 8;                       // back-references per tile
+};
 static constexpr uint32_t WINDOW2 = 32768;           // the DEFLATE window
 static constexpr uint32_t R2_DONE = 0x8000;          // state: R2_DONE | byte, or the tile index of an earlier byte
 static constexpr uint32_t PTC = 256;                 // page-table entries cached in LDS
@@ -1233,21 +1246,18 @@ static constexpr uint32_t PTC = 256;                 // page-table entries cache
 // 0x8000 | o = byte o of the 32 KiB in front of the part -- and a state below 0x2000 is the tile index of an earlier byte.
 template <bool MARK> struct RingOf { typedef uint8_t T; };
 template <> struct RingOf<true> { typedef uint16_t T; };
-template <bool MARK>
+template <bool MARK, bool BIG>
 struct RLds2T {
     typename RingOf<MARK>::T ring[WINDOW2];   // the last 32 KiB of output, at position mod 32 KiB
-    uint16_t state[TILE2];
-    uint32_t rec[MAXM2 + 2][4];        // back-references of the tile: first byte | run << 16; distance; 1 / distance and half of it as floats
-                                       // (the period arithmetic of a run longer than its distance: worked out once per reference, not per byte)   ([0]: none, run 0)
-    uint32_t rtab[RTAB2 + 1][2];       // 1 / d and 0.5 / d as floats, d < RTAB2 (a run can only be longer than a distance below 258)
-    uint32_t bitmap[TILE2 / 32];       // their first bytes
+    uint16_t state[RGeo<BIG>::TILE];
+    uint32_t rec[RGeo<BIG>::MAXM + 2][2];        // back-references of the tile: first byte | run << 16; distance ([0]: none, run 0; [last]: keeps what follows 16-byte aligned)
+    uint32_t bitmap[RGeo<BIG>::TILE / 32];       // their first bytes
     uint16_t h0[RT2 + 8];              // every thread's first halfword (the second half of its neighbour's last reference)
     uint32_t pt[PTC];
     uint32_t part[3 * NW2];
     uint32_t again[3];                 // pointer jumping: somebody still has an unknown byte (flag of round r: r mod 3)
     uint32_t cut[2];                   // where the tile ends when the window holds more than a tile: bytes, halfword
 };
-typedef RLds2T<false> RLds2;
 
 // exclusive prefix sum over the workgroup; every thread gets the grand total too.  One barrier: s.part is not touched
 // again before the next barrier of the caller.
@@ -1321,16 +1331,18 @@ __device__ __forceinline__ void stream_verdict(const PStream &st, uint32_t S, ui
 // parts / pmax: the part table (scan) when streams may be cut into parts (pmax slots each; 0: they are not).  MARK = false
 // resolves a whole stream, or its first part (grid = streams); MARK = true the parts behind the first (grid = streams x
 // (pmax - 1)) into symbols at sym[st.sym_off + position].
-template <uint32_t RETRY, bool MARK>
+template <uint32_t RETRY, bool MARK, bool BIG>
 __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const PStream *__restrict__ streams, const PSeg *__restrict__ segs,
                                                                const uint32_t *__restrict__ pt_slab, DPool pool,
                                                                spng_result *__restrict__ results, int32_t *__restrict__ done,
                                                                PPart *__restrict__ parts, uint32_t pmax, uint16_t *__restrict__ sym)
 {
     constexpr uint32_t retry = RETRY;
+    constexpr uint32_t TILE2 = RGeo<BIG>::TILE, BPT2 = RGeo<BIG>::BPT, HPT2 = RGeo<BIG>::HPT, EB2 = RGeo<BIG>::EB, MAXM2 = RGeo<BIG>::MAXM;
+    static_assert(HPT2 == 8 || HPT2 == 4, "a thread's halfwords of a window are one 16- or 8-byte load");
     constexpr uint32_t DONE = MARK ? 0x4000u : R2_DONE;       // a state that is a byte ...
     constexpr uint32_t KNOWN = MARK ? 0xc000u : R2_DONE;      // ... or, MARK, a marker: nothing left to look up
-    __shared__ __attribute__((aligned(16))) RLds2T<MARK> s;
+    __shared__ __attribute__((aligned(16))) RLds2T<MARK, BIG> s;
     const int tid = threadIdx.x, lane = tid & 63, wave = (int)UNI((uint32_t)tid >> 6);
     const uint32_t sidx = MARK ? blockIdx.x / (pmax - 1) : blockIdx.x;
     const uint32_t pidx = MARK ? 1 + blockIdx.x % (pmax - 1) : 0;
@@ -1354,11 +1366,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
     }
     if (tid < (int)(TILE2 / 32)) s.bitmap[tid] = 0;
     if (tid < 3) s.again[tid] = 0;
-    if (tid == 0) { s.rec[0][0] = 0; s.rec[0][1] = 1; s.rec[0][2] = 0; s.rec[0][3] = 0; }
-    for (uint32_t i = (uint32_t)tid; i <= RTAB2; i += RT2) {
-        const float rd = __builtin_amdgcn_rcpf((float)(i ? i : 1u));
-        s.rtab[i][0] = __builtin_bit_cast(uint32_t, rd); s.rtab[i][1] = __builtin_bit_cast(uint32_t, 0.5f * rd);
-    }
+    if (tid == 0) { s.rec[0][0] = 0; s.rec[0][1] = 1; }
     __syncthreads();
     const uint32_t seg_first = UNI(st.seg_first), seg_count = UNI(st.seg_count);
     uint32_t sk = part ? UNI(part->seg) : 0;
@@ -1431,26 +1439,17 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                               !(tid == (int)RT2 - 1 && (hh[HPT2 - 1] & 0xC000) == 0x8000);
             if (front && !fits) { s.cut[0] = curb; s.cut[1] = (uint32_t)tid * HPT2; }
             if (fits) {
-                // (the distances and their reciprocals first, for every halfword whatever it is: the table reads travel together,
-                // ahead of the loop that is serial in curb)
-                uint32_t ddv[HPT2];
-                v2u rtv[HPT2];
-#pragma unroll
-                for (int j = 0; j < (int)HPT2; ++j) {
-                    const uint32_t h1 = j < (int)HPT2 - 1 ? hh[j < (int)HPT2 - 1 ? j + 1 : (int)HPT2 - 1] : hnext;
-                    ddv[j] = (((hh[j] >> 8) & 63) | (h1 & 0x1ff) << 6) + 1;
-                    rtv[j] = *(const v2u *)s.rtab[ddv[j] < RTAB2 ? ddv[j] : RTAB2];
-                }
 #pragma unroll
                 for (int j = 0; j < (int)HPT2; ++j) {
                     const uint32_t v = hh[j];
                     if (!(v & 0x8000)) { s.state[curb] = (uint16_t)(DONE | v); curb += 1; }
                     else if ((v & 0xC000) == 0x8000) {
                         const uint32_t len = (v & 0xff) + 3;
+                        const uint32_t h1 = j < (int)HPT2 - 1 ? hh[j < (int)HPT2 - 1 ? j + 1 : (int)HPT2 - 1] : hnext;
+                        const uint32_t dd = (((v >> 8) & 63) | (h1 & 0x1ff) << 6) + 1;
                         atomicOr(&s.bitmap[curb >> 5], 1u << (curb & 31));
-                        v4u r4;
-                        r4[0] = curb | len << 16; r4[1] = ddv[j]; r4[2] = rtv[j][0]; r4[3] = rtv[j][1];
-                        *(v4u *)s.rec[curm + 1] = r4;
+                        s.rec[curm + 1][0] = curb | len << 16;
+                        s.rec[curm + 1][1] = dd;
                         curb += len; curm += 1;
                     }
                 }
@@ -1477,7 +1476,8 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
             uint32_t sv[BPT2];
             {
                 // back-references that start in front of each row: prefix sum over the bitmap (lane l: rows 2l, 2l + 1)
-                const v4u bw = *(const v4u *)(s.bitmap + 4 * lane);
+                v4u bw = {0, 0, 0, 0};                                    // (a 4 KiB tile has 64 rows: lanes 0-31)
+                if ((uint32_t)lane < TILE2 / 128) bw = *(const v4u *)(s.bitmap + 4 * lane);
                 const uint32_t ca = (uint32_t)__popc(bw[0]) + (uint32_t)__popc(bw[1]), cbb = (uint32_t)__popc(bw[2]) + (uint32_t)__popc(bw[3]);
                 uint32_t tt;
                 const uint32_t rb = wave_excl_scan(ca + cbb, tt, lane);
@@ -1491,7 +1491,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                 constexpr bool EARLY = decltype(early_c)::value;
 #pragma unroll
                 for (int part = 0; part < (int)(BPT2 / EB2); ++part) {
-                    v4u recv[EB2];
+                    v2u recv[EB2];
 #pragma unroll
                     for (int kk = 0; kk < (int)EB2; ++kk) {
                         const int k = part * (int)EB2 + kk;
@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         // bits BELOW a lane's, so the row's word goes in shifted down by one and its bit 0 joins the base (scalar)
                         const unsigned long long mw1 = ((unsigned long long)mhi << 32 | mlo) >> 1;
                         const uint32_t id = __builtin_amdgcn_mbcnt_hi((uint32_t)(mw1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mw1, base + (mlo & 1)));
-                        recv[kk] = *(const v4u *)s.rec[id];            // (no reference in front of this byte: entry 0, run 0)
+                        recv[kk] = *(const v2u *)s.rec[id];            // (no reference in front of this byte: entry 0, run 0)
                     }
                     uint32_t siv[EB2], farv[EB2];
 #pragma unroll
@@ -1515,15 +1515,11 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         const bool inside = kk2 < len;             // (the tokens taken cover bytes 0 .. tlen - 1 and nothing else)
                         // A run longer than its distance repeats its first `distance` bytes: a byte beyond the first
                         // period copies the period in front of the run (same value, chain one level deep instead of
-                        // run / distance levels).  kk2 mod d: the quotient floor((kk2 + 0.5) / d) by one fused multiply-add with the
-                        // reference's 1 / d and 0.5 / d (kk2 < 258, d <= kk2: (kk2 + 0.5) / d is 0.5 / 257 away from an integer at
-                        // least, the float error is 2^-22 of the value)
-                        if (inside && kk2 >= d) {
-                            // (the words copied out first: clang's __builtin_bit_cast of a vector ELEMENT reads element 0)
-                            const uint32_t rw = recv[kk][2], hw = recv[kk][3];
-                            const uint32_t quo = (uint32_t)__builtin_fmaf((float)kk2, __builtin_bit_cast(float, rw), __builtin_bit_cast(float, hw));
-                            kk2 -= mul24(d, quo);
-                        }
+                        // run / distance levels).  kk2 mod d: kk2 < 258, so the quotient by v_rcp is exact ((kk2 + 0.5) / d is 0.5 / 257
+                        // away from an integer at least) and the product a 24-bit multiply.  (Round 5 also tried the reciprocals from
+                        // a table, kept in four-word records -- 5 full-rate instructions per byte here instead of 14 issue slots: the
+                        // kernel took as long as before; the expand phase is not bound by its instruction count.  r05_tuning.md)
+                        if (inside && kk2 >= d) kk2 -= mul24(d, (uint32_t)(((float)kk2 + 0.5f) * __builtin_amdgcn_rcpf((float)d)));
                         siv[kk] = inside ? startb - d + kk2 : 0x7fffffffu;                     // >= 0x80000000: before the tile
                         farv[kk] = s.ring[(rbase + siv[kk]) & (WINDOW2 - 1)];
                     }
@@ -1808,8 +1804,8 @@ hipError_t launch_pinf2_resolve(PStream *d_streams, uint32_t nstreams, PSeg *d_s
                                 spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax, uint32_t retry, hipStream_t stream)
 {
     DPool pool{d_pool, nullptr, pages, 0};
-    if (retry) pinf2_resolve_kernel<1, false><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, nullptr);
-    else pinf2_resolve_kernel<0, false><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, nullptr);
+    if (retry) pinf2_resolve_kernel<1, false, true><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, nullptr);
+    else pinf2_resolve_kernel<0, false, true><<<nstreams, RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, nullptr);
     return hipGetLastError();
 }
 // the parts behind the first of every stream (pmax >= 2) ...
@@ -1817,7 +1813,9 @@ hipError_t launch_pinf2_parts(PStream *d_streams, uint32_t nstreams, PSeg *d_seg
                               spng_result *d_results, int32_t *d_done, PPart *d_parts, uint32_t pmax, uint16_t *d_sym, hipStream_t stream)
 {
     DPool pool{d_pool, nullptr, pages, 0};
-    pinf2_resolve_kernel<0, true><<<nstreams * (pmax - 1), RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, d_sym);
+    // (more marker parts than CUs: the geometry two of them share a CU with -- RGeo)
+    if (nstreams * (pmax - 1) > 256) pinf2_resolve_kernel<0, true, false><<<nstreams * (pmax - 1), RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, d_sym);
+    else pinf2_resolve_kernel<0, true, true><<<nstreams * (pmax - 1), RT2, 0, stream>>>(d_streams, d_segs, d_pt, pool, d_results, d_done, d_parts, pmax, d_sym);
     return hipGetLastError();
 }
 // ... and, when they and the first parts are done: the windows, symbols -> bytes, the verdicts

@@ -262,18 +262,20 @@ def part_cases():
 PART_CASES = list(part_cases())
 
 
+@pytest.mark.parametrize("tile", [4096, 8192])
 @pytest.mark.parametrize("parts", [4])
 @pytest.mark.parametrize("name", [c[0] for c in PART_CASES])
-def test_emulated_pipeline_resolves_a_stream_in_parts(emu, tmp_path, name, parts):
+def test_emulated_pipeline_resolves_a_stream_in_parts(emu, tmp_path, name, parts, tile):
     """several workgroups per stream (api.hip: batches of few streams): the chain cut into parts, those behind the first resolved
     to symbols with markers for what lies in front of them, the windows handed from part to part, symbols -> bytes, one verdict
-    (Adler-32 over all parts) -- the same bytes and the same result as one workgroup gives"""
+    (Adler-32 over all parts) -- the same bytes and the same result as one workgroup gives.  The marker parts have two geometries
+    (4 KiB tiles, two workgroups per CU, when a batch has more of them than CUs; 8 KiB tiles otherwise): both."""
     _, z, raw, segment = next(c for c in PART_CASES if c[0] == name)
     assert zlib.decompress(z) == raw
     (tmp_path / "z").write_bytes(z)
     (tmp_path / "raw").write_bytes(raw)
     r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", str(segment)], capture_output=True, text=True,
-                       timeout=900, env=dict(os.environ, EMU_PARTS=str(parts)))
+                       timeout=900, env=dict(os.environ, EMU_PARTS=str(parts), EMU_MARK_TILE=str(tile)))
     assert r.returncode == 0, (name, r.stdout[-300:], r.stderr[-300:])
     made = int(r.stdout.split("parts:")[1].split()[0])
     assert 2 <= made <= parts, r.stdout
@@ -281,7 +283,7 @@ def test_emulated_pipeline_resolves_a_stream_in_parts(emu, tmp_path, name, parts
     bad = bytearray(z); bad[-1] ^= 0x20
     (tmp_path / "z").write_bytes(bytes(bad))
     r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", str(segment)], capture_output=True, text=True,
-                       timeout=900, env=dict(os.environ, EMU_PARTS=str(parts)))
+                       timeout=900, env=dict(os.environ, EMU_PARTS=str(parts), EMU_MARK_TILE=str(tile)))
     assert r.returncode == 5 and "error" in r.stdout, (r.returncode, r.stdout[-300:])
 
 

@@ -115,7 +115,7 @@ int main(int argc, char **argv)
         if (verbose || i != out.size() || (st.ok == 1 && out.size() != want.size()))
             fprintf(stderr, "token stream expands to %zu bytes, agrees with the expected bytes up to %zu of %zu\n", out.size(), i, want.size());
     }
-    emu::launch(1, RT2, [&] { pinf2_resolve_kernel<0, false>(&st, segs.data(), pt.data(), pool, &res, &done, parts.data(), pmax, nullptr); });
+    emu::launch(1, RT2, [&] { pinf2_resolve_kernel<0, false, true>(&st, segs.data(), pt.data(), pool, &res, &done, parts.data(), pmax, nullptr); });
     // EMU_RETRY_PAGES=n: a stream whose segments found the pool empty takes the retry pass (api.hip: the pool to itself and
     // its like -- here a second pool of n pages)
     if (getenv("EMU_RETRY_PAGES")) {
@@ -128,11 +128,15 @@ int main(int argc, char **argv)
         emu::launch((unsigned)k, 64, [&] { pinf2_find_kernel<1>(&st, segs.data(), 0); });
         emu::launch((unsigned)k, 64, [&] { pinf2_decode_kernel<1>(&st, segs.data(), pt.data(), pool2, 0); });
         emu::launch(1, 64, [&] { pinf2_scan_kernel<1>(&st, segs.data(), parts.data()); });
-        emu::launch(1, RT2, [&] { pinf2_resolve_kernel<1, false>(&st, segs.data(), pt.data(), pool2, &res, &done, parts.data(), 0, nullptr); });
+        emu::launch(1, RT2, [&] { pinf2_resolve_kernel<1, false, true>(&st, segs.data(), pt.data(), pool2, &res, &done, parts.data(), 0, nullptr); });
         printf("retry pass: ok %d done %d pages %u\n", st.ok, done, next2);
     }
     if (pmax >= 2) {
-        emu::launch(pmax - 1, RT2, [&] { pinf2_resolve_kernel<0, true>(&st, segs.data(), pt.data(), pool, &res, &done, parts.data(), pmax, sym.data()); });
+        // (api.hip picks the marker parts' geometry by their number; here EMU_MARK_TILE=8192 asks for the big tiles)
+        if (getenv("EMU_MARK_TILE") && atoi(getenv("EMU_MARK_TILE")) == 8192)
+            emu::launch(pmax - 1, RT2, [&] { pinf2_resolve_kernel<0, true, true>(&st, segs.data(), pt.data(), pool, &res, &done, parts.data(), pmax, sym.data()); });
+        else
+            emu::launch(pmax - 1, RT2, [&] { pinf2_resolve_kernel<0, true, false>(&st, segs.data(), pt.data(), pool, &res, &done, parts.data(), pmax, sym.data()); });
         emu::launch(1, 512, [&] { pinf2_window_kernel(&st, parts.data(), pmax, sym.data(), win.data()); });
         emu::launch(FIX_WG, 256, [&] { pinf2_fixup_kernel(&st, parts.data(), pmax, sym.data(), win.data()); }, pmax - 1);
         emu::launch(1, 64, [&] { pinf2_verdict_kernel(&st, parts.data(), pmax, &res, &done, 1); });

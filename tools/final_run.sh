@@ -4,9 +4,20 @@
 # deflate of 1024 random 64 MiB streams), the N = 8 shard shape, then the headline bench line (it reads the traffic measured here).
 # Everything lands in gpurun_out/ (copied to profiles/ afterwards).
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-R=${R:-r05}
+export R=${R:-r05}
 T0=$(date +%s); lap() { echo "[t+$(( $(date +%s) - T0 )) s] $1"; }
 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
+# A/B in front of everything (AB="name name": builds under variants/, tools/build_variant.sh): the shipped library is the LAST name's
+# build; an earlier one that decodes the headline workload more than 0.5 % faster takes its place for the rest of this run
+# (gpurun_out/${R}_ab.txt says which -- the source is then set to match before the round ends)
+if [ -n "$AB" ]; then
+  for v in $AB; do
+    SPNG_LIB=/root/repo/variants/libspng_$v.so timeout 300 python tools/probe_v2.py --kinds swiftpng --steps 3 > gpurun_out/${R}_ab_$v.log 2>&1
+    echo "== $v $(grep -E '^swiftpng auto' gpurun_out/${R}_ab_$v.log | cut -c1-230)"
+  done
+  python tools/ab_pick.py $R $AB > gpurun_out/${R}_ab.txt
+  cat gpurun_out/${R}_ab.txt; lap "A/B"
+fi
 [ -n "$SKIP_TESTS" ] || timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${R}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${R}_pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${R}_smoke.log 2>&1; tail -1 gpurun_out/${R}_smoke.log; lap "tests + smoke"
 # decode: kernel-trace stats of the bench command
@@ -32,3 +43,5 @@ cp gpurun_out/${R}_pmc_encode.json profiles/${R}_pmc_encode.json
 [ -n "$SKIP_PROBES" ] || { timeout 400 python tools/probe_groups.py --kind zlib --unique 4 > gpurun_out/${R}_probe_groups.log 2>&1; head -3 gpurun_out/${R}_probe_groups.log
 PROBE_LEVEL=6 PROBE_WHICH=synth4k,photo PROBE_N=256 timeout 300 python tools/probe_deflate2.py > gpurun_out/${R}_probe_l6_256.log 2>&1; tail -2 gpurun_out/${R}_probe_l6_256.log; }
 rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_enc gpurun_out/enc_fetch gpurun_out/enc_write gpurun_out/enc_insts
+# phase cycle counters of one decode wave / one resolve workgroup (a -DSPNG_D_PROF build of the shipped source)
+[ ! -f variants/libspng_g_prof.so ] || { SPNG_LIB=/root/repo/variants/libspng_g_prof.so timeout 200 python tools/probe_v2.py --kinds swiftpng --steps 1 > gpurun_out/${R}_dprof.log 2>&1; grep -E "^(decode|resolve)" gpurun_out/${R}_dprof.log | sort | uniq -c | sort -rn | head -4 | cut -c1-400; }
