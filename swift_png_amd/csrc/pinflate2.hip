@@ -829,11 +829,14 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
     uint32_t q = q0, st = 0;                                    // st: 0 running, 1 end of block, 2 not a token
     uint64_t mb0 = 0, mb1 = 0;                                  // !RM: which of my tokens (by ordinal) are back-references
     uint32_t ntk = 0, edge = 0;
+    uint32_t qx = 0;
     while (q < sub1) {
         DPN(16, 1);
         uint32_t k, len0;
         uint32_t nb = decode_at2<false, PAIRS>(s, q, k, len0, d0, d1);
-        if (RARE((k & 1) != 0)) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
+        // (ONE way out of the loop, its condition: a lane that stops parks q behind everything and keeps where it stopped in qx --
+        // a `break` costs every step the exec-mask bookkeeping of a second exit: decode 275.3 -> 268.4 ms, r05_tuning.md section 5)
+        if (RARE((k & 1) != 0)) { st = k == D2_EOB ? 1u : 2u; qx = k == D2_EOB ? q + nb : q; q = 0xffffffffu; continue; }
         const uint32_t b = q - sub0;
         if (RM) {
             // (the mark and, for a back-reference, the one behind it -- in the next word when the token starts on a word's last
@@ -858,6 +861,7 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
         }
         q += nb;
     }
+    if (st) q = qx;
     if (q > lim) st = 2;                                        // (a chain that runs off the input: zeros from there on)
     WSYNC();
     DP(2);
@@ -885,11 +889,12 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
             // (bit i of `front`: the mark in front of bit i)
             const uint32_t front = RM ? __builtin_amdgcn_alignbit(mword, pword, 31) : 0u;
             if (RM && ((mword & front) >> (b & 31)) & 1) COV(5);
-            if (((mword & ~front) >> (b & 31)) & 1) { link = j; break; }
-            if (RARE((k & 1) != 0)) { st = k == D2_EOB ? 1u : 2u; if (k == D2_EOB) q += nb; break; }
+            if (((mword & ~front) >> (b & 31)) & 1) { link = j; qx = q; q = 0xffffffffu; continue; }
+            if (RARE((k & 1) != 0)) { st = k == D2_EOB ? 1u : 2u; qx = k == D2_EOB ? q + nb : q; q = 0xffffffffu; continue; }
             cnt2 += 1 + (PAIRS ? (k >> 1) & 1 : k >> 1);
             q += nb;
         }
+        if (q == 0xffffffffu) q = qx;
         if (q > lim) st = 2;
     }
     // q: where my chain merged / left the chunk / stopped
