@@ -836,7 +836,7 @@ static int32_t launch_inflate_plan(spng_ctx *c, InflatePlan &p, Arena &a, spng_r
             HIP_TRY(launch_pinf2_scan(ds + g.s0, g.s1 - g.s0, dg, dparts, retry, q));
             {
                 Timed t(c, SPNG_K_PINF_RESOLVE, q);
-                // (the parts behind the first on the second stream, beside the first parts: 93 KB + 61 KB of LDS share a CU)
+                // (the parts behind the first on the second stream, beside the first parts: 79 KB -- 93 KB when they have a CU each -- and 61 KB of LDS share a CU)
                 hipStream_t q2 = q;
                 if (pm && !p.overlap) {
                     if (!c->stream2) {
