@@ -991,7 +991,8 @@ __device__ __forceinline__ uint32_t decode_chunk(DLds &s, const g8 *src, uint64_
                 uint32_t h0 = 0, h1 = 0;
                 uint32_t k, len0;
                 const uint32_t nb = decode_at2<true, PAIRS>(s, qq, k, len0, h0, h1);
-                // (of a pair of literals whose second one starts in the next subsequence only the first is mine)
+                // (a pair's second literal is mine only when my count says so: round 0 cuts a pair at its subsequence's end, the
+                // crossing chain of round 1 does not)
                 const bool two = PAIRS ? (k & 2) != 0 && done + 2 <= mine : k == D2_REF;
                 if (ONE) {
                     g16 *t = (g16 *)(pa + ((r0 + done) << 1));
