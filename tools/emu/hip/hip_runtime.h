@@ -21,7 +21,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#if defined(__x86_64__) && !defined(EMU_UCONTEXT)
+#define EMU_FAST_SWITCH 1      // a context switch of our own: glibc's swapcontext saves and restores the signal mask with a system
+                               // call per switch -- half of the emulator's run time was spent in the kernel
+#else
 #include <ucontext.h>
+#endif
 #include <functional>
 #include <vector>
 
@@ -45,9 +50,31 @@ struct dim3e { unsigned x, y, z; };
 enum { RUN = 0, WAIT_WAVE = 1, WAIT_BLOCK = 2, DONE = 3 };
 enum { OP_BALLOT = 1, OP_SHFL, OP_DPP, OP_FENCE, OP_READFIRST, OP_SYNCOR };
 
+#ifdef EMU_FAST_SWITCH
+// Saves the callee-saved registers of the System V x86-64 ABI on the current stack, stores the stack pointer in *from, takes *to
+// as the stack pointer and restores from there; a fresh fiber's stack is laid out as if it had been switched away from in front
+// of its entry function (launch()).  Fibers are plain integer code: the x87 / SSE control words are the same everywhere.
+struct Ctx { void *sp = nullptr; };
+extern "C" void emu_switch(Ctx *from, Ctx *to);
+__asm__(".text\n"
+        ".globl emu_switch\n"
+        ".type emu_switch,@function\n"
+        "emu_switch:\n"
+        "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"
+        "  movq %rsp, (%rdi)\n"
+        "  movq (%rsi), %rsp\n"
+        "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n"
+        "  ret\n"
+        ".size emu_switch,.-emu_switch\n");
+#else
+struct Ctx { ucontext_t uc; };
+inline void emu_switch(Ctx *from, Ctx *to) { swapcontext(&from->uc, &to->uc); }
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
-    std::vector<char> stack;
+    Ctx ctx;
+    char *stack = nullptr;                              // (from launch()'s pool: allocated once, never zeroed again)
+    size_t stack_size = 0;
     dim3e tid, bid, bdim, gdim;
     int state = RUN;
     int op = 0;
@@ -58,9 +85,9 @@ struct Fiber {
 };
 
 inline Fiber *&cur() { static Fiber *c = nullptr; return c; }
-inline ucontext_t &sched_ctx() { static ucontext_t c; return c; }
+inline Ctx &sched_ctx() { static Ctx c; return c; }
 
-inline void yield_to_sched() { swapcontext(&cur()->ctx, &sched_ctx()); }
+inline void yield_to_sched() { emu_switch(&cur()->ctx, &sched_ctx()); }
 
 inline uint64_t wave_op(int op, uint64_t a, uint64_t b = 0, int src = 0)
 {
@@ -70,13 +97,24 @@ inline uint64_t wave_op(int op, uint64_t a, uint64_t b = 0, int src = 0)
     return f->out;
 }
 
+#ifdef EMU_FAST_SWITCH
+inline void fiber_entry()                                       // (entered by emu_switch's `ret`: the fiber is cur())
+{
+    Fiber *f = cur();
+    (*f->body)();
+    f->state = DONE;
+    emu_switch(&f->ctx, &sched_ctx());
+    abort();                                                    // (a finished fiber is not switched to again)
+}
+#else
 inline void trampoline(unsigned lo, unsigned hi)
 {
     Fiber *f = (Fiber *)(((uintptr_t)hi << 32) | lo);
     (*f->body)();
     f->state = DONE;
-    swapcontext(&f->ctx, &sched_ctx());
+    emu_switch(&f->ctx, &sched_ctx());
 }
+#endif
 
 // resolves a wave whose live lanes all wait at a wave op
 inline void resolve_wave(std::vector<Fiber> &fb, size_t base, size_t n)
@@ -129,19 +167,34 @@ inline void launch(unsigned grid, unsigned block, const std::function<void()> &b
         fb.clear(); fb.resize(block);
         for (unsigned t = 0; t < block; ++t) {
             Fiber &f = fb[t];
-            f.stack.resize(256 << 10);
+            // (stacks are kept between launches: a fresh 256 KB vector per fiber and launch was a mmap, a page-fault storm and a
+            // munmap each)
+            static std::vector<char *> pool;
+            while (pool.size() <= t) pool.push_back((char *)malloc(256 << 10));
+            f.stack = pool[t]; f.stack_size = 256 << 10;
             f.tid = {t, 0, 0}; f.bid = {b % grid, b / grid, 0}; f.bdim = {block, 1, 1}; f.gdim = {grid, gridy, 1};
             f.body = &body; f.state = RUN;
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = f.stack.data(); f.ctx.uc_stack.ss_size = f.stack.size(); f.ctx.uc_link = nullptr;
+#ifdef EMU_FAST_SWITCH
+            // the stack as emu_switch leaves one: six saved registers, the address it returns to (the entry function), and a
+            // slot above it so that the entry function finds the stack aligned as after a call
+            uintptr_t top = ((uintptr_t)f.stack + f.stack_size) & ~(uintptr_t)15;
+            void **sp = (void **)top;
+            *--sp = nullptr;                                    // (where a return address would be: fiber_entry never returns)
+            *--sp = (void *)fiber_entry;
+            for (int r = 0; r < 6; ++r) *--sp = nullptr;        // rbp, rbx, r12 - r15
+            f.ctx.sp = sp;
+#else
+            getcontext(&f.ctx.uc);
+            f.ctx.uc.uc_stack.ss_sp = f.stack; f.ctx.uc.uc_stack.ss_size = f.stack_size; f.ctx.uc.uc_link = nullptr;
             const uintptr_t p = (uintptr_t)&f;
-            makecontext(&f.ctx, (void (*)())trampoline, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+            makecontext(&f.ctx.uc, (void (*)())trampoline, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+#endif
         }
         for (;;) {
             bool progressed = false, all_done = true;
             for (unsigned t = 0; t < block; ++t) {
                 Fiber &f = fb[t];
-                if (f.state == RUN) { cur() = &f; swapcontext(&sched_ctx(), &f.ctx); progressed = true; }
+                if (f.state == RUN) { cur() = &f; emu_switch(&sched_ctx(), &f.ctx); progressed = true; }
                 if (f.state != DONE) all_done = false;
             }
             if (all_done) break;
