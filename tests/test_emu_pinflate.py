@@ -287,7 +287,7 @@ def test_emulated_pipeline_resolves_a_stream_in_parts(emu, tmp_path, name, parts
     assert r.returncode == 5 and "error" in r.stdout, (r.returncode, r.stdout[-300:])
 
 
-@pytest.mark.parametrize("seed", [3, 17, 29, 41, 58, 77])
+@pytest.mark.parametrize("seed", [3, 17, 29, 41, 58, 77, 5003, 7011, 9040, 11013, 15007, 17020, 19033, 30010])
 def test_emulated_pipeline_random_streams(emu, tmp_path, seed):
     """tools/emu/fuzz_pinflate.py: random data x zlib parameters x flush pattern x segment length x resolve parts (hundreds of
     seeds were run when the pipeline changed; a few stay in the suite)"""
