@@ -104,7 +104,8 @@ typedef struct spng_image_desc {
     uint8_t     channels;                       /* 1 (v / indexed), 2 (va), 3 (rgb), 4 (rgba)  */
     uint8_t     interlaced;                     /* Adam7                                       */
     uint8_t     format;                         /* SPNG_FORMAT_*                               */
-    uint32_t    reserved;                       /* flags: SPNG_IMAGE_OVERDRAW (spng_unfilter_resume_batch) */
+    uint32_t    reserved;                       /* flags, MUST be zero-initialised: SPNG_IMAGE_OVERDRAW (spng_unfilter_resume_batch
+                                                 * acts on it and refuses unknown bits with SPNG_E_ARGUMENT) */
 } spng_image_desc;
 /* PNG.Context.push(data:overdraw: true) (PNG.Context.swift:88-102, PNG.Image.overdraw, PNG.Image.swift:134-183): while an
  * interlaced image is incomplete, every assigned pixel is replicated over the cell of storage the later passes will refine,

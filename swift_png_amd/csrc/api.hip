@@ -1031,7 +1031,8 @@ int32_t spng_unfilter_resume_batch(spng_ctx *c, const spng_image_desc *descs, vo
     std::vector<spng_result> res(count);
     for (uint32_t i = 0; i < count; ++i) {
         const spng_image_desc &d = descs[i];
-        if (!valid_format(d.depth, d.channels) || !d.d_rows || !d.d_storage || h_prev_len[i] > h_now_len[i]) return SPNG_E_ARGUMENT;
+        if (!valid_format(d.depth, d.channels) || !d.d_rows || !d.d_storage || h_prev_len[i] > h_now_len[i] ||
+            (d.reserved & ~(uint32_t)SPNG_IMAGE_OVERDRAW)) return SPNG_E_ARGUMENT;   // (unknown flag bits: an uninitialised desc)
         const int volume = d.depth * d.channels;
         const uint32_t bpp = (uint32_t)(volume + 7) >> 3;
         const uint64_t u = spng_inflated_size(d.width, d.height, d.depth, d.channels, d.interlaced);
@@ -1817,12 +1818,16 @@ static int32_t deflate_fast_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
     };
     auto round_of = [&](const DeflateJob &j) -> uint64_t { const uint64_t sp = span_of(j); return sp < RV ? sp : RV; };
     auto al = [](uint64_t b) -> uint64_t { return (b + 255) & ~255ull; };
+    // (dfl4_scan / dfl4_place find a block's first bit at bbits[launch's max_blocks + k]: every stream's bbits is sized by the
+    // largest block count of the call, not by its own -- ADVICE r5: a short stream beside a long one had its staged bits overwritten)
+    uint64_t mb_all = 0;
+    for (size_t i = first; i < mid; ++i) { const uint64_t mb = deflate4_max_blocks(round_of(sorted[i])); mb_all = mb > mb_all ? mb : mb_all; }
     auto scratch_of = [&](const DeflateJob &j, bool blocks) -> uint64_t {
         const uint64_t V = round_of(j) + 64;
         uint64_t b = 2 * al(4 * V);
         if (blocks) {
             const uint64_t mb = deflate4_max_blocks(round_of(j));
-            b += al(4 * (V + 4096)) + al(4 * (4 + 2 * mb)) + al(16 * mb) + al(mb * deflate4_block_bytes() + 64);
+            b += al(4 * (V + 4096)) + al(4 * (4 + 2 * mb)) + al(16 * mb_all) + al(mb * deflate4_block_bytes() + 64);
         }
         return b;
     };
@@ -1881,7 +1886,7 @@ static int32_t deflate_fast_rounds(spng_ctx *c, std::vector<DeflateJob> &sorted,
             if (gr.blocks) {
                 const uint64_t mb = deflate4_max_blocks(round_of(j));
                 s.terms = (uint32_t *)take(4 * (V + 4096)); s.bdesc = (uint32_t *)take(4 * (4 + 2 * mb));
-                s.bbits = (uint64_t *)take(16 * mb); s.scratch = (uint8_t *)take(mb * deflate4_block_bytes() + 64);
+                s.bbits = (uint64_t *)take(16 * mb_all); s.scratch = (uint8_t *)take(mb * deflate4_block_bytes() + 64);
                 maxb_of[i - first] = (uint32_t)mb;
             }
             const uint64_t sp = span_of(j);
@@ -2021,7 +2026,9 @@ int32_t spng_deflate_resume_batch(spng_ctx *c, const spng_stream_desc *descs, co
         j.format = descs[i].format; j.level = levels[i]; j.image = i; j.exponent = descs[i].format == SPNG_FORMAT_IOS ? 15u : (uint32_t)e;
         j.more = last[i] ? 0u : 1u; j.state = (D1State *)d_states[i];
         if (h_state) { j.plan_pos = h_state[2 * i]; j.plan_limit = (uint32_t)h_state[2 * i + 1]; j.plan_aux = h_state[2 * i + 1]; }
-        if (j.plan_pos > j.src_len) return SPNG_E_ARGUMENT;     // (a state is only ever what an earlier call handed out)
+        // (a state is only ever what an earlier call handed out: the search position it names lies inside what the input allows --
+        // the match arrays and the round count of levels 0-7 are sized from it)
+        if (j.plan_pos > j.src_len || (levels[i] < 8 && j.plan_aux > deflate3_end(j.src_len, j.more != 0))) return SPNG_E_ARGUMENT;
         jobs[i] = j;
     }
     if (int32_t st = c->reserve(count * (sizeof(DeflateJob) + sizeof(spng_result) + sizeof(D2Stream) + sizeof(D2State) + sizeof(D3Stream) + sizeof(D1State) + 1024 + (gzip ? 4 * (size_t)gzip_pieces() : 0)) + 8192)) return st;
@@ -2196,6 +2203,7 @@ int32_t spng_decode_batch_multi(spng_ctx *const *ctxs, uint32_t n_ctx, const spn
             const uint32_t g0 = (uint32_t)((uint64_t)n * g / groups), g1 = (uint32_t)((uint64_t)n * (g + 1) / groups);
             status = spng_decode_batch(c, descs + first + g0, g1 - g0, d_res + g0, nullptr);
             if (status != SPNG_DONE || !leaves) continue;
+            sent[k] = 1;                                       // (before the first copy is enqueued: a failure half way still waits for stream_out below)
             if (hipError_t e = hipEventRecord(c->ev_out[g & 1], c->stream); e != hipSuccess) { status = fail_hip(e, "hipEventRecord"); break; }
             if (hipError_t e = hipStreamWaitEvent(c->stream_out, c->ev_out[g & 1], 0); e != hipSuccess) { status = fail_hip(e, "hipStreamWaitEvent"); break; }
             for (uint32_t i = first + g0; i < first + g1; ++i) {
@@ -2204,7 +2212,6 @@ int32_t spng_decode_batch_multi(spng_ctx *const *ctxs, uint32_t n_ctx, const spn
                 const hipError_t e = hipMemcpyPeerAsync(d_gather[i], root->device, descs[i].d_storage, c->device, s, c->stream_out);
                 if (e != hipSuccess) { status = fail_hip(e, "hipMemcpyPeerAsync"); break; }
             }
-            sent[k] = 1;
         }
     }
     // wait for everything that was enqueued (also on the way out of a failure), results to the host

@@ -549,6 +549,32 @@ def test_deflate_greedy_lazy_over_several_rounds(gpu, level):
     assert s.deflate(data, level) == ph.orc_deflate(data, level)
 
 
+@pytest.mark.parametrize("level", [1, 6])
+def test_deflate_batch_of_streams_of_different_lengths(gpu, level):
+    """in one call of spng_deflate_batch at levels 0-7 the block-placement kernels index every stream's block
+    start bits by the LAUNCH's largest block count; a short stream beside a long one had its staged bits overwritten and still
+    reported SPNG_DONE.  10 KB, 200 KB and 3 MB (and the short ones once more behind the long one) in one call: every stream is
+    the oracle's."""
+    import torch
+    s = gpu.load()
+    rng = np.random.default_rng(77 + level)
+
+    def content(n, seed):
+        r = np.random.default_rng(seed)
+        a = r.integers(-4, 5, n).astype(np.int16)
+        a[r.random(n) < 0.5] = 0
+        return np.cumsum(a).astype(np.uint8).tobytes()
+
+    sizes = [10_000, 200_000, 3 << 20, 10_007, 65_000, 1, 0, 2046 * 3]
+    datas = [content(n, 1000 + i) if n else b"" for i, n in enumerate(sizes)]
+    tens = [torch.frombuffer(bytearray(d or b"\0"), dtype=torch.uint8).cuda()[:len(d)] for d in datas]
+    outs, res = s.deflate_batch(tens, level)
+    for i, (d, o, r) in enumerate(zip(datas, outs, res)):
+        assert r.status == gpu.DONE, (i, r.status)
+        got = bytes(o[:r.written].cpu().numpy())
+        assert got == ph.orc_deflate(d, level), (i, sizes[i], r.written)
+
+
 def test_deflate_block_boundaries(gpu):
     """Blocks close after 2047 terms (greedy) / 2046-2047 (lazy); literal-only inputs around the
     boundary exercise the term-buffer guards (DeflatorBuffers.Stream.swift:219,277)."""

@@ -2,7 +2,7 @@
 """BASELINE configs[4]: one 8192x8192 RGBA16 Adam7 image; per-stage times."""
 import sys, time, zlib
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import torch
 import swift_png_amd as spng

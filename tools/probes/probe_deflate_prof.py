@@ -2,7 +2,7 @@
 """Phase cycle counts of the deflate kernels (library built with -DSPNG_DEFLATE_PROF, passed as SPNG_LIB)."""
 import sys, time, zlib
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import torch, numpy as np
 import swift_png_amd as spng

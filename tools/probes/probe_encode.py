@@ -2,7 +2,7 @@
 """How long does one 4K stream take at level 9 (random / photographic-like)?"""
 import sys, time, zlib
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import torch, numpy as np
 import swift_png_amd as spng

@@ -5,7 +5,7 @@ run under `rocprofv3 --kernel-trace --stats` it shows which kernels the differen
 """
 import argparse, json, sys, time
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402
 
