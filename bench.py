@@ -8,9 +8,10 @@
 decode (default).  A "step" is one pass of the decode hot path (spng_decode_batch: inflate -> unfilter,
 results left in HBM) over the whole batch.  Workload = BASELINE.json configs[1]: 1024 synthetic
 4096x4096 RGBA8 PNG streams, mixed filters chosen by the reference's own heuristic, DEFLATE level 6.
-The headline line is measured on zlib-made level-6 streams; the same batch re-encoded by the device
-deflater (swift-png's own level-6 bitstream: a dynamic block every <= 2047 tokens) is measured in the
-same run and reported under "swiftpng_streams".  At N > 1 the default is configs[2]: the SAME 1024
+The headline line is measured on swift-png-made level-6 streams (the batch's scanlines deflated by the
+device deflater, bit-exact with LZ77.Deflator: a dynamic block every <= 2047 tokens; `--streams`); the
+same scanlines deflated by host zlib (16 K-token blocks) are measured in the same run and reported under
+"zlib_streams".  At N > 1 the default is configs[2]: the SAME 1024
 images sharded 1024/N per GPU ("strong"), every rank decoding its shard in groups whose rasters travel
 to rank 0 over RCCL (grouped point-to-point, xGMI) while the next group decodes; `--scaling weak`
 gives every GPU its own 1024 images instead.  Compressed inputs are resident in HBM before the timed
@@ -42,7 +43,7 @@ DEPTH, CHANNELS = 8, 4
 MPIX = W * H / 1e6
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 STAGES = ("pinf_find", "pinf_decode", "pinf_resolve", "inflate", "unfilter")
-PMC_FILE = "r05_pmc_traffic.json"      # rocprofv3 --pmc passes of this very workload (tools/final_run.sh), committed
+PMC_FILE = "r06_pmc_traffic.json"      # rocprofv3 --pmc passes of this very workload (bench.py --traffic / tools/final_run.sh), committed
 
 
 def build_inputs(session, unique: int, threads: int, encoder: str):
@@ -122,6 +123,41 @@ def cpu_baseline(streams, images, rows, cores: int):
             "one_core": {"value": round(v_one, 2), "unit": "MPixels/s", "cores": 1, "sample": f"2 images, {one['wall_s']:.1f} s"},
             "zlib_anchor": {"value": round(MPIX / dtz, 2), "unit": "MPixels/s", "cores": 1,
                             "sample": f"zlib 1.2.11 inflate + oracle defilter of 1 image, {dtz:.1f} s"}}
+
+
+def measure_traffic(args):
+    """--traffic: HBM bytes per kernel measured for THIS invocation -- two rocprofv3 --pmc sub-runs (FETCH_SIZE, WRITE_SIZE: separate
+    passes, as MI355X_MICROARCH.md prescribes) of this script on the headline workload, a warm-up step and a timed one each, before
+    this process touches the GPU; the result replaces profiles/PMC_FILE (which carries the digest of the sources it was taken on)."""
+    import shutil
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="spng_pmc_")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        sub = [sys.executable, str(Path(__file__).resolve()), "--steps", "1", "--warmup", "1", "--no-alt", "--no-cpu-baseline", "--no-extras",
+               "--images", str(args.images), "--unique", str(args.unique), "--streams", args.streams]
+        for counter, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, d), "--"] + sub,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-300:]
+        dst = ROOT / "profiles" / PMC_FILE
+        r = subprocess.run([sys.executable, str(ROOT / "tools" / "pmc_traffic.py"), os.path.join(tmp, "fetch"), os.path.join(tmp, "write"),
+                            args.streams, str(args.images), str(args.unique), str(dst), "2"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-300:]
+        return True
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def traffic_provenance(kind: str):
+    """where `traffic` comes from and whether it describes the sources that are running"""
+    try:
+        import swift_png_amd as spng
+        cfg = json.loads((ROOT / "profiles" / PMC_FILE).read_text())["configs"][kind]
+        mine, theirs = spng.source_digest(), cfg.get("source_digest")
+        return {"file": "profiles/" + PMC_FILE, "source_digest_measured": theirs, "source_digest_running": mine, "same_sources": mine == theirs}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def pmc_traffic(kind: str, images: int, unique: int):
@@ -428,6 +464,41 @@ def run_single_image(torch, spng, s, stream, image, steps=5):
             "ms": round(dt * 1e3, 3), "mpixels_per_s": round(MPIX / dt, 1), "kernels_ms": prof, "bit_exact": True}
 
 
+def run_shard_probe(torch, spng, s, streams, images, steps=3):
+    """The per-GPU unit of BASELINE configs[2] at N = 8, measured where it can be measured: 128 of the headline's images in ONE
+    spng_decode_batch call (and in two calls of 64, the form whose rasters could travel while the second half decodes) on this one
+    GPU -- what a rank of the 8-GPU strong-scaling run computes per step before any gather.  Linear share of the headline step =
+    ms_per_step / 8."""
+    unique = len(streams)
+    d_streams = [s.to_device(z) for z in streams]
+    out = {"workload": "128 x 4096x4096 RGBA8 (the headline's streams) per call on ONE GPU: the shard of configs[2] at N = 8"}
+    ref = [s.to_device(img.reshape(-1)) for img in images]
+    for groups in (1, 2):
+        job = DecodeJob(spng, s, torch, d_streams, 128, 0, unique, groups)
+        for _ in range(2):
+            for g in range(groups):
+                job.decode_group(g)
+        torch.cuda.synchronize()
+        s.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for g in range(groups):
+                job.decode_group(g)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        prof = {k: round(s.profile_get(getattr(spng, "K_" + k.upper()))[0] / steps, 2) for k in STAGES}
+        s.profile(False)
+        res = job.results()
+        assert all(r.status == 0 and r.written == job.U and r.reserved == 1 for r in res)
+        for j in range(0, 128, 9):
+            assert torch.equal(job.d_out[j * job.S:(j + 1) * job.S], ref[job.src[j]]), f"shard probe: slot {j} differs"
+        out[f"calls_{groups}"] = {"ms": round(dt * 1e3, 2), "mpixels_per_s": round(128 * MPIX / dt, 1), "stages_ms": prof}
+        job.d_rows = job.d_out = job.dres = None
+        del job
+        torch.cuda.empty_cache()
+    return out
+
+
 def run_config5(torch, spng, s, steps):
     """BASELINE configs[4]: one 8192 x 8192 RGBA16 Adam7 image (536,886,272 inflated bytes, seven sub-images, one
     stream), level 6, decoded on one GPU: inflate pipeline + per-pass unfilter + scatter."""
@@ -700,12 +771,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="decode mode: skip the copy ceiling, configs[3] / configs[4] and file -> pixels legs")
+    ap.add_argument("--legs", default="", help="decode mode: comma list of the extra legs to run (default: all of them)")
+    ap.add_argument("--traffic", action="store_true",
+                    help="measure `traffic` inside this invocation: two rocprofv3 --pmc sub-runs of the headline workload first (about 3 min)")
+    ap.add_argument("--encode-steps", type=int, default=3, help="decode mode: timed steps of the two encode legs (after one warm-up)")
     ap.add_argument("--encode-images", type=int, default=1024,
                     help="decode mode: images of the configs[3] leg (BASELINE: 1024)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_spawn(args))
+
+    measured_now = False
+    if args.traffic and args.gpus == 1 and args.mode == "decode":
+        try:
+            measured_now = measure_traffic(args)
+        except Exception as exc:                               # noqa: BLE001  (the line still carries the committed figures, labelled)
+            print(f"--traffic: PMC sub-runs failed ({repr(exc)[:200]}); using profiles/{PMC_FILE}", file=sys.stderr)
 
     import torch
     import torch.distributed as dist
@@ -772,8 +854,10 @@ def main():
                          "traffic": (d.get("traffic") // d.get("launches_per_step", 1)) if d.get("traffic") else d.get("traffic"),
                          "ms_per_launch": d.get("ms_per_launch", d["ms_per_step"]), "launches_per_step": d.get("launches_per_step", 1),
                          "algorithmic_bytes_per_launch": d["algorithmic_bytes"] // d.get("launches_per_step", 1),
-                         **({"traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                               "workload, not measured in this run)"} if d.get("traffic") else {})},
+                         **({"traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE sub-runs of this invocation (--traffic)" if measured_now else
+                                                "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, not measured in this "
+                                                "run; `traffic_provenance` says on which sources)"),
+                             "traffic_provenance": traffic_provenance(args.streams)} if d.get("traffic") else {})},
             "kernels": kernels,
         }
         if world > 1:
@@ -804,7 +888,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(m["streams"], m["images"], m["rows"], cores)
         if world == 1 and not args.no_extras:
             # the other BASELINE configs and the path's neighbours, each on a bounded workload (never lose the headline to one)
+            only = set(args.legs.split(",")) if args.legs else None
+
             def leg(name, fn):
+                if only is not None and name not in only:
+                    return
                 try:
                     s.trim()                                   # (the context's scratch of the leg before: each leg sizes its own)
                     torch.cuda.empty_cache()
@@ -812,16 +900,27 @@ def main():
                 except Exception as exc:                       # noqa: BLE001
                     out[name] = {"error": repr(exc)[:300]}
             leg("copy_ceiling", lambda: copy_ceiling(torch, s))
-            if isinstance(out["copy_ceiling"].get("gbps"), float) and "unfilter" in kernels:
+            if isinstance(out.get("copy_ceiling", {}).get("gbps"), float) and "unfilter" in kernels:
                 kernels["unfilter"]["frac_of_copy_ceiling"] = round(kernels["unfilter"]["gbps"] / out["copy_ceiling"]["gbps"], 4)
             leg("single_image", lambda: run_single_image(torch, spng, s, m["streams"][0], m["images"][0]))
+
+            def shard_probe():
+                r = run_shard_probe(torch, spng, s, m["streams"][:8], m["images"][:8])
+                r["linear_share_of_headline_ms"] = round(ms / 8, 2)
+                return r
+            leg("shard_probe", shard_probe)
+
+            def small():
+                from bench_small import run_small_images
+                return run_small_images(torch, spng, s, 8192, 3, cpu=not args.no_cpu_baseline, cores=cores)
+            leg("small_images", small)
             leg("config5", lambda: run_config5(torch, spng, s, 3))
             leg("file_to_pixels", lambda: run_file_to_pixels(torch, spng, s, m["streams"][:8], m["images"][:8], min(256, args.images), 2))
 
             def enc():
                 from bench_encode import run_encode
                 ea = argparse.Namespace(**vars(args))
-                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), 1, 1, args.no_cpu_baseline   # (the first call of a context allocates the deflate slab)
+                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline = args.encode_images, min(8, args.encode_images), args.encode_steps, 1, args.no_cpu_baseline   # (the first call of a context allocates the deflate slab)
                 return run_encode(ea, torch, dist, spng, s, rank, world)
             leg("encode", enc)
 
@@ -830,7 +929,7 @@ def main():
                 # levels 0-7 through the chip-wide search; whole-stream digest of stream 0 against the oracle's)
                 from bench_encode import run_encode
                 ea = argparse.Namespace(**vars(args))
-                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline, ea.level = args.encode_images, min(8, args.encode_images), 1, 1, args.no_cpu_baseline, 6
+                ea.images, ea.unique, ea.steps, ea.warmup, ea.no_cpu_baseline, ea.level = args.encode_images, min(8, args.encode_images), args.encode_steps, 1, args.no_cpu_baseline, 6
                 return run_encode(ea, torch, dist, spng, s, rank, world, rasters_kind="synthetic")
             leg("encode_level6", enc6)
 

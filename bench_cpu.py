@@ -7,6 +7,7 @@ allocated and touched before the clock starts:
 
     python bench_cpu.py decode <dir with stream files z0, z1, ...> <cores> <tasks> <w> <h>
     python bench_cpu.py deflate <file with scanline bytes> <cores> <level> <slice bytes>
+    python bench_cpu.py files <dir with *.baseline.png> <cores> <tasks>       (bench_small.py: whole small PNG files)
 
 prints one JSON object: {"wall_s": ..., "tasks": ..., "cores": ..., "one_core_s": [...per-task seconds of worker 0...]}
 """
@@ -58,6 +59,27 @@ def _deflate(k):
     return len(out), time.perf_counter() - t0
 
 
+def _init_files(d):
+    import pnghelp as ph
+    lib = ph.oracle()
+    pngs = [ph.parse_png(p.read_bytes()) for p in sorted(Path(d).glob("*.baseline.png"))]
+    items = []
+    for p in pngs:
+        z = np.frombuffer(p.idat, dtype=np.uint8)
+        storage = np.zeros(lib.orc_storage_size(p.width, p.height, p.depth, p.channels), dtype=np.uint8)
+        items.append((z, storage, p))
+    _state.update(lib=lib, ph=ph, items=items)
+
+
+def _file(k):
+    lib, ph = _state["lib"], _state["ph"]
+    z, storage, p = _state["items"][k % len(_state["items"])]
+    aux = (ctypes.c_uint64 * 2)()
+    t0 = time.perf_counter()
+    rc = lib.orc_decode(ph._ptr(z), len(z), 0, p.width, p.height, p.depth, p.channels, int(p.interlaced), ph._ptr(storage), aux)
+    return rc, time.perf_counter() - t0
+
+
 def _noop(_):
     return 0
 
@@ -84,6 +106,20 @@ def main():
             wall = time.perf_counter() - t0
         print(json.dumps({"wall_s": wall, "tasks": tasks, "cores": cores, "slice": nslice,
                           "task_s": sorted(t for _, t in res)[len(res) // 2]}))
+    elif mode == "files":
+        d, cores, tasks = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+        with mp.Pool(cores, initializer=_init_files, initargs=(d,)) as pool:
+            pool.map(_file, range(28 * cores), chunksize=28)                 # every worker up, every file decoded once, pages touched
+            reps = 1
+            while True:                                                      # (small images: repeat until the clock has something to see)
+                t0 = time.perf_counter()
+                res = pool.map(_file, range(tasks * reps), chunksize=max(1, tasks * reps // (cores * 4)))
+                wall = time.perf_counter() - t0
+                if wall >= 2.0 or reps >= 64:
+                    break
+                reps *= 4
+        assert all(rc == 0 for rc, _ in res)
+        print(json.dumps({"wall_s": wall, "tasks": tasks * reps, "cores": cores, "task_s": sum(t for _, t in res) / len(res)}))
     else:
         raise SystemExit("mode")
 

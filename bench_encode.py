@@ -119,13 +119,14 @@ def run_encode(args, torch, dist, spng, s, rank, world, rasters_kind="random"):
     }
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     # HBM traffic of the deflate kernels from the committed rocprofv3 --pmc passes of this workload's deflate step (1024 random
-    # 64 MiB streams at level 9: profiles/r05_pmc_encode.json, tools/final_run.sh); FETCH_SIZE x 2 as on the decode side
+    # 64 MiB streams at level 9: profiles/r06_pmc_encode.json, tools/final_run.sh); FETCH_SIZE x 2 as on the decode side
     traffic, traffic_src = None, None
     try:
-        pmc = json.loads((ROOT / "profiles" / "r05_pmc_encode.json").read_text())
+        pmc = json.loads((ROOT / "profiles" / "r06_pmc_encode.json").read_text())
         if rasters_kind == "random" and args.level == 9 and pmc.get("streams") == args.images and dom == "deflate":
             traffic = int(pmc["deflate_hbm_bytes_per_step"])
-            traffic_src = "profiles/r05_pmc_encode.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same 1024 x 64 MiB level-9 deflate, not measured in this run)"
+            traffic_src = ("profiles/r06_pmc_encode.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same 1024 x 64 MiB level-9 deflate, not measured "
+                           f"in this run; taken on source digest {pmc.get('source_digest')}, running {spng.source_digest()})")
             kernels["deflate"]["traffic_by_kernel"] = pmc.get("kernels")
     except (OSError, KeyError, ValueError):
         pass

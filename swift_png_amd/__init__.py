@@ -58,6 +58,17 @@ EXPORTS = [
 ]
 
 
+def source_digest() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources and the ABI header: what a measurement file (profiles/*_pmc_*.json)
+    names as the build it was taken on, and what bench.py compares with the sources it runs"""
+    import hashlib
+    h = hashlib.sha256()
+    root = Path(__file__).resolve().parent
+    for f in sorted(list((root / "csrc").glob("*.hip")) + list((root / "csrc").glob("*.hpp")) + list((root.parent / "include").glob("*.h"))):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 class Result(ctypes.Structure):
     _fields_ = [("status", ctypes.c_int32), ("reserved", ctypes.c_int32), ("written", ctypes.c_uint64),
                 ("consumed", ctypes.c_uint64), ("aux", ctypes.c_uint64 * 2)]

@@ -1,11 +1,12 @@
 """Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/probe_deflate2.py (PROBE_WHICH=random PROBE_N=<streams>: a
 warm-up call and a timed one of spng_deflate_batch at level 9 over <streams> random 64 MiB buffers -- the deflate step of
-BASELINE configs[3]) into profiles/r05_pmc_encode.json, which bench_encode.py reads `encode.roofline.traffic` from.
+BASELINE configs[3]) into profiles/r06_pmc_encode.json, which bench_encode.py reads `encode.roofline.traffic` from.
 
     python tools/pmc_encode.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <streams> <out.json>
 
 Units KiB; FETCH_SIZE x 2 as MI355X_MICROARCH.md prescribes for gfx950 (16-byte-per-lane reads); per step = the sums / 2."""
-import csv, glob, json, re, sys
+import csv, glob, hashlib, json, re, sys
+from pathlib import Path
 
 
 def collect(d, counter):
@@ -31,5 +32,10 @@ for k in sorted(set(fetch) | set(write)):
 doc = {"note": "rocprofv3 --kernel-trace --pmc <counter> -- python tools/probe_deflate2.py (PROBE_WHICH=random, level 9): one counter per pass; "
                "a warm-up call and a timed call, figures per call; FETCH_SIZE x 2", "streams": streams, "kernels": kernels,
        "deflate_hbm_bytes_per_step": total}
+h = hashlib.sha256()
+root = Path(__file__).resolve().parent.parent / "swift_png_amd"
+for f in sorted(list((root / "csrc").glob("*.hip")) + list((root / "csrc").glob("*.hpp")) + list((root.parent / "include").glob("*.h"))):
+    h.update(f.name.encode()); h.update(f.read_bytes())
+doc["source_digest"] = h.hexdigest()[:16]      # (swift_png_amd.source_digest(): the build these counters were taken on)
 json.dump(doc, open(dst, "w"), indent=1)
 print(json.dumps(doc, indent=1))

@@ -1,5 +1,5 @@
 """Turns the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of one bench.py step into
-profiles/r05_pmc_traffic.json (the file bench.py reads `roofline.traffic` / `kernels.*.traffic` from).
+profiles/r06_pmc_traffic.json (the file bench.py reads `roofline.traffic` / `kernels.*.traffic` from).
 
     python tools/pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <kind> <images> <unique> <out.json> [<decode steps in the run>]
 
@@ -10,7 +10,8 @@ Corrections as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: both cou
 half of the bytes of wide (16 B/lane) coalesced reads, so corrected fetch = 2 x raw for the kernels whose reads are
 16 B/lane streams: every kernel of the decode step now is (decode stages its chunks and writes its tokens in 16-byte
 units, resolve reads tokens and writes bytes in 16-byte units, unfilter as before); raw figures are kept next to them."""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
+from pathlib import Path
 
 NAMES = {"pinf2_find_kernel": "pinf_find", "pinf2_decode_kernel": "pinf_decode", "pinf2_resolve_kernel": "pinf_resolve",
          "::inflate_kernel": "inflate", "unfilter_kernel": "unfilter", "unfilter_pk_kernel": "unfilter"}
@@ -51,6 +52,15 @@ for k in NAMES.values():
     cfg["kernels"][k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "launches": fetch[k]["launches"],
                          "hbm_bytes_raw": int((f + w) * 1024), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                          "hbm_bytes_per_step": int((2 * f + w) * 1024)}        # (per_launch: the older name of the same figure)
+def source_digest():
+    h = hashlib.sha256()
+    root = Path(__file__).resolve().parent.parent / "swift_png_amd"
+    for f in sorted(list((root / "csrc").glob("*.hip")) + list((root / "csrc").glob("*.hpp")) + list((root.parent / "include").glob("*.h"))):
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+cfg["source_digest"] = source_digest()        # (swift_png_amd.source_digest(): the build these counters were taken on)
 doc["configs"][kind] = cfg
 json.dump(doc, open(dst, "w"), indent=1)
 print(json.dumps(cfg, indent=1))
