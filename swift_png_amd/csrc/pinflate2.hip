@@ -657,12 +657,20 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
 // (retry: only the streams whose first pass ran out of token pages -- PStream.pass == 1 -- are looked at again)
 // (RETRY: the pass for the streams that found the pool empty is launched behind every batch and mostly has nothing to do; as
 // an instantiation of its own it has a name of its own in kernel traces)
+// Round 6: the screen.  PMC counters of the kernel on zlib-made streams (profiles/r06j_pmc_find_*.json) say that a wave retires
+// ~120 vector instructions per step of 64 bit positions and that five sixths of them are the screen, not the header parses of
+// its false positives (one position in 1150 passes it; a parse of a look-alike ends early) -- a version that validated 64
+// candidates at a time, a lane each, saved nothing.  So the screen itself: the completeness of the code-length code -- 19 fields of
+// three bits, sum of 2^(7 - l) over the used ones == 128 -- comes from a table of three fields per look-up (512 bytes of LDS, seven
+// look-ups) instead of 19 shift-compare-select-add steps, the fields from two 32-bit words instead of a 64-bit one, and the two bounds
+// (inside the input, inside the segment) are 32-bit compares against the window's own limits.
 template <uint32_t RETRY>
 __global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restrict__ streams, PSeg *__restrict__ segs, uint32_t seg0)
 {
     constexpr uint32_t retry = RETRY;
     __shared__ __attribute__((aligned(16))) DLds s;
     __shared__ __attribute__((aligned(16))) uint32_t win[512 + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t k3[512];       // three code-length-code lengths -> their 2^(7 - l) summed (l = 0: unused, 0)
     const int lane = threadIdx.x;
     PSeg &sg = segs[seg0 + blockIdx.x];
     const PStream &st = streams[UNI(sg.stream)];
@@ -681,6 +689,12 @@ __global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restric
             if ((cmf & 15) == 8 && (cmf >> 4) < 8 && ((cmf << 8) + flg) % 31 == 0 && !(flg & 0x20)) found = 16;
         }
     } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t x = (uint32_t)lane * 8 + i;
+            const uint32_t a = x & 7, b = (x >> 3) & 7, c = x >> 6;
+            k3[x] = (uint8_t)(((128u >> a) & 127) + ((128u >> b) & 127) + ((128u >> c) & 127));      // (<= 192)
+        }
         const uint64_t sb = uni64(st.seg_bytes) * 8;
         const uint64_t lo_nom = (uint64_t)j * sb;
         const uint64_t lo_bit = lo_nom > resume_bit ? lo_nom : ((resume_bit + 1 + 63) & ~(uint64_t)63);   // (window loads want whole bytes)
@@ -693,34 +707,47 @@ __global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restric
                 if (lane < 16) { for (int b = 0; b < 4; ++b) if (off + b < n) v |= (uint32_t)src[off + b] << (8 * b); win[512 + lane] = v; }
                 WSYNC();
             }
-            for (uint32_t p = 0; p < 16384 && wb + p < hi_bit && found == NONE2; p += 64) {
-                const uint32_t q = p + (uint32_t)lane;
-                const uint32_t w = q >> 5;
+            // the window's limits, counted from its first bit: where the segment ends, where the input ends
+            const uint32_t hi_rel = hi_bit - wb < 16384 ? (uint32_t)(hi_bit - wb) : 16384u;
+            const uint32_t tot_rel = total - wb < 0x40000000ull ? (uint32_t)(total - wb) : 0x40000000u;
+            // 2048 bit positions per step: a lane takes the 32 positions that start in ITS dword.  What a position's first 13 bits
+            // must look like -- BTYPE = 2; HLIT, HDIST <= 29 (30 and 31: bits 1-4 of the field all set) -- is decided for all 32
+            // at once on the shifted words (a fifth of them pass); the lane then walks its survivors, a code-length code each
+            for (uint32_t ss = 0; ss * 2048 < hi_rel && found == NONE2; ++ss) {
+                const uint32_t w = ss * 64 + (uint32_t)lane, base = w * 32;
                 const uint32_t d0 = win[w], d1 = win[w + 1], d2 = win[w + 2], d3 = win[w + 3];
-                const uint32_t v0 = __builtin_amdgcn_alignbit(d1, d0, q);
-                const uint32_t v1 = __builtin_amdgcn_alignbit(d2, d1, q);
-                const uint32_t v2 = __builtin_amdgcn_alignbit(d3, d2, q);
-                const uint32_t ncl = ((v0 >> 13) & 15) + 4;
-                bool cand = ((v0 >> 1) & 3) == 2 && ((v0 >> 3) & 31) <= 29 && ((v0 >> 8) & 31) <= 29 &&
-                            wb + q + 17 + 3 * ncl <= total && wb + q < hi_bit;
-                if (__ballot(cand)) {
-                    // the code-length code must be complete: sum of 2^(7-len) over the used lengths == 128
-                    const uint64_t W = ((uint64_t)v2 << 47) | ((uint64_t)v1 << 15) | (v0 >> 17);
-                    uint32_t kraft = 0;
-#pragma unroll
-                    for (uint32_t k = 0; k < 19; ++k) {
-                        const uint32_t l = (uint32_t)(W >> (3 * k)) & 7;
-                        kraft += (k < ncl && l) ? 128u >> l : 0u;
-                    }
-                    cand = cand && kraft == 128;
+                auto sh = [&](uint32_t k) -> uint32_t { return __builtin_amdgcn_alignbit(d1, d0, k); };      // bits k .. k + 31 of my positions' stream
+                uint32_t M = ~sh(1) & sh(2);
+                M &= ~(sh(4) & sh(5) & sh(6) & sh(7));
+                M &= ~(sh(9) & sh(10) & sh(11) & sh(12));
+                if (base + 32 > hi_rel) M &= base >= hi_rel ? 0u : ~(~0u << (hi_rel - base));              // (inside the segment)
+                uint32_t R = 0;                                  // my positions whose code-length code is complete
+                while (M) {
+                    const uint32_t i = (uint32_t)__ffs((int)M) - 1;
+                    M &= M - 1;
+                    const uint32_t v0 = __builtin_amdgcn_alignbit(d1, d0, i), v1 = __builtin_amdgcn_alignbit(d2, d1, i), v2 = __builtin_amdgcn_alignbit(d3, d2, i);
+                    const uint32_t ncl = ((v0 >> 13) & 15) + 4, nb = 3 * ncl;       // its 3 ncl bits (12 .. 57): stream bits 17 .. in two words
+                    if (base + i + 17 + nb > tot_rel) continue;                      // (inside the input)
+                    // sum of 2^(7-len) over the used lengths == 128: the fields behind the ncl-th cleared, three fields per look-up
+                    uint32_t lo = __builtin_amdgcn_alignbit(v1, v0, 17), hi = __builtin_amdgcn_alignbit(v2, v1, 17);
+                    lo &= nb >= 32 ? ~0u : ~(~0u << nb);
+                    hi &= nb <= 32 ? 0u : ~(~0u << (nb - 32));
+                    const uint32_t kraft = (uint32_t)k3[lo & 511] + k3[(lo >> 9) & 511] + k3[(lo >> 18) & 511] +
+                                           k3[__builtin_amdgcn_alignbit(hi, lo, 27) & 511] + k3[(hi >> 4) & 511] + k3[(hi >> 13) & 511] + k3[(hi >> 22) & 511];
+                    R |= kraft == 128 ? 1u << i : 0u;
                 }
-                unsigned long long m = __ballot(cand);
-                while (m && found == NONE2) {
-                    const int l = __ffsll((long long)m) - 1;
-                    const uint64_t at = wb + p + (uint32_t)l;
-                    Hdr2 h;
-                    if (UB(parse_header2(s, src, n, at, h, lane))) found = at;
-                    m &= m - 1;
+                // the survivors in stream order: lane by lane, bit by bit
+                unsigned long long lm = __ballot(R != 0);
+                while (lm && found == NONE2) {
+                    const int l = __ffsll((long long)lm) - 1;
+                    uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)R, l);
+                    while (r && found == NONE2) {
+                        const uint64_t at = wb + (ss * 64 + (uint32_t)l) * 32 + ((uint32_t)__ffs((int)r) - 1);
+                        Hdr2 h;
+                        if (UB(parse_header2(s, src, n, at, h, lane))) found = at;
+                        r &= r - 1;
+                    }
+                    lm &= lm - 1;
                 }
             }
         }
