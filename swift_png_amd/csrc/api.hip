@@ -579,7 +579,10 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         // (streams of small blocks -- swift-png closes one every 2047 terms, ~2 KB -- as the last batch showed them: their
         // search is nearly free, and twice the segments halve what the last round of resident waves leaves idle:
         // 1024 x 4K images, decode 317 -> 301 ms)
-        seg_bytes = total / ((c->block_bytes > 0 && c->block_bytes < 8192) ? 65536 : 32768);
+        // (round 6: the search is 2-3 x cheaper -- pinf2_find's bit-parallel screen --, so streams of small blocks take 2.5 x the
+        // segments again: 1024 x 4K images, swift-png-made: 418 KB segments 503.4 ms per step, 180 KB 494.5, 140 KB 494.0, 100 KB
+        // 500.1; zlib-made streams, whose search still costs 2.4 ms per 10^4 segments, stay: profiles/r06m_probe_segments.log)
+        seg_bytes = total / ((c->block_bytes > 0 && c->block_bytes < 8192) ? 163840 : 32768);
         uint64_t least = total / 4096;
         if (least < (64u << 10)) least = 64u << 10;
         if (least > (256u << 10)) least = 256u << 10;

@@ -62,10 +62,20 @@ __device__ __forceinline__ uint32_t sub8(uint32_t x, uint32_t p)              //
     constexpr uint32_t Hb = 0x80808080u;
     return ((x | Hb) - (p & ~Hb)) ^ ((x ^ ~p) & Hb);
 }
-__device__ __forceinline__ uint32_t sumabs8(uint32_t r, uint32_t acc)         // acc + sum |Int8(byte)|
+// acc + sum |Int8(byte)| over the four bytes of r: a signed byte s and the unsigned byte u = s + 128 (its pattern with the top bit
+// flipped) satisfy |s| = |u - 128|, so the sum is ONE sum of absolute differences against 0x80 (round 6: seven instructions before)
+__device__ __forceinline__ uint32_t sumabs8(uint32_t r, uint32_t acc)
 {
-    const uint32_t m = (r >> 7) & 0x01010101u, neg = (m << 8) - m;
-    return __builtin_amdgcn_sad_u8((r ^ neg) + m, 0u, acc);
+    constexpr uint32_t Hb = 0x80808080u;
+    return __builtin_amdgcn_sad_u8(r ^ Hb, Hb, acc);
+}
+// the same for the residual x - p, whose top bits the subtraction can leave flipped for free: sub8 ends in `^ ((x ^ ~p) & Hb)`;
+// ending in `^ ((x ^ p) & Hb)` instead gives the residual with every byte's top bit flipped
+__device__ __forceinline__ uint32_t sumabs8_sub(uint32_t x, uint32_t p, uint32_t acc)
+{
+    constexpr uint32_t Hb = 0x80808080u;
+    const uint32_t biased = ((x | Hb) - (p & ~Hb)) ^ ((x ^ p) & Hb);
+    return __builtin_amdgcn_sad_u8(biased, Hb, acc);
 }
 __device__ __forceinline__ uint32_t paeth_pk16(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -131,10 +141,10 @@ __device__ void filter_row_fast(const uint8_t *cur, const uint8_t *up, uint32_t 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 sc[0] = sumabs8(xs[k], sc[0]);
-                sc[1] = sumabs8(sub8(xs[k], as[k]), sc[1]);
-                sc[2] = sumabs8(sub8(xs[k], bs[k]), sc[2]);
-                sc[3] = sumabs8(sub8(xs[k], __builtin_amdgcn_lerp(as[k], bs[k], 0u)), sc[3]);
-                sc[4] = sumabs8(sub8(xs[k], paeth8(as[k], bs[k], cs[k])), sc[4]);
+                sc[1] = sumabs8_sub(xs[k], as[k], sc[1]);
+                sc[2] = sumabs8_sub(xs[k], bs[k], sc[2]);
+                sc[3] = sumabs8_sub(xs[k], __builtin_amdgcn_lerp(as[k], bs[k], 0u), sc[3]);
+                sc[4] = sumabs8_sub(xs[k], paeth8(as[k], bs[k], cs[k]), sc[4]);
             }
         }
     }

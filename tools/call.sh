@@ -1,4 +1,8 @@
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python tools/probe_v2.py --kinds swiftpng,zlib --steps 3 > gpurun_out/r06l_probe_find.log 2>&1; grep -E "^(swiftpng|zlib) auto" gpurun_out/r06l_probe_find.log | cut -c1-200
-timeout 400 python tools/probe_groups.py --kind zlib --unique 4 --shapes 128x1,32x1,1x1 > gpurun_out/r06l_probe_groups_zlib.log 2>&1; head -4 gpurun_out/r06l_probe_groups_zlib.log | cut -c1-220
-timeout 900 python -m pytest tests/test_gpu_pinflate.py tests/test_gpu_resume.py tests/test_gpu_gzip.py -q -x 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_files.py tests/test_gpu_gzip.py -q -x 2>&1 | tail -2
+timeout 900 python bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline --legs small_images,file_to_pixels > gpurun_out/r06o_bench_small.json 2> gpurun_out/r06o.err; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r06o_bench_small.json'))
+print(json.dumps(d.get('small_images'))[-700:])
+print(json.dumps(d.get('file_to_pixels'))[:600])
+PY

@@ -261,6 +261,11 @@ inline int __shfl_up(int v, int d, int = 64)
     const int lane = (int)(threadIdx.x & 63);
     return (int)(uint32_t)emu::wave_op(emu::OP_SHFL, (uint32_t)v, 0, lane >= d ? lane - d : lane);
 }
+inline int __shfl_down(int v, int d, int = 64)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    return (int)(uint32_t)emu::wave_op(emu::OP_SHFL, (uint32_t)v, 0, lane + d < 64 ? lane + d : lane);
+}
 inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)(uint32_t)emu::wave_op(emu::OP_SHFL, (uint32_t)v, 0, lane); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return (int)(uint32_t)emu::wave_op(emu::OP_READFIRST, (uint32_t)v); }
 inline int __builtin_amdgcn_ds_bpermute(int addr, int v) { return (int)(uint32_t)emu::wave_op(emu::OP_SHFL, (uint32_t)v, 0, (addr >> 2) & 63); }
