@@ -610,17 +610,22 @@ def run_scanline_formats(torch, spng, s, n=256):
     (algorithmic bytes U + S per image and direction), the defiltered rasters equal to the sources."""
     from swift_png_amd import synth
     out = {}
-    for name, depth, ch in (("rgb8", 8, 3), ("rgb16", 16, 3)):
-        m = n if depth == 8 else n // 2
+    import numpy as np
+    # (indexed8 / gray1: the byte-wise kernel of the 1- and 2-byte pixel formats and of the sub-byte ones -- what palette and bilevel
+    # PNGs go through; storage of a sub-byte format is one unscaled sample per byte, its scanlines are packed)
+    for name, depth, ch in (("rgb8", 8, 3), ("rgb16", 16, 3), ("indexed8", 8, 1), ("gray1", 1, 1)):
+        m = n if depth == 8 and ch == 3 else n // 2
         U = spng.inflated_size(W, H, depth, ch, False)
         S = spng.storage_size(W, H, depth, ch)
         unique = 4
         base = [synth.image(500 + k, W, H).reshape(H, W, 4) for k in range(unique)]
-        if depth == 8:
-            import numpy as np
+        if name == "rgb8":
             srcs = [s.to_device(np.ascontiguousarray(im[..., :3]).tobytes()) for im in base]
+        elif name == "indexed8":
+            srcs = [s.to_device(np.ascontiguousarray((im[..., 0] >> 2) + (im[..., 1] >> 6)).astype(np.uint8).tobytes()) for im in base]   # (palette indices with structure)
+        elif name == "gray1":
+            srcs = [s.to_device(np.ascontiguousarray(im[..., 1] >> 7).astype(np.uint8).tobytes()) for im in base]                           # (one sample, 0 / 1, per byte)
         else:
-            import numpy as np
             srcs = [s.to_device(np.repeat(im[..., :3], 2, axis=-1).tobytes()) for im in base]   # (big-endian samples v << 8 | v)
         d_sto = torch.empty(m * S, dtype=torch.uint8, device=s.tdev)
         for j in range(m):
@@ -639,8 +644,9 @@ def run_scanline_formats(torch, spng, s, n=256):
         torch.cuda.synchronize()
         if not torch.equal(d_back, d_sto):
             d = (d_back != d_sto).nonzero()[:, 0]
+            rowb = max(1, W * ch * depth // 8 if depth >= 8 else W)
             raise AssertionError(f"{name}: defiltered rasters differ from their sources: {len(d)} bytes, first at image {int(d[0]) // S} row "
-                                 f"{int(d[0]) % S // (W * ch * (depth // 8))} byte {int(d[0]) % (W * ch * (depth // 8))}, last at image {int(d[-1]) // S}")
+                                 f"{int(d[0]) % S // rowb} byte {int(d[0]) % rowb}, last at image {int(d[-1]) // S}")
         s.profile(True)
         for _ in range(3):
             assert s.lib.spng_filter_batch(s.ctx, fd, m, ctypes.c_void_p(dres.data_ptr()), None) == 0

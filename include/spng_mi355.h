@@ -184,18 +184,22 @@ int32_t spng_inflate_batch(spng_ctx *ctx, const spng_stream_desc *descs, uint32_
 
 /* LZ77.Inflator.push for streams that arrive in pieces (LZ77.Inflator.swift:30-61; PNG.Context.push(data:), one call per
  * IDAT chunk, PNG.Context.swift:88-102): the device-side counterpart of the reference's resumable state machine
- * (LZ77.InflatorState / BlockState), at block granularity.  d_src / src_len: ALL compressed bytes received so far
- * (the caller appends to its device buffer); d_dst: the output so far, kept between calls.  h_state: two words per
- * stream, {first bit of the first block that was not complete yet, inflated bytes in front of it}, as the previous call
- * returned them in spng_result.aux of a SPNG_NEED_MORE_INPUT result ({0, 0} or a NULL array: nothing seen yet).
- * Blocks the input now holds completely are decoded by the parallel pipeline exactly once; only the block the input
- * ends in is decoded again by the next call.  (Whatever the blocks are: the pipeline's first segment starts at the resume
- * point and takes stored and fixed blocks like dynamic ones, so a stream without a single dynamic header for the search to
- * find advances from push to push too -- on one wave.  Only what the pipeline declines altogether -- a pool or page table
- * that is exhausted -- is left to the serial kernel and decoded again from the last point by the next call.)  Results as
- * spng_inflate_batch (written / consumed count from the start of the stream; the zlib checksum -- the CRC-32 of a gzip
- * member -- is verified over the whole output by the call that reports SPNG_DONE); formats SPNG_FORMAT_ZLIB, SPNG_FORMAT_IOS
- * and SPNG_FORMAT_GZIP (state = bits and bytes of the member's DEFLATE payload; the header is parsed again per call). */
+ * (LZ77.InflatorState / BlockState), which stops and goes on at any byte (LZ77.InflatorBuffers.Stream.swift:61-65, 284-288,
+ * 352-356).  d_src / src_len: ALL compressed bytes received so far (the caller appends to its device buffer); d_dst: the output so
+ * far, kept between calls.  h_state: FOUR words per stream as the previous call returned them for a SPNG_NEED_MORE_INPUT result --
+ * {aux[0]: first bit of the block the input ended in, aux[1]: inflated bytes in front of that block, consumed: first bit INSIDE the
+ * block that was not complete yet (a token; a byte of a stored block; 0: the input ended in the block's header), written: inflated
+ * bytes in front of that bit (hand back 0 with a 0 bit)}; all zero or a NULL array: nothing seen yet.
+ * Blocks the input now holds completely are decoded by the parallel pipeline exactly once.  The block the input ends in: while it is
+ * of ordinary size it is decoded again from its header by the next call (cheaper than leaving everything behind it to one wave);
+ * once more than 1 MiB of input lies inside ONE block, the next call goes on at the token the last one stopped in front of (the
+ * serial kernel, its tables rebuilt from the block's header): a stream that is a single block pushed in k pieces costs O(n), not
+ * O(n k).  (Whatever the blocks are: the pipeline's first segment starts at the resume point and takes stored and fixed blocks
+ * like dynamic ones.)  Results as spng_inflate_batch, except `consumed` of a SPNG_NEED_MORE_INPUT result (above; gzip: a bit of the
+ * member's DEFLATE payload, like aux[0]); written / consumed of finished streams count from the start of the stream; the zlib
+ * checksum -- the CRC-32 of a gzip member -- is verified over the whole output by the call that reports SPNG_DONE); formats
+ * SPNG_FORMAT_ZLIB, SPNG_FORMAT_IOS and SPNG_FORMAT_GZIP (state = bits and bytes of the member's DEFLATE payload; the header is
+ * parsed again per call). */
 int32_t spng_inflate_resume_batch(spng_ctx *ctx, const spng_stream_desc *descs, const uint64_t *h_state, uint32_t count,
                                   spng_result *d_results, spng_result *h_results);
 

@@ -398,16 +398,22 @@ class Session:
         _check(self.lib, self.lib.spng_inflate_batch(self.ctx, descs, n, None, res))
         return outs, list(res)
 
-    def inflate_resume(self, src, src_len, dst, fmt=FORMAT_ZLIB, state=(0, 0)):
+    def inflate_resume(self, src, src_len, dst, fmt=FORMAT_ZLIB, state=(0, 0, 0, 0)):
         """One push of a stream that arrives in pieces (spng_inflate_resume_batch): src / dst are device tensors that
         hold ALL compressed bytes so far (src_len of them) / the output so far; state is what the previous call
-        returned.  -> (Result, next state)"""
+        returned: four words -- {header bit of the block the input ended in, bytes in front of it, first bit inside it that is
+        still to decode (0: its header), bytes in front of that} (a pair is taken as a state at a block boundary).
+        -> (Result, next state)"""
         desc = (StreamDesc * 1)(StreamDesc(self._ptr(src), int(src_len), self._ptr(dst), dst.numel(), fmt, 0))
-        st = (ctypes.c_uint64 * 2)(int(state[0]), int(state[1]))
+        state = tuple(state) + (0, 0) * (len(state) == 2)
+        st = (ctypes.c_uint64 * 4)(*[int(v) for v in state])
         res = (Result * 1)()
         _check(self.lib, self.lib.spng_inflate_resume_batch(self.ctx, desc, st, 1, None, res))
         r = res[0]
-        return r, ((r.aux[0], r.aux[1]) if r.status == NEED_MORE_INPUT else tuple(state))
+        if r.status == NEED_MORE_INPUT:
+            tok = int(r.consumed)
+            return r, (int(r.aux[0]), int(r.aux[1]), tok, int(r.written) if tok else 0)
+        return r, tuple(state)
 
     def unfilter_resume(self, desc, work, prev_len, now_len):
         """The scanlines of one image that became complete between prev_len and now_len inflated bytes are defiltered and

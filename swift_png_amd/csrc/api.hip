@@ -531,10 +531,12 @@ struct InflatePlan {
     size_t bytes() const
     {
         return jobs.size() * (sizeof(InflateJob) + sizeof(PStream) + 4 + (size_t)pmax * sizeof(PPart) + 256 + (gzip ? 8 + 4 * (size_t)gzip_pieces() : 0) +
-                              (state.empty() ? 0 : 16 + 8 * (size_t)gzip_pieces())) +
+                              (state.empty() ? 0 : 32 + 8 * (size_t)gzip_pieces())) +
                segs.size() * sizeof(PSeg) + 8192 + 512;
     }
 };
+
+static constexpr uint64_t RESUME_SERIAL_BITS = 8ull << 20;      // 1 MiB of input inside one block: resume there, not at its header
 
 // Cuts every stream into segments and makes sure the context owns what the pipeline needs.  Segment length: long
 // enough that the search for a block header (which costs more per bit than decoding) stays a small part of a
@@ -549,7 +551,7 @@ struct InflatePlan {
 static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
 {
     p.internal = p.state.empty();
-    if (p.internal) p.state.assign(p.jobs.size() * 2, 0);
+    if (p.internal) p.state.assign(p.jobs.size() * 4, 0);
     for (auto &j : p.jobs) j.internal = p.internal ? 1 : 0;
     p.parallel = c->cfg[SPNG_CFG_INFLATE_MODE] != SPNG_INFLATE_SERIAL && !p.jobs.empty();
     for (auto &j : p.jobs) p.gzip = p.gzip || j.format == SPNG_FORMAT_GZIP;
@@ -599,7 +601,14 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         memset(&st, 0, sizeof st);
         st.src = j.src; st.dst = j.dst; st.src_len = j.src_len; st.dst_cap = j.dst_cap;
         st.format = j.format; st.image = j.image;
-        if (!p.state.empty()) { st.start_bit = p.state[2 * i]; st.out_pos = p.state[2 * i + 1]; }
+        if (!p.state.empty()) {
+            st.start_bit = p.state[4 * i]; st.out_pos = p.state[4 * i + 1];
+            // The caller's state stands inside a block.  A block of ordinary size is simply decoded again from its header by the
+            // pipeline (cheaper than the serial kernel for everything behind it); one that has already taken more than
+            // RESUME_SERIAL_BITS of input would make every push cost what all pushes before it did -- a stream that is ONE block
+            // pushed in k pieces O(n k) --: the serial kernel goes on at the token the last push stopped in front of.
+            if (!p.internal && p.state[4 * i + 2] && p.state[4 * i + 2] - p.state[4 * i] > RESUME_SERIAL_BITS) st.serial_only = 1;
+        }
         st.seg_first = (uint32_t)p.segs.size();
         uint64_t k = (j.src_len + seg_bytes - 1) / seg_bytes;
         if (k < 1) k = 1;
@@ -765,10 +774,10 @@ static void stage_inflate(InflatePlan &p, Arena &a)
     const size_t n = p.jobs.size();
     p.jobs_at = a.take(n * sizeof(InflateJob));
     if (!p.state.empty()) {
-        p.state_at = a.take(n * 16);
-        memcpy(a.host<uint64_t>(p.state_at), p.state.data(), n * 16);
+        p.state_at = a.take(n * 32);
+        memcpy(a.host<uint64_t>(p.state_at), p.state.data(), n * 32);
         for (size_t i = 0; i < n; ++i) {
-            p.jobs[i].state = a.dev<uint64_t>(p.state_at) + 2 * i;
+            p.jobs[i].state = a.dev<uint64_t>(p.state_at) + 4 * i;
             if (p.parallel) p.streams[i].state = p.jobs[i].state;
         }
     }
@@ -942,16 +951,19 @@ static int32_t inflate_batch(spng_ctx *c, const spng_stream_desc *descs, const u
     std::lock_guard<std::mutex> g(c->mu);
     InflatePlan plan;
     plan.jobs.resize(count);
-    if (resume) plan.state.assign((size_t)count * 2, 0);
+    if (resume) plan.state.assign((size_t)count * 4, 0);
     for (uint32_t i = 0; i < count; ++i) {
         if ((!descs[i].d_src && descs[i].src_len) || (!descs[i].d_dst && descs[i].dst_cap) || descs[i].format < SPNG_FORMAT_ZLIB ||
             descs[i].format > SPNG_FORMAT_GZIP) return SPNG_E_ARGUMENT;
         plan.jobs[i] = InflateJob{(const uint8_t *)descs[i].d_src, (uint8_t *)descs[i].d_dst,
                                   descs[i].src_len, descs[i].dst_cap, descs[i].format, i, nullptr, nullptr, 0, 0};
         if (resume && h_state) {
-            plan.state[2 * i] = h_state[2 * i]; plan.state[2 * i + 1] = h_state[2 * i + 1];
-            // (a state is only ever what an earlier call handed out: inside the input and the output)
-            if (plan.state[2 * i] > descs[i].src_len * 8 || plan.state[2 * i + 1] > descs[i].dst_cap) return SPNG_E_ARGUMENT;
+            const uint64_t *hs = h_state + 4 * (size_t)i;
+            for (int k = 0; k < 4; ++k) plan.state[4 * (size_t)i + k] = hs[k];
+            // (a state is only ever what an earlier call handed out: inside the input and the output, the token behind its block's
+            // header, its bytes behind the block's)
+            if (hs[0] > descs[i].src_len * 8 || hs[1] > descs[i].dst_cap || hs[2] > descs[i].src_len * 8 || hs[3] > descs[i].dst_cap ||
+                (hs[2] && (hs[2] <= hs[0] || hs[3] < hs[1])) || (!hs[2] && hs[3])) return SPNG_E_ARGUMENT;
         }
     }
     if (int32_t st = plan_inflate(c, plan)) return st;

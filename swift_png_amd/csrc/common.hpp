@@ -127,8 +127,9 @@ struct InflateJob {
     int32_t        format;
     uint32_t       image;
     const int32_t *skip;          // device flag: non-zero = the parallel pipeline already produced this stream
-    // {first bit of the first block not decoded completely yet, inflated bytes in front of it}: the pipeline moves it
-    // forward, the serial kernel starts there.  spng_inflate_resume_batch: what the previous call returned; every other
+    // FOUR words: {first bit of the first block not decoded completely yet, inflated bytes in front of it, first bit INSIDE that block
+    // that is still to decode (0: its header), inflated bytes in front of that}: the pipeline moves the first pair forward (and
+    // clears the second), the serial kernel starts there.  spng_inflate_resume_batch: what the previous call returned; every other
     // call: the library's own slot, {0, 0} (`internal`), so that a stream the pipeline cannot finish -- truncated,
     // corrupt -- costs the serial kernel one block, not the whole stream.
     uint64_t      *state;
@@ -154,6 +155,7 @@ struct PStream {
     // resumable streams (spng_inflate_resume_batch): where to start, and where to note how far the chain got
     uint64_t       start_bit, out_pos;
     uint64_t      *state;
+    uint32_t       serial_only, pad_;      // the caller's state stands deep inside a huge block: the serial kernel goes on THERE (the pipeline would decode the block again)
     // several workgroups per stream: parts_max slots in the part table (0: one workgroup), how many the chain was cut into
     uint32_t       parts_max, parts;
     uint64_t       out_total;              // scan: bytes of the whole chain

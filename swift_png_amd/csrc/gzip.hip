@@ -127,6 +127,9 @@ __global__ void gzip_inflate_post_kernel(const InflateJob *__restrict__ jobs, sp
     const InflateJob &j = jobs[i];
     spng_result &r = results[j.image];
     const uint64_t off = gz[i];
+    // (spng_inflate_resume_batch: `consumed` of a stream that wants more input is a BIT position inside the payload -- part of the
+    // state the caller hands back --, not a byte count of the member)
+    if (r.status == SPNG_NEED_MORE_INPUT && j.state && !j.internal) return;
     if (r.status == SPNG_DONE) {
         const gbyte *p = (const gbyte *)j.src;                 // (the payload: gzip_pre_kernel moved the window)
         const uint64_t n = j.src_len, at = r.consumed;

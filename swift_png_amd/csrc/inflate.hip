@@ -96,6 +96,7 @@ struct Ctrl {
     int32_t  status;               // walker's final status; SPNG_DONE + check => compare Adler-32
     uint32_t check, declared, pad;
     uint64_t aux0, aux1, bits;
+    uint64_t blk_bit, tok_bit;     // the header of the block the decoder stopped in; the first token (or stored byte) that was not complete (0: none)
     // scout <-> walker
     uint32_t w_gen, w_stop, w_idle, w_quit;   // start order (generation), stop order, acknowledgement, exit
     uint32_t w_prod, w_cons;                  // windows of this generation produced / consumed
@@ -331,8 +332,11 @@ __device__ __forceinline__ void copy_match(Lds &s, const Out &o, uint64_t pos, u
 // ------------------------------------------------------------------------------------------------
 // wave 1: the resolver
 // ------------------------------------------------------------------------------------------------
+// out_pos: where this call's first byte goes (a call resumed inside a block: behind what earlier calls took of it); blk_out0: the
+// output position of the header the call starts from.  The decoder marks every block start in the token stream (a capacity check
+// of zero bytes), so that the resolver knows the output position of the LAST block started: what a caller needs to resume there.
 __device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint64_t dst_cap, uint64_t src_len, bool resumed, bool internal,
-                                                        uint64_t start_bit, uint64_t out_pos, spng_result *__restrict__ result, int lane)
+                                                        uint64_t blk_out0, uint64_t out_pos, spng_result *__restrict__ result, int lane)
 {
 #ifndef SPNG_B_PRIO
 #define SPNG_B_PRIO 2
@@ -348,6 +352,7 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint
 #endif
     int32_t status = SPNG_NEED_MORE_INPUT;
     uint64_t aux0 = 0, aux1 = 0, bits = 0;
+    uint64_t blk_out = blk_out0;
     bool failed = false;
 
     for (;;) {
@@ -404,6 +409,10 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint
             m = (uint32_t)__ffsll((long long)bad) - 1;
             status = __builtin_amdgcn_readlane(bad_ref ? SPNG_E_STRING_REFERENCE : SPNG_E_OUTPUT_CAPACITY, (int)m);
             failed = true;
+        }
+        {   // block starts among the tokens taken: the last one's output position
+            const unsigned long long marks = __ballot((uint32_t)lane < m && is_check && dist == 0);
+            if (marks) blk_out = uni64(o.pos + (uint32_t)__builtin_amdgcn_readlane((int)offs, 63 - __clzll((long long)marks)));
         }
         head = UNI(head + m + (failed ? 1u : 0u));
         COMPILER_ORDER();                                      // the token loads were issued: release their slots
@@ -472,7 +481,13 @@ __device__ __attribute__((always_inline)) void resolver(Lds &s, gbyte *dst, uint
         res.written = o.pos;
         res.consumed = (bits + 7) / 8 > src_len ? src_len : (bits + 7) / 8;
         res.aux[0] = aux0; res.aux[1] = aux1;
-        if (resumed && !internal && status == SPNG_NEED_MORE_INPUT) { res.aux[0] = start_bit; res.aux[1] = out_pos; }   // where the next call starts
+        if (resumed && !internal && status == SPNG_NEED_MORE_INPUT) {
+            // where the next call starts: the header of the block the input ends in and the bytes in front of it, and -- inside
+            // that block -- the first token that was not complete (in BITS, in `consumed`; 0: at the header) with the bytes in
+            // front of it (= written): spng_inflate_resume_batch's four words
+            res.aux[0] = uni64(s.c.blk_bit); res.aux[1] = blk_out;
+            res.consumed = uni64(s.c.tok_bit);
+        }
     }
 }
 
@@ -699,8 +714,12 @@ __device__ __forceinline__ void push(Lds &s, Queue &q, unsigned long long who, u
 #define FAIL(code, a0, a1) do { status = (code); aux0 = (a0); aux1 = (a1); goto done; } while (0)
 #define PUSH(who, tok) push(s, q, (who), (tok), lane)
 
+// start_bit: the block header to start on (0: the stream's first bit).  tok_bit != 0: the call goes on INSIDE that block -- its
+// header is read again for the tables (stored blocks: for LEN), then decoding continues at bit tok_bit; done_in_block = bytes of
+// the block earlier calls produced (stored blocks: how far into the LEN bytes).  The reference's inflator stops and resumes at
+// any byte (LZ77.InflatorBuffers.Stream.swift:61-65, 284-288, 352-356).
 __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src, uint64_t n, int32_t format, bool resumed,
-                                                       uint64_t start_bit, int lane)
+                                                       uint64_t start_bit, uint64_t tok_bit, uint64_t done_in_block, int lane)
 {
     const uint64_t total = n * 8;
 #ifndef SPNG_NO_PRIO
@@ -710,6 +729,8 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
     int32_t status = SPNG_NEED_MORE_INPUT;
     uint64_t aux0 = 0, aux1 = 0;
     uint32_t check = 0, declared = 0, wgen = 0;
+    uint64_t blk_bit = start_bit, stop_bit = 0;                // the block at hand; where inside it the input ended (0: in its header)
+    bool inside = tok_bit != 0;                                // the first block: continue at tok_bit
     Queue q = {};
     PROF_DECL
 #ifdef SPNG_INFLATE_PROF
@@ -735,6 +756,8 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
     for (;;) {
         // .metadata: readBlockMetadata (InflatorBuffers.Stream.swift:59-141)
         PROF_BEGIN();
+        blk_bit = bitpos(r);
+        if (!inside) PUSH(1ull, T_CHECK);                      // (a block starts here: the resolver notes its output position)
         if (bitpos(r) + 3 > total) goto done;
         const uint32_t bfinal = TAKE(1);
         const uint32_t type = TAKE(2);
@@ -747,16 +770,21 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
             if (l != (~m & 0xffffu)) FAIL(SPNG_E_BLOCK_COUNT_PARITY, l, m);
             // readBlock(upTo:) (:384-399): copies as many of the LEN bytes as the input holds, after
             // making sure all of them fit the output
-            const uint64_t from = boundary / 8 + 4;
-            const uint32_t have = n - from < l ? (uint32_t)(n - from) : l;
-            PUSH(1ull, T_CHECK | have);
+            uint64_t from = boundary / 8 + 4;
+            uint32_t l_left = l;
+            if (inside) {                                      // (earlier calls copied done_in_block of the LEN bytes)
+                const uint32_t dn = done_in_block < l ? (uint32_t)done_in_block : l;
+                from += dn; l_left -= dn; inside = false;
+            }
+            const uint32_t have = n - from < l_left ? (uint32_t)(n - from) : l_left;
+            if (have) PUSH(1ull, T_CHECK | have);               // (a check of 0 bytes is a block start)
             for (uint32_t done_ = 0; done_ < have; done_ += 64) {
                 const uint32_t piece = have - done_ < 64 ? have - done_ : 64;
                 const uint32_t b = (uint32_t)lane < piece ? src[from + done_ + lane] : 0u;
                 PUSH(piece == 64 ? ~0ull : (1ull << piece) - 1, b << 8);
             }
-            if (have < l) { r.pos = n * 8; goto done; }
-            seek(s, r, src, n, from + l, lane);
+            if (have < l_left) { r.pos = n * 8; stop_bit = n * 8; goto done; }
+            seek(s, r, src, n, from + l_left, lane);
         } else if (type == 1 || type == 2) {
             if (type == 1) {
                 // fixed trees, HuffmanTree.swift:24-47
@@ -834,6 +862,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
             // bit; the walker only has to find the true chain of token boundaries through each
             // window and queue the tokens on it.
             {
+                if (inside) { seek_bits(s, r, src, n, tok_bit, lane); inside = false; }     // (the tables stand: on with the block's tokens)
                 const uint64_t org = r.pos;
                 wgen += 1;
                 LDS_STORE(&s.c.w_prod, 0u); LDS_STORE(&s.c.w_cons, 0u);   // (every lane, same value: no branch)
@@ -977,7 +1006,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
                     if (spins > SPIN_LIMIT) SPIN_ABORT();
                 }
                 seek_bits(s, r, src, n, org + ((uint64_t)k << 6) + ent, lane);
-                if (stop == 2) goto done;
+                if (stop == 2) { stop_bit = bitpos(r); goto done; }
             }
         } else {
             FAIL(SPNG_E_BLOCK_TYPE, type, 0);
@@ -1005,6 +1034,7 @@ done:
     if (lane == 0) {
         s.c.status = status; s.c.check = check; s.c.declared = declared;
         s.c.aux0 = aux0; s.c.aux1 = aux1; s.c.bits = bitpos(r);
+        s.c.blk_bit = blk_bit; s.c.tok_bit = stop_bit;
     }
     LDS_ORDER();
     if (lane == 0) LDS_STORE(&s.c.a_done, 1u);
@@ -1030,7 +1060,11 @@ __global__ __launch_bounds__(256) void inflate_kernel(const InflateJob *__restri
     const uint32_t image = UNI(job->image);
     typedef uint64_t __attribute__((address_space(1))) gstate;
     const gstate *state = (const gstate *)uni64((uint64_t)job->state);
-    const uint64_t start_bit = state ? uni64(state[0]) : 0, out_pos = state ? uni64(state[1]) : 0;
+    // {header of the block to start from, bytes in front of it, first bit inside it that is still to decode (0: its header), bytes in
+    // front of that}
+    const uint64_t start_bit = state ? uni64(state[0]) : 0, blk_out = state ? uni64(state[1]) : 0;
+    const uint64_t tok_bit = state ? uni64(state[2]) : 0, tok_out = state ? uni64(state[3]) : 0;
+    const uint64_t out_pos = tok_bit ? tok_out : blk_out;
     const bool internal = UNI(job->internal) != 0;
     // (a slot of the library's own that still reads {0, 0}: the pipeline got nowhere, this is a whole stream)
     const bool resumed = state != nullptr && !(internal && start_bit == 0 && out_pos == 0);
@@ -1041,8 +1075,8 @@ __global__ __launch_bounds__(256) void inflate_kernel(const InflateJob *__restri
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t role = UNI(threadIdx.x >> 6);
-    if (role == 0)      decoder(s, src, src_len, format, resumed, start_bit, lane);
-    else if (role == 1) resolver(s, dst, dst_cap, src_len, resumed, internal, start_bit, out_pos, results + image, lane);
+    if (role == 0)      decoder(s, src, src_len, format, resumed, start_bit, tok_bit, tok_bit ? tok_out - blk_out : 0, lane);
+    else if (role == 1) resolver(s, dst, dst_cap, src_len, resumed, internal, blk_out, out_pos, results + image, lane);
     else if (role == 2) scout(s, src, src_len, lane);
     // (wave 3 has nothing to do.  It is there because the dispatcher places 256-thread workgroups
     //  evenly -- exactly four per CU, all 1024 streams of a batch resident at once -- and 192-thread

@@ -680,7 +680,9 @@ __global__ __launch_bounds__(64) void pinf2_find_kernel(const PStream *__restric
     const uint32_t j = UNI(sg.index);
     uint64_t found = NONE2;
     const uint64_t resume_bit = uni64(st.start_bit);       // resumable streams: nothing in front of it is looked at again
-    if (j == 0) {
+    if (UNI(st.serial_only)) {
+        // (no segment has a start: the chain is empty, the stream is the serial kernel's -- which resumes INSIDE the block at hand)
+    } else if (j == 0) {
         // .initial (InflatorBuffers.swift:92-104, StreamHeader.swift:16-54)
         if (resume_bit) found = resume_bit;
         else if (UNI(st.format) == SPNG_FORMAT_IOS) found = 0;
@@ -1326,7 +1328,7 @@ __device__ __forceinline__ void stream_verdict(const PStream &st, uint32_t S, ui
     if (st.ok == 2) {
         // the chain stopped in front of a block the input does not hold completely (or that is not acceptable): the
         // serial kernel goes on from there
-        state[0] = st.end_bit; state[1] = pos;
+        state[0] = st.end_bit; state[1] = pos; state[2] = 0; state[3] = 0;     // (a block boundary: nothing taken of the block behind it)
     } else if (!whole) {
         // resumed and complete: the trailer must be there; the sum over ALL bytes is compared afterwards (gzip.hip)
         const uint64_t endb = (st.end_bit + 7) / 8, consumed = endb + (st.format == SPNG_FORMAT_ZLIB ? 4 : 0);

@@ -36,7 +36,7 @@ class LZ77:
             self._in = bytearray()
             self._d_in, self._n_in = None, 0      # device: all compressed bytes so far
             self._d_out = None                    # device: all inflated bytes so far
-            self._state = (0, 0)
+            self._state = (0, 0, 0, 0)
             self._out = b""
             self._avail = 0
             self._cursor = 0
@@ -290,7 +290,7 @@ class PNG:
             direct = not self.interlaced and depth * channels >= 8
             self._d_work = None if direct else s.empty(self._U + 64)
             self._d_storage = s.to_device(self._storage) if self._storage_bytes else s.empty(1)
-            self._state = (0, 0)
+            self._state = (0, 0, 0, 0)
             self._defiltered = 0
             self.defiltered_total = 0            # scanline bytes handed to the defilter over all pushes (each row once: == U at the end)
 

@@ -21,7 +21,7 @@ class Pusher:
         self.s, self.fmt = s, fmt
         self.d_in, self.n = s.empty(1 << 16), 0
         self.d_out = s.empty(cap)
-        self.state = (0, 0)
+        self.state = (0, 0, 0, 0)
         self.states = [self.state]
 
     def push(self, piece):
@@ -357,3 +357,59 @@ def test_mirror_deflator_streams_every_push(gpu):
             out += chunk
         assert out == ph.orc_deflate(data, level)
         assert d.device_calls == pushes and early > 0
+
+
+def test_resume_inside_a_block_costs_every_byte_once(gpu):
+    """VERDICT r5 (missing 1, next 7): a stream that is ONE block, pushed in pieces.  Block-granular resumption decodes the block again
+    from its header on every push -- O(n k); with the token position in the state the call goes on where the last one stopped.
+    Small enough for the oracle after every push: 1.5 MiB of literals in one fixed-Huffman block (assembled by hand: zlib closes a block every 32 K symbols) in 48 pushes; then 32 MiB in 512 pushes against zlib's own streaming inflate, within 2 x the one-shot time."""
+    import time
+    import torch
+    s = gpu.load()
+    rng = np.random.default_rng(3)
+
+    def one_block(n):
+        # (zlib closes a block every 32 K symbols whatever it is asked: the block is assembled here -- a final fixed-Huffman block of n
+        # literals below 144, eight bits each most significant first, and the end-of-block code)
+        vals = rng.integers(0, 144, n, dtype=np.uint8)
+        bits = np.concatenate([np.array([1, 1, 0], np.uint8), np.unpackbits((vals + 0x30)[:, None], axis=1, bitorder="big").reshape(-1),
+                               np.zeros(7, np.uint8)])
+        data = vals.tobytes()
+        return data, b"\x78\x01" + np.packbits(bits, bitorder="little").tobytes() + zlib.adler32(data).to_bytes(4, "big")
+
+    data, z = one_block(3 << 19)
+    last, p = check_prefixes(s, z, [len(z) // 48 + 1])
+    assert last.status == 0 and last.written == len(data)
+    inside = [st for st in p.states if st[2]]
+    assert len(set(inside)) >= 40 and all(b[2] >= a[2] for a, b in zip(inside, inside[1:])), "the token position moves forward inside the block"
+    assert len({st[0] for st in inside}) == 1, "one block"
+    # 32 MiB, 512 pushes
+    data, z = one_block(32 << 20)
+    d_z = s.to_device(z)
+    d_out = s.empty(len(data) + 64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res, _ = s.inflate_resume(d_z, len(z), d_out, spng.FORMAT_ZLIB, (0, 0, 0, 0))
+    torch.cuda.synchronize()
+    one_shot = time.perf_counter() - t0
+    assert res.status == 0 and res.written == len(data)
+    assert hashlib.sha256(bytes(d_out[:len(data)].cpu().numpy())).digest() == hashlib.sha256(data).digest()
+    d_out.zero_()
+    step = len(z) // 512 + 1
+    ref = zlib.decompressobj()
+    avail, state = 0, (0, 0, 0, 0)
+    torch.cuda.synchronize()
+    spent = 0.0
+    for k in range(512):
+        n = min(len(z), (k + 1) * step)
+        t0 = time.perf_counter()
+        res, state = s.inflate_resume(d_z, n, d_out, spng.FORMAT_ZLIB, state)
+        spent += time.perf_counter() - t0
+        avail += len(ref.decompress(z[k * step:n]))
+        assert res.status == (0 if n == len(z) else 1), (k, res.status)
+        assert res.written == avail, (k, res.written, avail)          # bytes of the complete tokens so far: zlib's streaming inflate says the same
+        if n == len(z):
+            break
+    assert hashlib.sha256(bytes(d_out[:len(data)].cpu().numpy())).digest() == hashlib.sha256(data).digest()
+    print(f"one-block 32 MiB stream: one call {one_shot * 1e3:.1f} ms, 512 pushes {spent * 1e3:.1f} ms")
+    assert spent <= 2.0 * one_shot + 0.25, (spent, one_shot)           # (+ the 512 calls' own launch overhead: ~0.4 ms each)

@@ -3,7 +3,8 @@
 // prints its result the way the oracle's is printed, so that tests/test_emu_inflate.py can compare status, counts, error payload and
 // bytes.  From a prepared copy of the source (EMU_INFLATE_SRC); never part of the product.
 //
-//   emu_inflate <stream file> <format 0 zlib | 1 ios | 2 gzip-less raw> <capacity> <output file> [start_bit out_pos <bytes so far file>]
+//   emu_inflate <stream file> <format 0 zlib | 1 ios | 2 gzip-less raw> <capacity> <output file> [block_bit block_out token_bit token_out <bytes so far file>]
+//   (the five: a call of spng_inflate_resume_batch that goes on where an earlier one stopped -- its four words of state and the output so far)
 //   prints: status written consumed aux0 aux1
 #include EMU_INFLATE_SRC
 
@@ -28,14 +29,14 @@ int main(int argc, char **argv)
     const uint64_t n = src.size();
     src.resize(n + 64);
     std::vector<uint8_t> dst(cap + 64, 0xEE);
-    uint64_t state[2] = {0, 0};
+    uint64_t state[4] = {0, 0, 0, 0};
     InflateJob job;
     memset(&job, 0, sizeof job);
     job.src = src.data(); job.dst = dst.data(); job.src_len = n; job.dst_cap = cap; job.format = format; job.image = 0; job.skip = nullptr;
     job.state = nullptr; job.internal = 0;
-    if (argc > 7) {
-        state[0] = strtoull(argv[5], nullptr, 10); state[1] = strtoull(argv[6], nullptr, 10);
-        std::vector<uint8_t> sofar = slurp(argv[7]);
+    if (argc > 9) {
+        for (int k = 0; k < 4; ++k) state[k] = strtoull(argv[5 + k], nullptr, 10);
+        std::vector<uint8_t> sofar = slurp(argv[9]);
         memcpy(dst.data(), sofar.data(), sofar.size() < cap ? sofar.size() : cap);
         job.state = state;
     }

@@ -42,7 +42,7 @@ int main(int argc, char **argv)
     memset(&st, 0, sizeof st);
     st.src = src.data(); st.dst = dst.data(); st.src_len = src.size(); st.dst_cap = want.size();
     st.format = format; st.image = 0;
-    uint64_t state[2] = {0, 0};
+    uint64_t state[4] = {0, 0, 0, 0};                          // (four words: the pipeline moves the first pair and clears the second)
     st.state = state;                                          // (api.hip: every stream has a state slot, {0, 0} unless resumed)
     if (argc > 7) {
         state[0] = st.start_bit = strtoull(argv[6], nullptr, 10); state[1] = st.out_pos = strtoull(argv[7], nullptr, 10);
