@@ -97,6 +97,8 @@ struct Ctrl {
     uint32_t check, declared, pad;
     uint64_t aux0, aux1, bits;
     uint64_t blk_bit, tok_bit;     // the header of the block the decoder stopped in; the first token (or stored byte) that was not complete (0: none)
+    uint64_t r_tok, r_done;        // a call that goes on inside a block: the bit to go on at, the bytes of the block already produced
+    // (all four live here, not in the decoder's registers: its scalar registers are the walker loop's)
     // scout <-> walker
     uint32_t w_gen, w_stop, w_idle, w_quit;   // start order (generation), stop order, acknowledgement, exit
     uint32_t w_prod, w_cons;                  // windows of this generation produced / consumed
@@ -714,12 +716,12 @@ __device__ __forceinline__ void push(Lds &s, Queue &q, unsigned long long who, u
 #define FAIL(code, a0, a1) do { status = (code); aux0 = (a0); aux1 = (a1); goto done; } while (0)
 #define PUSH(who, tok) push(s, q, (who), (tok), lane)
 
-// start_bit: the block header to start on (0: the stream's first bit).  tok_bit != 0: the call goes on INSIDE that block -- its
-// header is read again for the tables (stored blocks: for LEN), then decoding continues at bit tok_bit; done_in_block = bytes of
+// start_bit: the block header to start on (0: the stream's first bit).  inside_: the call goes on INSIDE that block -- its
+// header is read again for the tables (stored blocks: for LEN), then decoding continues at bit s.c.r_tok; s.c.r_done = bytes of
 // the block earlier calls produced (stored blocks: how far into the LEN bytes).  The reference's inflator stops and resumes at
 // any byte (LZ77.InflatorBuffers.Stream.swift:61-65, 284-288, 352-356).
 __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src, uint64_t n, int32_t format, bool resumed,
-                                                       uint64_t start_bit, uint64_t tok_bit, uint64_t done_in_block, int lane)
+                                                       uint64_t start_bit, bool inside_, int lane)
 {
     const uint64_t total = n * 8;
 #ifndef SPNG_NO_PRIO
@@ -729,8 +731,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
     int32_t status = SPNG_NEED_MORE_INPUT;
     uint64_t aux0 = 0, aux1 = 0;
     uint32_t check = 0, declared = 0, wgen = 0;
-    uint64_t blk_bit = start_bit, stop_bit = 0;                // the block at hand; where inside it the input ended (0: in its header)
-    bool inside = tok_bit != 0;                                // the first block: continue at tok_bit
+    bool inside = inside_;                                     // the first block: continue at s.c.r_tok
     Queue q = {};
     PROF_DECL
 #ifdef SPNG_INFLATE_PROF
@@ -756,7 +757,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
     for (;;) {
         // .metadata: readBlockMetadata (InflatorBuffers.Stream.swift:59-141)
         PROF_BEGIN();
-        blk_bit = bitpos(r);
+        s.c.blk_bit = bitpos(r);                               // (every lane, same value)
         if (!inside) PUSH(1ull, T_CHECK);                      // (a block starts here: the resolver notes its output position)
         if (bitpos(r) + 3 > total) goto done;
         const uint32_t bfinal = TAKE(1);
@@ -772,7 +773,8 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
             // making sure all of them fit the output
             uint64_t from = boundary / 8 + 4;
             uint32_t l_left = l;
-            if (inside) {                                      // (earlier calls copied done_in_block of the LEN bytes)
+            if (inside) {                                      // (earlier calls copied r_done of the LEN bytes)
+                const uint64_t done_in_block = uni64(s.c.r_done);
                 const uint32_t dn = done_in_block < l ? (uint32_t)done_in_block : l;
                 from += dn; l_left -= dn; inside = false;
             }
@@ -783,7 +785,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
                 const uint32_t b = (uint32_t)lane < piece ? src[from + done_ + lane] : 0u;
                 PUSH(piece == 64 ? ~0ull : (1ull << piece) - 1, b << 8);
             }
-            if (have < l_left) { r.pos = n * 8; stop_bit = n * 8; goto done; }
+            if (have < l_left) { r.pos = n * 8; s.c.tok_bit = n * 8; goto done; }
             seek(s, r, src, n, from + l_left, lane);
         } else if (type == 1 || type == 2) {
             if (type == 1) {
@@ -862,7 +864,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
             // bit; the walker only has to find the true chain of token boundaries through each
             // window and queue the tokens on it.
             {
-                if (inside) { seek_bits(s, r, src, n, tok_bit, lane); inside = false; }     // (the tables stand: on with the block's tokens)
+                if (inside) { seek_bits(s, r, src, n, uni64(s.c.r_tok), lane); inside = false; }     // (the tables stand: on with the block's tokens)
                 const uint64_t org = r.pos;
                 wgen += 1;
                 LDS_STORE(&s.c.w_prod, 0u); LDS_STORE(&s.c.w_cons, 0u);   // (every lane, same value: no branch)
@@ -1006,7 +1008,7 @@ __device__ __attribute__((always_inline)) void decoder(Lds &s, const gbyte *src,
                     if (spins > SPIN_LIMIT) SPIN_ABORT();
                 }
                 seek_bits(s, r, src, n, org + ((uint64_t)k << 6) + ent, lane);
-                if (stop == 2) { stop_bit = bitpos(r); goto done; }
+                if (stop == 2) { s.c.tok_bit = bitpos(r); goto done; }
             }
         } else {
             FAIL(SPNG_E_BLOCK_TYPE, type, 0);
@@ -1034,7 +1036,6 @@ done:
     if (lane == 0) {
         s.c.status = status; s.c.check = check; s.c.declared = declared;
         s.c.aux0 = aux0; s.c.aux1 = aux1; s.c.bits = bitpos(r);
-        s.c.blk_bit = blk_bit; s.c.tok_bit = stop_bit;
     }
     LDS_ORDER();
     if (lane == 0) LDS_STORE(&s.c.a_done, 1u);
@@ -1071,11 +1072,12 @@ __global__ __launch_bounds__(256) void inflate_kernel(const InflateJob *__restri
     if (threadIdx.x == 0) {
         s.c.tail = 0; s.c.head = 0; s.c.a_done = 0; s.c.b_fail = 0; s.c.a_wait = 0;
         s.c.w_gen = 0; s.c.w_stop = 0; s.c.w_idle = 0; s.c.w_quit = 0; s.c.w_prod = 0; s.c.w_cons = 0;
+        s.c.blk_bit = start_bit; s.c.tok_bit = 0; s.c.r_tok = tok_bit; s.c.r_done = tok_bit ? tok_out - blk_out : 0;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t role = UNI(threadIdx.x >> 6);
-    if (role == 0)      decoder(s, src, src_len, format, resumed, start_bit, tok_bit, tok_bit ? tok_out - blk_out : 0, lane);
+    if (role == 0)      decoder(s, src, src_len, format, resumed, start_bit, tok_bit != 0, lane);
     else if (role == 1) resolver(s, dst, dst_cap, src_len, resumed, internal, blk_out, out_pos, results + image, lane);
     else if (role == 2) scout(s, src, src_len, lane);
     // (wave 3 has nothing to do.  It is there because the dispatcher places 256-thread workgroups
