@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--parts-total", default="0", help="comma list: workgroups that resolve a small batch side by side, all streams "
                     "together (SPNG_CFG_RESOLVE_PARTS = total / images per call); 0 = the planner's own choice")
     ap.add_argument("--shapes", default="128x1,128x2,128x4,32x1,8x1", help="images x calls")
+    ap.add_argument("--segment-bytes", default="0", help="comma list of SPNG_CFG_SEGMENT_BYTES values (0 = the planner's own)")
     args = ap.parse_args()
     import torch
     import swift_png_amd as spng
@@ -33,7 +34,8 @@ def main():
     torch.cuda.empty_cache()
     out = {}
     shapes = [tuple(int(v) for v in sh.split("x")) for sh in args.shapes.split(",")]
-    for total, (n, groups) in [(int(t), sh) for t in args.parts_total.split(",") for sh in shapes]:
+    for segb, total, (n, groups) in [(int(sb), int(t), sh) for sb in args.segment_bytes.split(",") for t in args.parts_total.split(",") for sh in shapes]:
+        s.configure(spng.CFG_SEGMENT_BYTES, segb)
         s.configure(spng.CFG_RESOLVE_PARTS, max(2, min(64, total // (n // groups))) if total else 0)
         job = bench.DecodeJob(spng, s, torch, d_streams, n, 0, args.unique, groups)
         for _ in range(2):
@@ -52,12 +54,13 @@ def main():
         res = job.results()
         assert all(r.status == 0 and r.written == job.U for r in res)
         line = {"ms": round(dt * 1e3, 2), "mpixels_per_s": round(n * bench.MPIX / dt, 1), "stages_ms": prof}
-        tag = f"{n} images in {groups} call(s)" + (f", {total} parts in all" if total else "")
+        tag = f"{n} images in {groups} call(s)" + (f", {total} parts in all" if total else "") + (f", segments of {segb}" if segb else "")
         out[tag] = line
         print(tag + ":", json.dumps(line), flush=True)
         del job
         torch.cuda.empty_cache()
     s.configure(spng.CFG_RESOLVE_PARTS, 0)
+    s.configure(spng.CFG_SEGMENT_BYTES, 0)
     print(json.dumps(out))
 
 
