@@ -585,9 +585,14 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         // segments again: 1024 x 4K images, swift-png-made: 418 KB segments 503.4 ms per step, 180 KB 494.5, 140 KB 494.0, 100 KB
         // 500.1; zlib-made streams, whose search still costs 2.4 ms per 10^4 segments, stay: profiles/r06m_probe_segments.log)
         seg_bytes = total / ((c->block_bytes > 0 && c->block_bytes < 8192) ? 163840 : 32768);
+        // (streams of small blocks, whose search is nearly free: 32 .. 64 KiB in small batches -- one 4K image 7.6 -> 6.65 ms per
+        // call, 32 images 26.1 -> 22.7; zlib-made streams pay the search of every added segment -- 32 images 23.1 -> 27.0 at 32 KiB --
+        // and stay at 64 .. 256 KiB: profiles/r06r_probe_small_segments_*.log)
+        const bool small_blocks = c->block_bytes > 0 && c->block_bytes < 8192;
         uint64_t least = total / 4096;
-        if (least < (64u << 10)) least = 64u << 10;
-        if (least > (256u << 10)) least = 256u << 10;
+        const uint64_t lo = small_blocks ? 32u << 10 : 64u << 10, hi = small_blocks ? 64u << 10 : 256u << 10;
+        if (least < lo) least = lo;
+        if (least > hi) least = hi;
         if (seg_bytes < least) seg_bytes = least;
     }
     seg_bytes = (seg_bytes + 255) & ~(uint64_t)255;

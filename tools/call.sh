@@ -1,4 +1,2 @@
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-T0=$(date +%s)
-timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/r06q_pytest_gpu.log 2>&1; tail -5 gpurun_out/r06q_pytest_gpu.log; echo "[t+$(( $(date +%s) - T0 )) s]"
-timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 600 python tools/probe_groups.py --kind swiftpng --unique 4 --shapes 1x1,8x1,32x1,128x1,128x2 > gpurun_out/r06s_probe_groups_swiftpng.log 2>&1; grep "call(s)" gpurun_out/r06s_probe_groups_swiftpng.log | cut -c1-230
