@@ -655,7 +655,25 @@ def run_scanline_formats(torch, spng, s, n=256):
         f_ms, u_ms = s.profile_get(spng.K_FILTER)[0] / 3, s.profile_get(spng.K_UNFILTER)[0] / 3
         s.profile(False)
         moved = m * (U + S)
-        out[name] = {"images": m, "algorithmic_bytes": moved,
+        extra = {}
+        if name == "indexed8":
+            # what libpng writes for palette images: every row filtered with None -- defiltering is a pass through the kernel
+            plain = [torch.cat([torch.zeros(H, 1, dtype=torch.uint8, device=s.tdev), sr.view(H, -1)], dim=1).reshape(-1) for sr in srcs]
+            for j in range(m):
+                d_rows[j * U:(j + 1) * U] = plain[j % unique]
+            torch.cuda.synchronize()
+            assert s.lib.spng_unfilter_batch(s.ctx, ud, m, None, ctypes.c_void_p(dres.data_ptr()), None) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(d_back, d_sto), "indexed8, all rows None: rasters differ"
+            s.profile(True)
+            for _ in range(3):
+                assert s.lib.spng_unfilter_batch(s.ctx, ud, m, None, ctypes.c_void_p(dres.data_ptr()), None) == 0
+            torch.cuda.synchronize()
+            n_ms = s.profile_get(spng.K_UNFILTER)[0] / 3
+            s.profile(False)
+            extra = {"unfilter_all_rows_none": {"ms": round(n_ms, 3), "gbps": round(moved / (n_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(moved / (n_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}}
+            del plain
+        out[name] = {"images": m, "algorithmic_bytes": moved, **extra,
                      "unfilter": {"ms": round(u_ms, 3), "gbps": round(moved / (u_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(moved / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
                      "filter": {"ms": round(f_ms, 3), "gbps": round(moved / (f_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(moved / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
                      "bit_exact": True}

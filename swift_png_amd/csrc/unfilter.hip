@@ -128,7 +128,8 @@ __device__ __forceinline__ bool skip_status(int32_t s)
 }
 
 // ---- reconstruction of one tile: generic byte-wise form (any bpp) ----------------------------
-template <int BPP, int P>
+// (PAETH = false: no row of the band is filtered with Paeth -- its arithmetic is not there)
+template <int BPP, int P, bool PAETH>
 __device__ __forceinline__ void reconstruct_generic(uint8_t *tile, int rowb, int lane, uint32_t ft,
                                                     int64_t ux0, uint32_t (&o)[BPP], uint32_t (&bprev)[BPP])
 {
@@ -148,7 +149,7 @@ __device__ __forceinline__ void reconstruct_generic(uint8_t *tile, int rowb, int
             if (ft == 1) pred = a;
             else if (ft == 2) pred = b[k];
             else if (ft == 3) pred = (a + b[k]) >> 1;
-            else if (ft == 4) pred = paeth(a, b[k], c);
+            else if (PAETH && ft == 4) pred = paeth(a, b[k], c);
             o[k] = (x + pred) & 0xffu;
             mine[t * BPP + k] = (uint8_t)o[k];
             bprev[k] = b[k];
@@ -364,7 +365,9 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         constexpr bool PACKED = BPP == 3 || BPP == 6;          // (a unit in dwords: reconstruct_packed)
         constexpr int NS = PACKED ? (BPP + 3) / 4 : BPP;
         const bool any_pae = __any(ft == 4);                   // no Paeth row in this band: skip its arithmetic
-        (void)any_pae;
+        // every row of the band filtered with None (what libpng writes for palette and low-depth images): the tiles only pass
+        // through (the band below reads this one's last row back from the output, not from registers)
+        const bool all_none = !__any(row < rows && ft != 0);
         uint32_t o[NS], bprev[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k) { o[k] = 0; bprev[k] = 0; }
@@ -402,12 +405,13 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
 
             const int64_t ux0 = (int64_t)T * C::P - lane;
 #ifndef SPNG_UNF_NOCOMPUTE        // tuning builds only: measure the memory pipeline alone
-            if constexpr (PACKED) {
+            if (all_none) {
+            } else if constexpr (PACKED) {
                 (void)ux0;
                 if (any_pae) reconstruct_packed<BPP, C::P, true>(tile, C::ROWB, lane, ft, o, bprev);
                 else         reconstruct_packed<BPP, C::P, false>(tile, C::ROWB, lane, ft, o, bprev);
-            } else
-                reconstruct_generic<BPP, C::P>(tile, C::ROWB, lane, ft, ux0, o, bprev);
+            } else if (any_pae) reconstruct_generic<BPP, C::P, true>(tile, C::ROWB, lane, ft, ux0, o, bprev);
+            else                reconstruct_generic<BPP, C::P, false>(tile, C::ROWB, lane, ft, ux0, o, bprev);
 #endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 
