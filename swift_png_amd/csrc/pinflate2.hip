@@ -1229,6 +1229,10 @@ __global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ st
     uint32_t np = 0;
     if (pmax > 1 && ok && uni64(st.start_bit) == 0 && uni64(st.out_pos) == 0 && out <= uni64(st.dst_cap) && out > 0) {
         PPart *pp = parts + (uint64_t)blockIdx.x * pmax;
+        uint64_t w0 = (uint64_t)gridDim.x * (pmax - 1) > 256 ? 1 : 0;     // the first part's extra half share
+#ifdef SPNG_EMU
+        if (getenv("EMU_FIRST_PART_SHARE")) w0 = 1;            // (the emulator drives one stream: the rule would never fire)
+#endif
         uint64_t begun = 0;                                      // first byte of the part being filled
         uint32_t kk = 0, tnext = 1;                              // next boundary: the first segment at or behind tnext / pmax
         np = 1;
@@ -1236,13 +1240,18 @@ __global__ __launch_bounds__(64) void pinf2_scan_kernel(PStream *__restrict__ st
         for (uint32_t hops = 0; hops < count; ++hops) {
             const PSeg *sg = segs + first + kk;
             const uint64_t ob = uni64(sg->out_base);
-            if (kk != 0 && tnext < pmax && ob >= 32768u && ob > begun && ob * pmax >= (uint64_t)tnext * out) {
+            // (the first part resolves to bytes, the others to symbols that a second pass turns into bytes: a marker workgroup is ~1.5 x
+            // slower per byte -- 128 images: 28.3 ms against 18.9 for equal shares --, so the first part takes 1.5 shares: boundary t
+            // lies at (2 t + w0) / (2 pmax + w0) of the output, w0 = 1)
+            // (only where the marker parts run on 4 KiB tiles, two to a CU -- launch_pinf2_parts' rule; with a CU each they keep up: one
+            // image 2.94 ms with equal shares, 3.30 with the larger first part)
+            if (kk != 0 && tnext < pmax && ob >= 32768u && ob > begun && ob * (2 * pmax + w0) >= (uint64_t)(2 * tnext + w0) * out) {
                 if (lane == 0) {
                     pp[np].seg = kk; pp[np].out_pos = ob; pp[np].present = 1;
                     pp[np - 1].seg_end = kk; pp[np - 1].out_len = ob - begun;
                 }
                 begun = ob; np += 1;
-                tnext = (uint32_t)(ob * pmax / out) + 1;
+                tnext = (uint32_t)((ob * (2 * pmax + w0) / out + 2 - w0) / 2);      // the first boundary behind ob: 2 t + w0 > ob (2 pmax + w0) / out
             }
             if ((int32_t)UNI(sg->status) == PSEG_FINAL || (int32_t)UNI(sg->status) == PSEG_PARTIAL) break;
             kk = UNI(sg->next);

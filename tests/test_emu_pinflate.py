@@ -279,6 +279,10 @@ def test_emulated_pipeline_resolves_a_stream_in_parts(emu, tmp_path, name, parts
     assert r.returncode == 0, (name, r.stdout[-300:], r.stderr[-300:])
     made = int(r.stdout.split("parts:")[1].split()[0])
     assert 2 <= made <= parts, r.stdout
+    # the first part with one and a half shares (what batches whose marker parts share their CUs get)
+    r = subprocess.run([str(emu), str(tmp_path / "z"), str(tmp_path / "raw"), "0", str(segment)], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, EMU_PARTS=str(parts), EMU_MARK_TILE=str(tile), EMU_FIRST_PART_SHARE="1"))
+    assert r.returncode == 0 and 2 <= int(r.stdout.split("parts:")[1].split()[0]) <= parts, (name, r.stdout[-300:], r.stderr[-300:])
     # a wrong Adler-32 is the pipeline's own verdict in parts too
     bad = bytearray(z); bad[-1] ^= 0x20
     (tmp_path / "z").write_bytes(bytes(bad))

@@ -1,9 +1,4 @@
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_decode.py -q -x -k "unfilter or pngsuite or fuzz_shapes" 2>&1 | tail -2
-timeout 900 python bench.py --steps 2 --warmup 1 --no-alt --no-cpu-baseline --legs scanline_formats,small_images > gpurun_out/r06u_scan.json 2> gpurun_out/r06u.err; python - <<PY
-import json
-d=json.load(open('gpurun_out/r06u_scan.json'))
-print(json.dumps(d['scanline_formats'])[:1800])
-print(d['small_images']['ms_per_step'], d['small_images']['kernels_ms'])
-PY
-tail -3 gpurun_out/r06u.err
+timeout 900 python -m pytest tests/test_gpu_pinflate.py tests/test_gpu_multi.py -q -x 2>&1 | tail -2
+timeout 600 python tools/probe_groups.py --kind swiftpng --unique 4 --shapes 1x1,8x1,32x1,128x1,128x2 > gpurun_out/r06w_probe_groups_swiftpng.log 2>&1; grep "call(s)" gpurun_out/r06w_probe_groups_swiftpng.log | cut -c1-200
+timeout 600 python tools/probe_groups.py --kind zlib --unique 4 --shapes 1x1,32x1,128x1 > gpurun_out/r06w_probe_groups_zlib.log 2>&1; grep "call(s)" gpurun_out/r06w_probe_groups_zlib.log | cut -c1-200
