@@ -1,51 +1,31 @@
 #!/bin/bash
-# Round-end measurement on the GPU box: parity suite, smoke, kernel-trace stats of the decode and of the encode step, the PMC passes
-# (decode: FETCH_SIZE / WRITE_SIZE of the headline workload; encode: the same two counters + instruction counters of the level-9
-# deflate of 1024 random 64 MiB streams), the N = 8 shard shape, then the headline bench line (it reads the traffic measured here).
-# Everything lands in gpurun_out/ (copied to profiles/ afterwards).
+# Round-end measurement on the GPU box, ONE gpurun call: parity suite, smoke, kernel-trace stats of the decode step and of the encode
+# step, the PMC passes of the level-9 deflate (FETCH_SIZE / WRITE_SIZE in separate passes), then the headline bench line with
+# `--traffic` (its own PMC sub-runs of the decode step, taken inside the invocation), the driver's own command, phase counters.
+# Everything lands in gpurun_out/ (the files quoted in DESIGN.md / profiles/README.md are copied to profiles/ afterwards).
 cd /root/repo; mkdir -p gpurun_out; export TMPDIR=/tmp
-export R=${R:-r05}
+export R=${R:-r06}
 T0=$(date +%s); lap() { echo "[t+$(( $(date +%s) - T0 )) s] $1"; }
 python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
-# A/B in front of everything (AB="name name": builds under variants/, tools/build_variant.sh): the shipped library is the LAST name's
-# build; an earlier one that decodes the headline workload more than 0.5 % faster takes its place for the rest of this run
-# (gpurun_out/${R}_ab.txt says which -- the source is then set to match before the round ends)
-if [ -n "$AB" ]; then
-  for v in $AB; do
-    SPNG_LIB=/root/repo/variants/libspng_$v.so timeout 300 python tools/probe_v2.py --kinds swiftpng --steps 3 > gpurun_out/${R}_ab_$v.log 2>&1
-    echo "== $v $(grep -E '^swiftpng auto' gpurun_out/${R}_ab_$v.log | cut -c1-230)"
-  done
-  python tools/ab_pick.py $R $AB > gpurun_out/${R}_ab.txt
-  cat gpurun_out/${R}_ab.txt; lap "A/B"
-fi
 [ -n "$SKIP_TESTS" ] || timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${R}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${R}_pytest_gpu.log
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${R}_smoke.log 2>&1; tail -1 gpurun_out/${R}_smoke.log; lap "tests + smoke"
-# decode: kernel-trace stats of the bench command
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python bench.py --steps 3 --warmup 1 --no-swiftpng --no-cpu-baseline --no-extras > gpurun_out/${R}_bench_under_rocprof.json 2> gpurun_out/prof_stats.err
-find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${R}_rocprof_kernel_stats.csv; head -8 gpurun_out/${R}_rocprof_kernel_stats.csv | cut -c1-160
-# decode: PMC traffic (a warm-up step and a timed one: figures per step = sums / 2)
-if [ -z "$SKIP_PMC" ]; then
-P="python bench.py --steps 1 --warmup 1 --no-swiftpng --no-cpu-baseline --no-extras"
-timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- $P > /dev/null 2> gpurun_out/prof_fetch.err
-timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- $P > /dev/null 2> gpurun_out/prof_write.err
-python tools/pmc_traffic.py gpurun_out/prof_fetch gpurun_out/prof_write swiftpng 1024 32 gpurun_out/${R}_pmc_traffic.json 2 > gpurun_out/pmc.log 2>&1; tail -12 gpurun_out/pmc.log; lap "decode stats + PMC"
-cp gpurun_out/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json   # (the bench line below reads it: traffic of this very build)
-fi
+# decode: kernel-trace stats of the bench command (1 warm-up + 3 timed steps of the headline workload)
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python /root/repo/bench.py --steps 3 --warmup 1 --no-alt --no-cpu-baseline --no-extras > /root/repo/gpurun_out/${R}_bench_under_rocprof.json 2> /tmp/prof_stats.err)
+find /tmp/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${R}_rocprof_kernel_stats.csv; head -6 gpurun_out/${R}_rocprof_kernel_stats.csv | cut -c1-160; lap "decode kernel stats"
 if [ -z "$SKIP_ENC" ]; then
-# encode: kernel-trace stats of the encode step, PMC traffic and instruction counters of its deflate
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_enc -- python bench.py --mode encode --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${R}_bench_encode_under_rocprof.json 2> gpurun_out/prof_enc.err
-find gpurun_out/prof_enc -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${R}_rocprof_encode_kernel_stats.csv; head -6 gpurun_out/${R}_rocprof_encode_kernel_stats.csv | cut -c1-160
-PROBE_WHICH=random PROBE_N=1024 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/enc_fetch -- python tools/probe_deflate2.py > /dev/null 2> gpurun_out/enc_fetch.err
-PROBE_WHICH=random PROBE_N=1024 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/enc_write -- python tools/probe_deflate2.py > /dev/null 2> gpurun_out/enc_write.err
-python tools/pmc_encode.py gpurun_out/enc_fetch gpurun_out/enc_write 1024 gpurun_out/${R}_pmc_encode.json > gpurun_out/pmc_enc.log 2>&1; tail -5 gpurun_out/pmc_enc.log; lap "encode stats + PMC"
-cp gpurun_out/${R}_pmc_encode.json profiles/${R}_pmc_encode.json
+# encode: kernel-trace stats of the encode step, PMC traffic of its deflate (a warm-up call and a timed one: figures per call)
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_enc -- python /root/repo/bench.py --mode encode --steps 1 --warmup 1 --no-cpu-baseline > /root/repo/gpurun_out/${R}_bench_encode_under_rocprof.json 2> /tmp/prof_enc.err)
+find /tmp/prof_enc -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/${R}_rocprof_encode_kernel_stats.csv; head -5 gpurun_out/${R}_rocprof_encode_kernel_stats.csv | cut -c1-160
+(cd /tmp && PROBE_WHICH=random PROBE_N=1024 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/enc_fetch -- python /root/repo/tools/probe_deflate2.py > /dev/null 2> /tmp/enc_fetch.err)
+(cd /tmp && PROBE_WHICH=random PROBE_N=1024 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/enc_write -- python /root/repo/tools/probe_deflate2.py > /dev/null 2> /tmp/enc_write.err)
+python tools/pmc_encode.py /tmp/enc_fetch /tmp/enc_write 1024 gpurun_out/${R}_pmc_encode.json > gpurun_out/pmc_enc.log 2>&1; tail -3 gpurun_out/pmc_enc.log; lap "encode stats + PMC"
+cp gpurun_out/${R}_pmc_encode.json profiles/${R}_pmc_encode.json   # (the bench line below reads it: traffic of this very build)
 fi
-# (instruction counters of the deflate kernels: profiles/r05k_pmc_l6_insts.json, taken earlier in the round on the level-6 probe)
-# the headline line last: it carries the traffic measured above
-[ -n "$SKIP_BENCH" ] || { timeout 1500 python bench.py > gpurun_out/${R}_bench_n1.json 2> gpurun_out/${R}_bench.err; head -c 1500 gpurun_out/${R}_bench_n1.json; echo; lap "bench"; }
-# probes (last: what a budget that runs out may cut)
-[ -n "$SKIP_PROBES" ] || { timeout 400 python tools/probe_groups.py --kind zlib --unique 4 > gpurun_out/${R}_probe_groups.log 2>&1; head -3 gpurun_out/${R}_probe_groups.log
-PROBE_LEVEL=6 PROBE_WHICH=synth4k,photo PROBE_N=256 timeout 300 python tools/probe_deflate2.py > gpurun_out/${R}_probe_l6_256.log 2>&1; tail -2 gpurun_out/${R}_probe_l6_256.log; }
-rm -rf gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_enc gpurun_out/enc_fetch gpurun_out/enc_write gpurun_out/enc_insts
+# the headline line: `--traffic` takes the decode step's PMC passes inside the invocation (profiles/r06_pmc_traffic.json is rewritten)
+[ -n "$SKIP_BENCH" ] || { timeout 2400 python bench.py --traffic > gpurun_out/${R}_bench_n1.json 2> gpurun_out/${R}_bench.err; head -c 1200 gpurun_out/${R}_bench_n1.json; echo; tail -2 gpurun_out/${R}_bench.err; cp profiles/${R}_pmc_traffic.json gpurun_out/ 2>/dev/null; lap "bench --traffic"; }
+# the driver's own command
+[ -n "$SKIP_DRIVER" ] || { timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${R}_bench_driver_cmd.json 2> gpurun_out/${R}_bench_driver.err; head -c 400 gpurun_out/${R}_bench_driver_cmd.json; echo; lap "driver's command"; }
 # phase cycle counters of one decode wave / one resolve workgroup (a -DSPNG_D_PROF build of the shipped source)
-[ -n "$SKIP_PROBES" ] || [ ! -f variants/libspng_g_prof.so ] || { SPNG_LIB=/root/repo/variants/libspng_g_prof.so timeout 200 python tools/probe_v2.py --kinds swiftpng --steps 1 > gpurun_out/${R}_dprof.log 2>&1; grep -E "^(decode|resolve)" gpurun_out/${R}_dprof.log | sort | uniq -c | sort -rn | head -4 | cut -c1-400; }
+[ ! -f variants/libspng_prof.so ] || { SPNG_LIB=/root/repo/variants/libspng_prof.so timeout 200 python tools/probe_v2.py --kinds swiftpng --steps 1 > gpurun_out/${R}_dprof.log 2>&1; grep -E "^(decode|resolve)" gpurun_out/${R}_dprof.log | sort | uniq -c | sort -rn | head -3 | cut -c1-400; }
+rm -rf /tmp/prof_stats /tmp/prof_enc /tmp/enc_fetch /tmp/enc_write
+lap "done"
