@@ -1,5 +1,5 @@
 """GPU probe: the two kernels of the level >= 8 rounds -- time of a batch, of its search launches and of its parse launches."""
-import sys, time, os; sys.path.insert(0, ".")
+import sys, time, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (runs from any directory: rocprofv3 wants /tmp)
 import numpy as np, torch
 import swift_png_amd as spng
 from swift_png_amd import synth
