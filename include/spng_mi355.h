@@ -140,7 +140,7 @@ enum { SPNG_CFG_INFLATE_MODE = 0,   /* SPNG_INFLATE_AUTO: parallel pipeline, ser
                                               on two streams, the decode of one beside the resolve of the other
                                               (an experiment: slower than one pass on MI355X, so never by default) */
        SPNG_CFG_RESOLVE_PARTS = 5,         /* parallel inflate, batches of <= 384 streams: workgroups that resolve ONE stream side by
-                                              side (0: as many as fill the chip, at most 64; 1: one, as in large batches; n: n) */
+                                              side (0: as many as fill the chip, at most 128 and not below ~1 MiB of output each; 1: one, as in large batches; n: n, at most 128) */
        SPNG_CFG_DEFLATE_MODE = 6,          /* levels >= 8: SPNG_DEFLATE_AUTO = search and parse in kernels of their own, rounds of 2^21 vertices
                                               (streams its candidate pool cannot serve: the one-kernel search afterwards);
                                               SPNG_DEFLATE_ONE_KERNEL = one wave per stream does everything (round 2's kernel) */

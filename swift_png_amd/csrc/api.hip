@@ -536,6 +536,9 @@ struct InflatePlan {
     }
 };
 
+#ifndef SPNG_PARTS_MAX
+#define SPNG_PARTS_MAX 128        // parts a stream's chain is cut into at most (round 5: 64 -- one to four images left half the chip idle)
+#endif
 static constexpr uint64_t RESUME_SERIAL_BITS = 8ull << 20;      // 1 MiB of input inside one block: resume there, not at its header
 
 // Cuts every stream into segments and makes sure the context owns what the pipeline needs.  Segment length: long
@@ -725,7 +728,16 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         uint32_t pm = (uint32_t)(512 / p.jobs.size());
         if (pm < 2) pm = 2;
         if (c->cfg[SPNG_CFG_RESOLVE_PARTS] > 1) pm = (uint32_t)c->cfg[SPNG_CFG_RESOLVE_PARTS];
-        if (pm > 64) pm = 64;
+        if (pm > SPNG_PARTS_MAX) pm = SPNG_PARTS_MAX;
+        if (c->cfg[SPNG_CFG_RESOLVE_PARTS] <= 1) {
+            // (a part has fixed costs -- its first window, the hand-over of the windows part by part, the symbols' second pass --: not
+            // below ~1 MiB of output each.  One 4K image: 64 parts 2.94 ms, 128 parts 3.81; the 8192^2 RGBA16 image of configs[4]:
+            // 64 parts 11.1 ms, 128 parts 8.3: profiles/r06x_probe_parts128.log)
+            uint64_t most = 0;
+            for (auto &j : p.jobs) most = j.dst_cap > most ? j.dst_cap : most;
+            const uint64_t by_size = most >> 20 < 2 ? 2 : most >> 20;
+            if (pm > by_size) pm = (uint32_t)by_size;
+        }
         uint64_t syms = 0;
         for (size_t i = 0; i < p.jobs.size(); ++i) {
             p.streams[i].sym_off = syms;

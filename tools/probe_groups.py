@@ -36,7 +36,7 @@ def main():
     shapes = [tuple(int(v) for v in sh.split("x")) for sh in args.shapes.split(",")]
     for segb, total, (n, groups) in [(int(sb), int(t), sh) for sb in args.segment_bytes.split(",") for t in args.parts_total.split(",") for sh in shapes]:
         s.configure(spng.CFG_SEGMENT_BYTES, segb)
-        s.configure(spng.CFG_RESOLVE_PARTS, max(2, min(64, total // (n // groups))) if total else 0)
+        s.configure(spng.CFG_RESOLVE_PARTS, max(2, min(128, total // (n // groups))) if total else 0)
         job = bench.DecodeJob(spng, s, torch, d_streams, n, 0, args.unique, groups)
         for _ in range(2):
             for g in range(groups):
