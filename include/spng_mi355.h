@@ -416,6 +416,10 @@ int32_t spng_copy_ceiling(spng_ctx *ctx, void *d_dst, const void *d_src, uint64_
 /* Gives the context's scratch back to the device (token pool, symbol scratch, deflate slab and rings): the next call that
  * needs one allocates it again.  Waits for the context's work first. */
 int32_t spng_trim(spng_ctx *ctx);
+/* 1: this device's LDS serves the lanes of an atomic exchange on one address in ascending lane order (probed when the context was
+ * created) and the deflater's match search inserts a batch of positions with ONE exchange per lane; 0: it keeps the read-back form.
+ * No reference counterpart (which of two bit-identical code paths runs: bench and tests report it). */
+int32_t spng_lds_exchange_ordered(spng_ctx *ctx, int32_t *ordered);
 
 #ifdef __cplusplus
 }

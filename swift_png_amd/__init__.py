@@ -54,7 +54,7 @@ EXPORTS = [
     "spng_unfilter_resume_batch", "spng_decode_batch",
     "spng_inflate", "spng_unfilter", "spng_decode", "spng_adler32", "spng_filter_batch", "spng_filter",
     "spng_lex_batch", "spng_write_idat_batch", "spng_crc32", "spng_unpack_batch", "spng_unpack", "spng_unpack_as", "spng_pack_batch", "spng_pack_as", "spng_deflate_bound", "spng_deflate_batch", "spng_deflate", "spng_deflate_window", "spng_encode_batch",
-    "spng_shard", "spng_decode_batch_multi", "spng_copy_ceiling", "spng_trim", "spng_deflate_state_bytes", "spng_deflate_resume_batch",
+    "spng_shard", "spng_decode_batch_multi", "spng_copy_ceiling", "spng_trim", "spng_lds_exchange_ordered", "spng_deflate_state_bytes", "spng_deflate_resume_batch",
 ]
 
 

@@ -251,6 +251,8 @@ int32_t spng_create(int device, void *stream, spng_ctx **out)
         if (e2 != hipSuccess) { delete c; return fail_hip(e2, "hipStreamCreateWithFlags"); }
         c->owns_stream = true;
     }
+    // (the deflater's match search asks the device once how its LDS orders the lanes of an atomic exchange: deflate.hip)
+    if (hipError_t e3 = launch_deflate3_probe(c->stream); e3 != hipSuccess) { (void)hipGetLastError(); }
     *out = c;
     return SPNG_DONE;
 }
@@ -2133,6 +2135,18 @@ int32_t spng_copy_ceiling(spng_ctx *c, void *d_dst, const void *d_src, uint64_t 
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     c->pool.push_back(e0); c->pool.push_back(e1);
     *ms_per_copy = (double)ms / repeats;
+    return SPNG_DONE;
+}
+
+int32_t spng_lds_exchange_ordered(spng_ctx *c, int32_t *ordered)
+{
+    if (!c || !ordered) return SPNG_E_ARGUMENT;
+    HIP_TRY(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t v = 0;
+    HIP_TRY(deflate3_probe_result(&v));
+    *ordered = (int32_t)v;
     return SPNG_DONE;
 }
 

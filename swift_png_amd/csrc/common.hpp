@@ -316,6 +316,8 @@ uint64_t deflate3_round_positions();
 uint64_t deflate3_end(uint64_t n, bool more);
 hipError_t launch_deflate3_begin(const D3Stream *d_streams, uint32_t count, hipStream_t stream);
 hipError_t launch_deflate3_search(const D3Stream *d_streams, uint32_t count, uint32_t cps, uint32_t chunk_len, uint32_t parity, hipStream_t stream);
+hipError_t launch_deflate3_probe(hipStream_t stream);
+hipError_t deflate3_probe_result(uint32_t *ordered);      // once per context: may the match search's inserter use the one-exchange form?
 hipError_t launch_deflate3_parse(const D3Stream *d_streams, uint32_t count, spng_result *d_results, uint32_t parity, hipStream_t stream);
 // ... with the blocks written side by side (one-shot streams)
 uint64_t deflate4_max_blocks(uint64_t positions);

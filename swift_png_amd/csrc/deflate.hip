@@ -1521,12 +1521,111 @@ static constexpr uint32_t D3_FAR = 40000;                       // where a head 
 #ifndef SPNG_D3_HBITS
 #define SPNG_D3_HBITS 13
 #endif
+// ds_mskor_rtn_b32: MEM = (MEM & ~mask) | data, the old dword back -- an exchange of HALF a dword, which is what a 16-bit bucket head is.
+__device__ __forceinline__ uint32_t lds_mskor(uint16_t *p, uint32_t mask, uint32_t data)
+{
+#ifdef SPNG_EMU
+    // (fibers run one after the other between two meetings of their wave, lane 0 first: the lanes of one address in ascending order)
+    uint32_t *w = (uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t old = *w;
+    *w = (old & ~mask) | data;
+    return old;
+#else
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)p & ~3u;
+    uint32_t r;
+    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(a), "v"(mask), "v"(data) : "memory");
+    return r;
+#endif
+}
+// the bucket's old head out, `mine` in: one LDS operation
+__device__ __forceinline__ uint32_t lds_exchange16(uint16_t *p, uint32_t mine)
+{
+    const uint32_t sh = ((uint32_t)(uintptr_t)p & 2u) << 3;
+    return (lds_mskor(p, 0xffffu << sh, (mine & 0xffffu) << sh) >> sh) & 0xffffu;
+}
+// four of them, one wait: the LDS serves a wave's operations in the order it issued them, so the four batches of a quad of 256
+// positions keep their order and the inserter pays one round trip for the quad instead of four
+__device__ __forceinline__ void lds_exchange16_x4(uint16_t *p0, uint16_t *p1, uint16_t *p2, uint16_t *p3, const uint32_t (&mine)[4], uint32_t (&old)[4])
+{
+#ifdef SPNG_EMU
+    uint16_t *p[4] = {p0, p1, p2, p3};
+    for (int k = 0; k < 4; ++k) { old[k] = lds_exchange16(p[k], mine[k]); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); }   // (the emulator's lanes meet here: batch k before batch k + 1)
+#else
+    uint16_t *p[4] = {p0, p1, p2, p3};
+    uint32_t a[4], m[4], d[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t full = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)p[k];
+        sh[k] = (full & 2u) << 3; a[k] = full & ~3u; m[k] = 0xffffu << sh[k]; d[k] = (mine[k] & 0xffffu) << sh[k];
+    }
+    uint32_t r0, r1, r2, r3;
+    asm volatile("ds_mskor_rtn_b32 %0, %4, %5, %6\n\tds_mskor_rtn_b32 %1, %7, %8, %9\n\tds_mskor_rtn_b32 %2, %10, %11, %12\n\t"
+                 "ds_mskor_rtn_b32 %3, %13, %14, %15\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(a[0]), "v"(m[0]), "v"(d[0]), "v"(a[1]), "v"(m[1]), "v"(d[1]), "v"(a[2]), "v"(m[2]), "v"(d[2]), "v"(a[3]), "v"(m[3]), "v"(d[3])
+                 : "memory");
+    old[0] = (r0 >> sh[0]) & 0xffffu; old[1] = (r1 >> sh[1]) & 0xffffu; old[2] = (r2 >> sh[2]) & 0xffffu; old[3] = (r3 >> sh[3]) & 0xffffu;
+#endif
+}
+// Does this device's LDS serve the lanes that exchange on ONE halfword in ascending lane order, whatever the lanes on the dword's
+// other half do?  (The ISA does not promise it; every part seen so far does.)  d3_lds_order_kernel -- launched once per context,
+// spng_create -- tries five address patterns and sets the flag the inserter reads; where the answer is no, d3_insert keeps the
+// read-back form of round 5.
+#ifdef SPNG_EMU
+static uint32_t g_d3_xchg = getenv("EMU_D3_READBACK") ? 0u : 1u;      // (tests run both forms of the inserter)
+#else
+__device__ uint32_t g_d3_xchg = 0;
+#endif
+__device__ __forceinline__ uint32_t d3_probe_cell(int pattern, uint32_t lane)
+{
+    return pattern == 0 ? 0u : pattern == 1 ? lane & 1u : pattern == 2 ? lane >> 5 : pattern == 3 ? (lane * 7u) & 3u : (lane * 5u) % 11u;
+}
+__global__ __launch_bounds__(64) void d3_lds_order_kernel(uint32_t allow)
+{
+    __shared__ uint16_t cell[64];
+    const int lane = threadIdx.x;
+    bool ok = true;
+#pragma unroll 1
+    for (int pattern = 0; pattern < 5; ++pattern) {
+        cell[lane] = (uint16_t)(1000u + (uint32_t)lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        const uint32_t a = d3_probe_cell(pattern, (uint32_t)lane);
+        const uint32_t got = lds_exchange16(&cell[a], (uint32_t)lane + 1u);
+        // expected: the value of the nearest lower lane with the same cell, or the cell's first content
+        uint32_t want = 1000u + a;
+        for (int l = 0; l < lane; ++l)
+            if (d3_probe_cell(pattern, (uint32_t)l) == a) want = (uint32_t)l + 1u;
+        ok = ok && got == want;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        // ... and what stays is the highest lane's
+        uint32_t last = 1000u + (uint32_t)lane;
+        for (int l = 0; l < 64; ++l)
+            if (d3_probe_cell(pattern, (uint32_t)l) == (uint32_t)lane) last = (uint32_t)l + 1u;
+        ok = ok && cell[lane] == last;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    }
+    const bool all = __ballot(!ok) == 0;
+    if (lane == 0) g_d3_xchg = all && allow ? 1u : 0u;
+}
+#ifndef SPNG_EMU
+hipError_t launch_deflate3_probe(hipStream_t stream)
+{
+    d3_lds_order_kernel<<<1, 64, 0, stream>>>(getenv("SPNG_D3_READBACK") ? 0u : 1u);     // (the A/B switch of tools/probe_deflate2.py)
+    return hipGetLastError();
+}
+// what the probe found on the current device (after the stream it ran on has been waited for)
+hipError_t deflate3_probe_result(uint32_t *ordered)
+{
+    return hipMemcpyFromSymbol(ordered, HIP_SYMBOL(g_d3_xchg), sizeof(uint32_t), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 template <uint32_t R_>
 struct D3LdsT {
     static constexpr uint32_t R = R_;                          // ring positions (a multiple of 256)
     union { uint8_t in[R_ + D3_MIR]; uint32_t in32[(R_ + D3_MIR) / 4]; };
     uint16_t link[R_];
-    uint16_t head[(1u << SPNG_D3_HBITS) + 64];                  // (+ a spare slot for idle lanes)
+    alignas(4) uint16_t head[(1u << SPNG_D3_HBITS) + 64];       // (+ a spare slot for idle lanes)
     uint32_t cur[SPNG_D3_WAVES];                                // the batch each wave is at (~0: none any more)
     uint32_t staged, inserted, next, pad;                       // positions (relative to the warm-up's first) below which bytes / links stand; batches claimed
 #ifdef SPNG_D3_PROF
@@ -1590,7 +1689,7 @@ __device__ __forceinline__ uint32_t d3_common_prefix(const L &s, uint32_t q, uin
 #define D3_MEET() ((void)0)
 #endif
 template <class L>
-__device__ __forceinline__ void d3_insert(L &s, uint32_t rel, uint32_t idx, uint32_t key, uint64_t p0, uint32_t pm, uint64_t n, bool sum, uint32_t &accS, uint32_t &accI, int lane)
+__device__ __forceinline__ void d3_insert(L &s, uint32_t rel, uint32_t idx, uint32_t key, uint64_t p0, uint32_t pm, uint64_t n, bool sum, uint32_t &accS, uint32_t &accI, bool xchg, int lane)
 {
     const uint64_t p = p0 + lane;
     const bool live = p + 4 <= n;                              // the last three positions never start a match
@@ -1604,6 +1703,19 @@ __device__ __forceinline__ void d3_insert(L &s, uint32_t rel, uint32_t idx, uint
     const uint32_t slot = live ? h : spare;
     // (the store and the read-back are atomic operations: what comes back is what SOME lane of the bucket stored -- plain
     //  accesses the compiler forwards from this lane's own store, and the duplicate test below is never true)
+    if (xchg) {
+        // Round 6: ONE LDS operation.  ds_mskor_rtn_b32 on the bucket's half of its dword hands every lane what stood in its bucket and
+        // leaves its own position there; the lanes of one bucket are served in ascending lane order (what d3_lds_order_kernel has seen
+        // this device do, or this path is not taken), so a lane gets the nearest lower lane of its bucket -- or the bucket's old head --
+        // and the highest lane stays: the read-back, the ballot and the radix match below are this one instruction.  (The inserter
+        // is ONE wave per CU and every searcher waits for it: 750 cycles of the 1465 a batch of 64 positions took were its
+        // dependent LDS round trips.  Heads stay 16 bits wide: 32-bit cells for a plain exchange cost the CU its second workgroup.)
+        const uint32_t old = lds_exchange16(&s.head[slot], mine);
+        const uint32_t d = (mine - old) & 0xffffu;
+        s.link[idx + lane] = (uint16_t)(live && d <= 32767u ? d : 0u);
+        D3_MEET();
+        return;
+    }
     const uint32_t old = s.head[slot];
     D3_MEET();
     __hip_atomic_store(&s.head[slot], (uint16_t)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1629,6 +1741,40 @@ __device__ __forceinline__ void d3_insert(L &s, uint32_t rel, uint32_t idx, uint
     D3_MEET();
 }
 
+// The four batches of a quad of 256 positions (the exchange form; idx: a multiple of 256, so the quad does not wrap the ring): four
+// keys, four hashes, four exchanges under one wait, four links.  first_sum / end_sum: the positions [first_sum, end_sum) are summed.
+template <class L>
+__device__ __forceinline__ void d3_insert_quad(L &s, uint32_t rel, uint32_t idx, uint64_t p0, uint32_t &pm, uint64_t n, uint32_t first_sum, uint32_t end_sum,
+                                               uint32_t &accS, uint32_t &accI, int lane)
+{
+    uint32_t key[4], mine[4], old[4], h[4];
+    bool live[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) key[k] = d3_u32(s, idx + 64u * k + (uint32_t)lane);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t r = rel + 64u * k + (uint32_t)lane;
+        const uint64_t p = p0 + 64u * k + (uint32_t)lane;
+        live[k] = p + 4 <= n;
+        if (p < n && r >= first_sum && r < end_sum) {
+            const uint32_t byte = key[k] & 0xff;
+            accS += byte;
+            accI += pm * byte;
+        }
+        pm = pm + 64 >= 65521 ? pm + 64 - 65521 : pm + 64;
+        const uint32_t hk = (key[k] * 0x9E3779B1u) >> (32 - SPNG_D3_HBITS);
+        h[k] = live[k] ? hk : (1u << SPNG_D3_HBITS) + (uint32_t)lane;
+        mine[k] = r & 0xffffu;
+    }
+    lds_exchange16_x4(&s.head[h[0]], &s.head[h[1]], &s.head[h[2]], &s.head[h[3]], mine, old);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t d = (mine[k] - old[k]) & 0xffffu;
+        s.link[idx + 64u * k + (uint32_t)lane] = (uint16_t)(live[k] && d <= 32767u ? d : 0u);
+    }
+    D3_MEET();
+}
+
 // One chunk [c0, c1) of a stream's positions on one workgroup.  rb: the round's first position (records are kept in round
 // coordinates); extra: the last `extra` positions are searched but not summed (the next chunk's: a lazy parse looks one ahead).  FULL: vinfo / bbase / bwords / pool (what dfl2_parse_kernel reads); else match[position - rb] = run << 16 | distance
 // (0: no run > 5).  temp: SPNG_D3_WAVES x 30 x 64 words of global scratch of this workgroup (FULL).
@@ -1645,6 +1791,7 @@ __device__ __forceinline__ void d3_search_chunk(L &s, const gbyte *in, uint64_t 
     const uint32_t nr = n - warm < (1u << 30) ? (uint32_t)(n - warm) : 1u << 30;  // the input's end, relative (bytes behind it read as zero)
     const uint32_t stage_end = (c1r + 336 + 255) & ~255u;      // bytes staged in all (a batch looks 258 + 8 bytes ahead, + a dword of slack)
     const uint64_t last_main = n - 4 + 1;                      // positions 0 .. n-4 are searched
+    const bool xchg = UNI(g_d3_xchg) != 0;                       // (read once: the inserter's loop keeps it in a scalar register)
     const uint32_t nbatches = (c1r - c0r + 63) / 64;
     for (uint32_t i = threadIdx.x; i < (1u << SPNG_D3_HBITS) + 64; i += SPNG_D3_WAVES * 64) s.head[i] = (uint16_t)(0u - D3_FAR);   // (far behind position 0: no link)
     if (threadIdx.x < SPNG_D3_WAVES) s.cur[threadIdx.x] = threadIdx.x == 0 ? ~0u : 0u;
@@ -1718,14 +1865,18 @@ __device__ __forceinline__ void d3_search_chunk(L &s, const gbyte *in, uint64_t 
                 D3_MEET();
             }
             if (staged < stage_end) stage_step();              // the step behind this quad's positions: their keys reach three bytes into it
-            if (i == 0) key_next = d3_u32(s, (uint32_t)lane);
             D3P_T0();
+            const bool quad = xchg && i + 256 <= c1r;
+            if (quad) {
+                d3_insert_quad(s, i, iidx, warm + i, pm, n, c0r, c1r - extra, accS, accI, lane);
+                iidx = iidx + 256 >= D3R ? 0 : iidx + 256;
+            } else if (i == 0 || xchg) key_next = d3_u32(s, iidx + (uint32_t)lane);
 #pragma unroll 1
-            for (uint32_t k = 0; k < 256 && i + k < c1r; k += 64) {
+            for (uint32_t k = 0; !quad && k < 256 && i + k < c1r; k += 64) {
                 const uint32_t rel = i + k;
                 const uint32_t key = key_next, nidx = iidx + 64 >= D3R ? 0 : iidx + 64;
                 key_next = d3_u32(s, nidx + (uint32_t)lane);   // (keys travel a batch ahead: bytes below rel + 131, and i + 512 are staged)
-                d3_insert(s, rel, iidx, key, warm + rel, pm, n, rel + (uint32_t)lane >= c0r && rel + (uint32_t)lane < c1r - extra, accS, accI, lane);
+                d3_insert(s, rel, iidx, key, warm + rel, pm, n, rel + (uint32_t)lane >= c0r && rel + (uint32_t)lane < c1r - extra, accS, accI, xchg, lane);
                 iidx = nidx;
                 pm = pm + 64 >= 65521 ? pm + 64 - 65521 : pm + 64;
             }

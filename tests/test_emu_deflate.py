@@ -179,6 +179,11 @@ def test_emulated_search_window_wraps_its_ring(emu, tmp_path):
         (tmp_path / "want").write_bytes(want)
         r = subprocess.run([str(emu), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0", "1"], capture_output=True, text=True, timeout=1800)
         assert r.returncode == 0, (level, r.stdout[-300:], r.stderr[-300:])
+        # (round 6: the inserter takes a bucket's old head and leaves its position there in ONE atomic exchange where the device's LDS
+        # orders the lanes of an address -- the default here; the read-back form of round 5, which devices that do not keep: the same)
+        r = subprocess.run([str(emu), str(tmp_path / "in"), str(tmp_path / "want"), str(level), "0", "1"], capture_output=True, text=True, timeout=1800,
+                           env=dict(os.environ, EMU_D3_READBACK="1"))
+        assert r.returncode == 0, (level, "read-back inserter", r.stdout[-300:], r.stderr[-300:])
 
 
 def test_emulated_search_workgroup_of_sixteen_waves(tmp_path_factory, tmp_path):

@@ -36,7 +36,12 @@ if "synth4k" in which:
     torch.cuda.synchronize()
     run("synthetic 4096^2 rows", [rows4k[i % 4] for i in range(N)])
     del rows4k, imgs
-if "photo" in which:
+if "bench_photo" in which:
+    # the rasters of bench.py's encode_photographic leg (synth.image(100 + k)): heavier chains than the eight above
+    ph = [s.to_device(s.filter(synth.image(100 + k, 1024, 1024).tobytes(), 1024, 1024, 8, 4, False)) for k in range(8)]
+    run("bench photographic 1024^2 rows", [ph[i % 8] for i in range(N)])
+    for k in range(8): run(f"bench photographic image {100 + k}", [ph[k]] * 32)
+elif "photo" in which:
     ph = [s.to_device(s.filter(synth.image(k, 1024, 1024).tobytes(), 1024, 1024, 8, 4, False)) for k in range(8)]
     run("photographic 1024^2 rows", [ph[i % 8] for i in range(N)])
     if "one" in which: run("photographic, one stream", ph[:1])
