@@ -1299,7 +1299,6 @@ struct RLds2T {
     uint16_t h0[RT2 + 8];              // every thread's first halfword (the second half of its neighbour's last reference)
     uint32_t pt[PTC];
     uint32_t part[3 * NW2];
-    uint32_t again[3];                 // pointer jumping: somebody still has an unknown byte (flag of round r: r mod 3)
     uint32_t cut[2];                   // where the tile ends when the window holds more than a tile: bytes, halfword
 };
 
@@ -1409,7 +1408,6 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
         for (uint64_t p = (pos > WINDOW2 ? pos - WINDOW2 : 0) + (uint32_t)tid; p < pos; p += RT2) s.ring[p & (WINDOW2 - 1)] = dst[p];
     }
     if (tid < (int)(TILE2 / 32)) s.bitmap[tid] = 0;
-    if (tid < 3) s.again[tid] = 0;
     if (tid == 0) { s.rec[0][0] = 0; s.rec[0][1] = 1; }
     __syncthreads();
     const uint32_t seg_first = UNI(st.seg_first), seg_count = UNI(st.seg_count);
@@ -1594,8 +1592,14 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
             __syncthreads();
             RP2(3);
             if (tid < (int)(TILE2 / 32)) s.bitmap[tid] = 0;          // (read above; next written after the next scan's barriers)
-            // ---- pointer jumping: all of a thread's reads of a round travel together
-            for (uint32_t round = 0;; ++round) {
+            // ---- pointer jumping: all of a thread's reads of a round travel together.  Round 6: every WAVE jumps until its own bytes are
+            // known and the workgroup meets once behind the rounds (it met behind every round and went on while ANY wave had an unknown
+            // byte).  A state only ever changes from an index to what stood at that index -- an earlier index or the byte itself --
+            // so whatever a lane reads there, before or after its owner's update of this round, stands for the same byte: rounds of
+            // different waves may interleave freely (they did within a round before), and every chain ends at a byte that was known
+            // when the tile's expansion was complete.
+            for (;;) {
+                asm volatile("" ::: "memory");                       // (the states are read anew in every round)
                 bool more = false;
                 uint32_t gv[BPT2];
 #pragma unroll
@@ -1607,16 +1611,10 @@ __global__ __launch_bounds__(RT2, SPNG_R_WAVES) void pinf2_resolve_kernel(const 
                         sv[k] = gv[k]; s.state[j] = (uint16_t)gv[k]; more = more || !(gv[k] & KNOWN);
                     }
                 }
-                // one barrier per round.  Three flags in rotation: the one cleared here was last read before
-                // this round's barrier and is next set after the next round's.
-                const uint32_t fr = round % 3;
-                if (more) s.again[fr] = 1;
-                __syncthreads();
-                const bool go = s.again[fr] != 0;
-                if (tid == 0) s.again[fr == 0 ? 2 : fr - 1] = 0;
                 RPN2(9, 1);
-                if (!go) break;
+                if (!__ballot(more)) break;
             }
+            __syncthreads();
             RP2(4);
             // ---- the bytes: into the ring, then to the output in whole 16-byte units of the position
             {
