@@ -532,6 +532,42 @@ def test_deflate_one_kernel_mode(gpu):
         s.configure(gpu.CFG_DEFLATE_MODE, gpu.DEFLATE_AUTO)
 
 
+def test_deflate_inserter_forms(gpu):
+    """The match search's inserter exchanges bucket heads with one ds_mskor_rtn_b32 per lane where the device's LDS serves the
+    lanes of an address in ascending order (probed when the context is created: spng_lds_exchange_ordered), and reads its store
+    back where it does not (SPNG_D3_READBACK forces that form): both give the oracle's bytes -- hash chains with many positions
+    of one bucket in a batch (runs, a short period) and none (noise)"""
+    import ctypes
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    s = gpu.load()
+    v = ctypes.c_int32(-1)
+    assert s.lib.spng_lds_exchange_ordered(s.ctx, ctypes.byref(v)) == 0 and v.value in (0, 1)
+    assert s.lib.spng_lds_exchange_ordered(s.ctx, None) == gpu.E_ARGUMENT
+    code = ("import sys, hashlib, ctypes; sys.path.insert(0, %r); sys.path.insert(0, %r); import swift_png_amd as spng; import test_gpu_decode as t\n"
+            "s = spng.load(); v = ctypes.c_int32(-1); s.lib.spng_lds_exchange_ordered(s.ctx, ctypes.byref(v)); print('ordered', v.value)\n"
+            "for kind, data in sorted(t._deflate_payloads().items()):\n"
+            "    for level in (4, 6, 9): print(kind, level, hashlib.sha256(s.deflate(data, level)).hexdigest())\n") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for form in ("probed", "readback"):
+        env = dict(os.environ)
+        env.pop("SPNG_D3_READBACK", None)
+        if form == "readback":
+            env["SPNG_D3_READBACK"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-400:]
+        out[form] = r.stdout.strip().splitlines()
+    assert out["readback"][0] == "ordered 0"
+    assert out["probed"][0] == "ordered %d" % v.value
+    assert out["probed"][1:] == out["readback"][1:]
+    for line in out["probed"][1:]:
+        kind, level, digest = line.split()
+        assert digest == hashlib.sha256(ph.orc_deflate(_deflate_payloads()[kind], int(level))).hexdigest(), (kind, level)
+
+
 @pytest.mark.parametrize("level", [1, 6])
 def test_deflate_greedy_lazy_over_several_rounds(gpu, level):
     """levels 0-7 go through in rounds of 2^21 positions (search of round r + 1 beside the parse of round r, parse position, queued
