@@ -588,11 +588,11 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         // 1024 x 4K images, decode 317 -> 301 ms)
         // (round 6: the search is 2-3 x cheaper -- pinf2_find's bit-parallel screen --, so streams of small blocks take 2.5 x the
         // segments again: 1024 x 4K images, swift-png-made: 418 KB segments 503.4 ms per step, 180 KB 494.5, 140 KB 494.0, 100 KB
-        // 500.1; zlib-made streams, whose search still costs 2.4 ms per 10^4 segments, stay: profiles/r06m_probe_segments.log)
+        // 500.1; zlib-made streams, whose search still costs 2.4 ms per 10^4 segments, stay: profiles/archive/r06m_probe_segments.log)
         seg_bytes = total / ((c->block_bytes > 0 && c->block_bytes < 8192) ? 163840 : 32768);
         // (streams of small blocks, whose search is nearly free: 32 .. 64 KiB in small batches -- one 4K image 7.6 -> 6.65 ms per
         // call, 32 images 26.1 -> 22.7; zlib-made streams pay the search of every added segment -- 32 images 23.1 -> 27.0 at 32 KiB --
-        // and stay at 64 .. 256 KiB: profiles/r06r_probe_small_segments_*.log)
+        // and stay at 64 .. 256 KiB: profiles/archive/r06r_probe_small_segments_*.log)
         const bool small_blocks = c->block_bytes > 0 && c->block_bytes < 8192;
         uint64_t least = total / 4096;
         const uint64_t lo = small_blocks ? 32u << 10 : 64u << 10, hi = small_blocks ? 64u << 10 : 256u << 10;
@@ -734,7 +734,7 @@ static int32_t plan_inflate(spng_ctx *c, InflatePlan &p)
         if (c->cfg[SPNG_CFG_RESOLVE_PARTS] <= 1) {
             // (a part has fixed costs -- its first window, the hand-over of the windows part by part, the symbols' second pass --: not
             // below ~1 MiB of output each.  One 4K image: 64 parts 2.94 ms, 128 parts 3.81; the 8192^2 RGBA16 image of configs[4]:
-            // 64 parts 11.1 ms, 128 parts 8.3: profiles/r06x_probe_parts128.log)
+            // 64 parts 11.1 ms, 128 parts 8.3: profiles/archive/r06x_probe_parts128.log)
             uint64_t most = 0;
             for (auto &j : p.jobs) most = j.dst_cap > most ? j.dst_cap : most;
             const uint64_t by_size = most >> 20 < 2 ? 2 : most >> 20;

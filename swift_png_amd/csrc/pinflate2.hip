@@ -657,7 +657,7 @@ __device__ __forceinline__ uint32_t decode_at2(const DLds &s, uint32_t q, uint32
 // (retry: only the streams whose first pass ran out of token pages -- PStream.pass == 1 -- are looked at again)
 // (RETRY: the pass for the streams that found the pool empty is launched behind every batch and mostly has nothing to do; as
 // an instantiation of its own it has a name of its own in kernel traces)
-// Round 6: the screen.  PMC counters of the kernel on zlib-made streams (profiles/r06j_pmc_find_*.json) say that a wave retires
+// Round 6: the screen.  PMC counters of the kernel on zlib-made streams (profiles/archive/r06j_pmc_find_*.json) say that a wave retires
 // ~120 vector instructions per step of 64 bit positions and that five sixths of them are the screen, not the header parses of
 // its false positives (one position in 1150 passes it; a parse of a look-alike ends early) -- a version that validated 64
 // candidates at a time, a lane each, saved nothing.  So the screen itself: the completeness of the code-length code -- 19 fields of

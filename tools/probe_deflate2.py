@@ -20,7 +20,16 @@ def run(name, tensors):
 gen = torch.Generator(device=s.tdev); gen.manual_seed(7)
 N = int(os.environ.get("PROBE_N", "256"))
 which = os.environ.get("PROBE_WHICH", "random,photo,one")
-if "random" in which:
+if "distinct" in which:
+    # 1024 streams in 1024 buffers of their own (what bench.py's encode leg hands over) instead of 8 buffers read 128 times each
+    big = torch.randint(0, 256, (N * (64 << 20),), dtype=torch.uint8, device=s.tdev, generator=gen)
+    run("random 64 MiB, a buffer per stream", [big[i * (64 << 20):(i + 1) * (64 << 20)] for i in range(N)])
+    if os.environ.get("PROBE_SLAB"):
+        s.configure(spng.CFG_DEFLATE_BYTES, int(os.environ["PROBE_SLAB"]) << 30)
+        run(f"... with a slab of {os.environ['PROBE_SLAB']} GiB", [big[i * (64 << 20):(i + 1) * (64 << 20)] for i in range(N)])
+        s.configure(spng.CFG_DEFLATE_BYTES, 0)
+    del big
+elif "random" in which:
     rnd = [torch.randint(0, 256, (64 << 20,), dtype=torch.uint8, device=s.tdev, generator=gen) for _ in range(8)]
     run("random 64 MiB", [rnd[i % 8] for i in range(N)])
     del rnd
