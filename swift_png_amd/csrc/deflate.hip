@@ -1966,6 +1966,14 @@ __device__ __forceinline__ void d3_search_chunk(L &s, const gbyte *in, uint64_t 
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) { const uint32_t a = (uint32_t)__shfl_xor((int)mh, m, 64), b2 = (uint32_t)__shfl_xor((int)mc, m, 64); mh = a > mh ? a : mh; mc = b2 > mc ? b2 : mc; }
             D3P_CNT(4, 1); D3P_CNT(5, mh); D3P_CNT(6, mc);
+            uint32_t sh_ = p_hops + p_cmp, ms_ = p_hops + p_cmp;       // lane steps in all, against 64 x the slowest lane's
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                sh_ += (uint32_t)__shfl_xor((int)sh_, m, 64);
+                const uint32_t o_ = (uint32_t)__shfl_xor((int)ms_, m, 64);
+                ms_ = o_ > ms_ ? o_ : ms_;
+            }
+            D3P_CNT(7, sh_); D3P_CNT(8, ms_);
         }
 #endif
         const uint64_t v = (warm + p0r - rb) + (uint32_t)lane;  // round coordinates
@@ -1997,8 +2005,8 @@ __device__ __forceinline__ void d3_search_chunk(L &s, const gbyte *in, uint64_t 
 #ifdef SPNG_D3_PROF
     __syncthreads();
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0)
-        printf("d3 prof wg %u (%u positions, %u batches): total %llu kcyc; inserter: throttle wait %llu insert %llu; searchers (sum of 16 waves): wait %llu walk %llu kcyc; batches %llu, max-lane hops %llu, compare steps %llu\n",
-               blockIdx.x, c1r - c0r, nbatches, (__builtin_readcyclecounter() - d3p_start) >> 10, s.prof[0] >> 10, s.prof[1] >> 10, s.prof[2] >> 10, s.prof[3] >> 10, s.prof[4], s.prof[5], s.prof[6]);
+        printf("d3 prof wg %u (%u positions, %u batches): total %llu kcyc; inserter: throttle wait %llu insert %llu; searchers (sum of 16 waves): wait %llu walk %llu kcyc; batches %llu, max-lane hops %llu, compare steps %llu; lane steps (hops + compares) %llu of 64 x %llu\n",
+               blockIdx.x, c1r - c0r, nbatches, (__builtin_readcyclecounter() - d3p_start) >> 10, s.prof[0] >> 10, s.prof[1] >> 10, s.prof[2] >> 10, s.prof[3] >> 10, s.prof[4], s.prof[5], s.prof[6], s.prof[7], s.prof[8]);
 #endif
 }
 
