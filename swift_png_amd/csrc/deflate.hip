@@ -1974,6 +1974,7 @@ __device__ __forceinline__ void d3_search_chunk(L &s, const gbyte *in, uint64_t 
                 ms_ = o_ > ms_ ? o_ : ms_;
             }
             D3P_CNT(7, sh_); D3P_CNT(8, ms_);
+            if (mh + mc > 256) { D3P_CNT(9, mh); D3P_CNT(10, mc); D3P_CNT(11, 1); D3P_CNT(12, sh_); }     // the stragglers
         }
 #endif
         const uint64_t v = (warm + p0r - rb) + (uint32_t)lane;  // round coordinates
@@ -2005,8 +2006,8 @@ __device__ __forceinline__ void d3_search_chunk(L &s, const gbyte *in, uint64_t 
 #ifdef SPNG_D3_PROF
     __syncthreads();
     if (threadIdx.x == 0 && (blockIdx.x & 63) == 0)
-        printf("d3 prof wg %u (%u positions, %u batches): total %llu kcyc; inserter: throttle wait %llu insert %llu; searchers (sum of 16 waves): wait %llu walk %llu kcyc; batches %llu, max-lane hops %llu, compare steps %llu; lane steps (hops + compares) %llu of 64 x %llu\n",
-               blockIdx.x, c1r - c0r, nbatches, (__builtin_readcyclecounter() - d3p_start) >> 10, s.prof[0] >> 10, s.prof[1] >> 10, s.prof[2] >> 10, s.prof[3] >> 10, s.prof[4], s.prof[5], s.prof[6], s.prof[7], s.prof[8]);
+        printf("d3 prof wg %u (%u positions, %u batches): total %llu kcyc; inserter: throttle wait %llu insert %llu; searchers (sum of 16 waves): wait %llu walk %llu kcyc; batches %llu, max-lane hops %llu, compare steps %llu; lane steps (hops + compares) %llu of 64 x %llu; batches over 256 steps: %llu with max-lane hops %llu, compare steps %llu, lane steps %llu\n",
+               blockIdx.x, c1r - c0r, nbatches, (__builtin_readcyclecounter() - d3p_start) >> 10, s.prof[0] >> 10, s.prof[1] >> 10, s.prof[2] >> 10, s.prof[3] >> 10, s.prof[4], s.prof[5], s.prof[6], s.prof[7], s.prof[8], s.prof[11], s.prof[9], s.prof[10], s.prof[12]);
 #endif
 }
 
