@@ -220,8 +220,10 @@ __device__ void filter_row_fast(const uint8_t *cur, const uint8_t *up, uint32_t 
     }
 }
 
+static constexpr uint32_t PACKED_ROW = 2048;                   // bytes of a sub-byte scanline that go through LDS (16384 one-bit samples; 16 KB per workgroup: the other formats keep their six workgroups per CU)
 __global__ __launch_bounds__(256) void filter_kernel(const FilterJob *__restrict__ jobs)
 {
+    __shared__ uint8_t packed[4][2][PACKED_ROW];              // [wave][this row, the row above]
     const FilterJob job = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t volume = job.depth * job.channels, bpp = (volume + 7) >> 3;
@@ -241,6 +243,46 @@ __global__ __launch_bounds__(256) void filter_kernel(const FilterJob *__restrict
             case 6: filter_row_fast<6>(cur, up, job.pitch, out, lane); break;
             default: filter_row_fast<8>(cur, up, job.pitch, out, lane); break;
             }
+            continue;
+        }
+        if (volume < 8 && job.pitch <= PACKED_ROW) {
+            // Samples of 1, 2 or 4 bits (round 6): a scanline byte is 8 / depth storage bytes, and the loops below ask for each of
+            // this row's and the row above's up to twice per candidate and pass -- 64 byte loads per byte of a 1-bit row (the
+            // `scanline_formats` leg: 3 % of peak).  The two rows are packed ONCE into LDS and the filters read them there.
+            uint8_t *cur = packed[wave][0], *up = packed[wave][1];
+            for (uint32_t j = lane; j < job.pitch; j += 64) {
+                cur[j] = (uint8_t)raw_byte(job, y, j, direct, volume, bpp);
+                up[j] = y ? (uint8_t)raw_byte(job, y - 1, j, direct, volume, bpp) : (uint8_t)0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            uint32_t sc[5] = {0, 0, 0, 0, 0};
+            for (uint32_t j = lane; j < job.pitch; j += 64) {          // (bpp = 1)
+                const uint32_t x = cur[j], a = j ? cur[j - 1] : 0u, b = up[j], c = j ? up[j - 1] : 0u;
+                sc[0] += abs8(x);
+                sc[1] += abs8(x - a);
+                sc[2] += abs8(x - b);
+                sc[3] += abs8(x - ((a + b) >> 1));
+                sc[4] += abs8(x - paeth_u(a, b, c));
+            }
+#pragma unroll
+            for (int f = 0; f < 5; ++f)
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) sc[f] += __shfl_xor(sc[f], m, 64);
+            uint32_t best = 0, minimum = sc[0];
+#pragma unroll
+            for (int f = 1; f < 5; ++f) if (sc[f] < minimum) { minimum = sc[f]; best = f; }
+            uint8_t *out = job.rows + (uint64_t)y * job.row_stride;
+            if (lane == 0) out[0] = (uint8_t)best;
+            for (uint32_t j = lane; j < job.pitch; j += 64) {
+                const uint32_t x = cur[j], a = j ? cur[j - 1] : 0u, b = up[j], c = j ? up[j - 1] : 0u;
+                uint32_t pred = 0;
+                if (best == 1) pred = a;
+                else if (best == 2) pred = b;
+                else if (best == 3) pred = (a + b) >> 1;
+                else if (best == 4) pred = paeth_u(a, b, c);
+                out[1 + j] = (uint8_t)(x - pred);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");     // (the next row of this wave packs over these)
             continue;
         }
         uint32_t sc[5] = {0, 0, 0, 0, 0};

@@ -36,6 +36,9 @@ CASES = [("rgba8 noise", 64, 20, 8, 4, "noise"), ("rgba8 photograph", 256, 64, 8
          ("rgba8 gradient", 200, 33, 8, 4, "gradient"), ("rgb8", 100, 30, 8, 3, "noise"), ("rgba16", 60, 40, 16, 4, "noise"),
          ("gray8", 333, 17, 8, 1, "gradient"), ("va8", 50, 50, 8, 2, "noise"), ("gray4", 99, 12, 4, 1, "noise"), ("gray1", 77, 9, 1, 1, "noise"),
          ("rgb16 one row", 19, 1, 16, 3, "noise"),
+         # samples below a byte: rows packed once into LDS (round 6) -- several steps of 64 bytes, and a row too long for the buffer
+         ("gray2", 130, 11, 2, 1, "noise"), ("gray1 wide", 3001, 7, 1, 1, "noise"), ("gray4 wide", 1500, 5, 4, 1, "gradient"),
+         ("gray1 beyond the buffer", 20000, 3, 1, 1, "noise"),
          # rows wider than a wave's step of 1 KiB: the aligned store takes the bytes in front of lane 0 from lane 63 of the step before
          ("rgba8 wide", 600, 40, 8, 4, "synth"), ("rgba16 wide", 260, 18, 16, 4, "noise"), ("rgb8 wide", 1024, 19, 8, 3, "gradient")]
 
