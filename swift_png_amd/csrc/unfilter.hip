@@ -45,8 +45,10 @@ struct __attribute__((packed)) U128u { u32x4 v; };       // 16 bytes, alignment 
 #define SPNG_UNF_P8 32                                   // tile width in units for bpp > 4
 #endif
 
-template <int BPP> struct Cfg {
-    static constexpr int P    = (BPP <= 4) ? SPNG_UNF_P4 : SPNG_UNF_P8;   // units per tile window
+// BPP: bytes of a unit (what a lane reconstructs per step and the lanes' windows are skewed by); PX: bytes of a pixel -- the distance
+// of the left and upper-left neighbours.  PX < BPP (round 6): pixels of 1 and 2 bytes ride four and two to a unit of four bytes.
+template <int BPP, int PX = BPP> struct Cfg {
+    static constexpr int P    = (PX != BPP) ? 16 : (BPP <= 4) ? SPNG_UNF_P4 : SPNG_UNF_P8;   // units per tile window
     static constexpr int K    = (63 + P - 1) / P;        // producer tiles a consumer tile reaches into
     static constexpr int TB   = P * BPP;                 // bytes per row per tile (multiple of 16)
     static constexpr int ROWB = TB + 16;                 // LDS row stride: conflict-free b128 columns
@@ -157,6 +159,42 @@ __device__ __forceinline__ void reconstruct_generic(uint8_t *tile, int rowb, int
     }
 }
 
+// ---- reconstruction of one tile: pixels of 1 or 2 bytes, four or two to a dword unit (round 6) --------------------------------
+// The byte-wise form above costs a pixel of one byte ~40 VALU operations and three LDS accesses (indexed-8 at 15 % of peak).  Here a
+// unit is a dword whatever the pixel: one LDS read and one write per four bytes, the row above's dword by DPP; inside the dword the
+// bytes are reconstructed one after the other (byte k's left neighbour is byte k - PX of the dword, or of the dword before).
+template <int PX, int P, bool PAETH>
+__device__ __forceinline__ void reconstruct_subunit(uint8_t *tile, int rowb, int lane, uint32_t ft, int64_t ux0, uint32_t &o, uint32_t &bprev)
+{
+    const uint32_t m_sub = ft == 1 ? 0xffu : 0u, m_up = ft == 2 ? 0xffu : 0u, m_avg = ft == 3 ? 0xffu : 0u, m_pae = ft == 4 ? 0xffu : 0u;
+    uint8_t *mine = tile + (1 + lane) * rowb;
+#pragma unroll 2
+    for (int t = 0; t < P; ++t) {
+        const bool interior = ux0 + t > 0;               // unit 0's first pixel has no left / upper-left neighbour
+        const uint32_t b4 = from_lane_above(o, *(const uint32_t *)(tile + 4 * t));
+        const uint32_t x4 = *(const uint32_t *)(mine + 4 * t);
+        uint32_t a[PX], c[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+            a[k] = interior ? (o >> (8 * (4 - PX + k))) & 0xffu : 0u;
+            c[k] = interior ? (bprev >> (8 * (4 - PX + k))) & 0xffu : 0u;
+        }
+        uint32_t r4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t x = (x4 >> (8 * k)) & 0xffu, b = (b4 >> (8 * k)) & 0xffu;
+            const uint32_t l = a[k % PX], ul = c[k % PX];
+            uint32_t pred = (l & m_sub) | (b & m_up) | (((l + b) >> 1) & m_avg);
+            if (PAETH) pred |= paeth(l, b, ul) & m_pae;
+            const uint32_t v = (x + pred) & 0xffu;
+            r4 |= v << (8 * k);
+            a[k % PX] = v; c[k % PX] = b;
+        }
+        o = r4; bprev = b4;
+        *(uint32_t *)(mine + 4 * t) = r4;
+    }
+}
+
 // ---- reconstruction of one tile: 4 or 8 bytes per unit, two packed-u16 halves per dword ------
 // even bytes live in `lo` (x & 0x00ff00ff), odd bytes in `hi` ((x >> 8) & 0x00ff00ff); sums of two
 // bytes cannot carry across the 16-bit lanes, signed differences use the packed-i16 VALU ops.
@@ -258,12 +296,13 @@ __device__ __forceinline__ void reconstruct_packed(uint8_t *tile, int rowb, int 
     }
 }
 
-template <int BPP>
+template <int BPP, int PX = BPP>
 __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob *__restrict__ jobs,
                                                                      const spng_result *__restrict__ results,
                                                                      uint32_t sb_rows)
 {
-    using C = Cfg<BPP>;
+    using C = Cfg<BPP, PX>;
+    static_assert(PX == BPP || (BPP == 4 && (PX == 1 || PX == 2)), "sub-unit pixels ride in dwords");
     constexpr int NW = SPNG_UNF_NW;
     __shared__ __attribute__((aligned(16))) uint8_t tiles[NW][65 * C::ROWB];
     __shared__ uint32_t done[NW];                        // tiles completed by each wave
@@ -308,7 +347,7 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         rows = last - first;
     }
     const int64_t pitch = job.pitch;
-    const uint32_t W = job.pitch / BPP;
+    const uint32_t W = (job.pitch + BPP - 1) / BPP;             // (PX < BPP: the last unit may reach past the row -- loads read zeros there, stores stop)
     const uint32_t ntiles = (W + 63 + C::P - 1) / C::P;
     const uint32_t nbands = (rows + 63) / 64;
     uint8_t *tile = tiles[wave];
@@ -363,7 +402,8 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
         const uint32_t row = band * 64 + lane;
         const uint32_t ft = row < rows ? job.in[(uint64_t)row * job.in_stride] : 0u;
         constexpr bool PACKED = BPP == 3 || BPP == 6;          // (a unit in dwords: reconstruct_packed)
-        constexpr int NS = PACKED ? (BPP + 3) / 4 : BPP;
+        constexpr bool SUBUNIT = PX != BPP;                    // (pixels inside a dword unit: reconstruct_subunit)
+        constexpr int NS = SUBUNIT ? 1 : PACKED ? (BPP + 3) / 4 : BPP;
         const bool any_pae = __any(ft == 4);                   // no Paeth row in this band: skip its arithmetic
         // every row of the band filtered with None (what libpng writes for palette and low-depth images): the tiles only pass
         // through (the band below reads this one's last row back from the output, not from registers)
@@ -406,6 +446,9 @@ __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob
             const int64_t ux0 = (int64_t)T * C::P - lane;
 #ifndef SPNG_UNF_NOCOMPUTE        // tuning builds only: measure the memory pipeline alone
             if (all_none) {
+            } else if constexpr (SUBUNIT) {
+                if (any_pae) reconstruct_subunit<PX, C::P, true>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
+                else         reconstruct_subunit<PX, C::P, false>(tile, C::ROWB, lane, ft, ux0, o[0], bprev[0]);
             } else if constexpr (PACKED) {
                 (void)ux0;
                 if (any_pae) reconstruct_packed<BPP, C::P, true>(tile, C::ROWB, lane, ft, o, bprev);
@@ -741,8 +784,8 @@ hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, s
         return hipGetLastError();
     }
     switch (bpp) {
-    case 1: unfilter_kernel<1><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
-    case 2: unfilter_kernel<2><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
+    case 1: unfilter_kernel<4, 1><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
+    case 2: unfilter_kernel<4, 2><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     case 3: unfilter_kernel<3><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     case 6: unfilter_kernel<6><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     default: return hipErrorInvalidValue;
