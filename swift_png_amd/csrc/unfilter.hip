@@ -41,6 +41,9 @@ struct __attribute__((packed)) U128u { u32x4 v; };       // 16 bytes, alignment 
 #ifndef SPNG_UNF_P4
 #define SPNG_UNF_P4 64                                   // tile width in units for bpp <= 4
 #endif
+#ifndef SPNG_UNF_PSUB
+#define SPNG_UNF_PSUB 16                                 // tile width in dword units for pixels of 1 and 2 bytes
+#endif
 #ifndef SPNG_UNF_P8
 #define SPNG_UNF_P8 32                                   // tile width in units for bpp > 4
 #endif
@@ -48,7 +51,7 @@ struct __attribute__((packed)) U128u { u32x4 v; };       // 16 bytes, alignment 
 // BPP: bytes of a unit (what a lane reconstructs per step and the lanes' windows are skewed by); PX: bytes of a pixel -- the distance
 // of the left and upper-left neighbours.  PX < BPP (round 6): pixels of 1 and 2 bytes ride four and two to a unit of four bytes.
 template <int BPP, int PX = BPP> struct Cfg {
-    static constexpr int P    = (PX != BPP) ? 16 : (BPP <= 4) ? SPNG_UNF_P4 : SPNG_UNF_P8;   // units per tile window
+    static constexpr int P    = (PX != BPP) ? SPNG_UNF_PSUB : (BPP <= 4) ? SPNG_UNF_P4 : SPNG_UNF_P8;   // units per tile window
     static constexpr int K    = (63 + P - 1) / P;        // producer tiles a consumer tile reaches into
     static constexpr int TB   = P * BPP;                 // bytes per row per tile (multiple of 16)
     static constexpr int ROWB = TB + 16;                 // LDS row stride: conflict-free b128 columns
