@@ -250,9 +250,29 @@ __global__ __launch_bounds__(256) void filter_kernel(const FilterJob *__restrict
             // this row's and the row above's up to twice per candidate and pass -- 64 byte loads per byte of a 1-bit row (the
             // `scanline_formats` leg: 3 % of peak).  The two rows are packed ONCE into LDS and the filters read them there.
             uint8_t *cur = packed[wave][0], *up = packed[wave][1];
+            // (samples side by side in storage -- every image that is not an Adam7 sub-image: the 8 / depth storage bytes of a scanline
+            //  byte in one load, their low bits gathered by a multiplication: bytes b0 .. b3 of x = w & 0x01010101 meet in the top byte
+            //  of x * 0x08040201 as b0 << 3 | b1 << 2 | b2 << 1 | b3)
+            const uint32_t per = 8 / job.depth;
+            const bool side_by_side = job.sx == 1;
+            auto pack_row = [&](uint32_t yy, uint32_t j) -> uint32_t {
+                if (!(side_by_side && (uint64_t)j * per + per <= job.sub_w)) return raw_byte(job, yy, j, direct, volume, bpp);
+                const uint8_t *p = job.storage + (uint64_t)(job.by + yy * job.sy) * job.width + job.bx + (uint64_t)j * per;
+                if (job.depth == 1) {
+                    uint32_t lo, hi;
+                    __builtin_memcpy(&lo, p, 4); __builtin_memcpy(&hi, p + 4, 4);
+                    return (((lo & 0x01010101u) * 0x08040201u) >> 24) << 4 | ((hi & 0x01010101u) * 0x08040201u) >> 24;
+                }
+                if (job.depth == 2) {
+                    uint32_t w;
+                    __builtin_memcpy(&w, p, 4);
+                    return ((w & 0x03030303u) * 0x40100401u) >> 24;
+                }
+                return ((uint32_t)p[0] & 15u) << 4 | ((uint32_t)p[1] & 15u);
+            };
             for (uint32_t j = lane; j < job.pitch; j += 64) {
-                cur[j] = (uint8_t)raw_byte(job, y, j, direct, volume, bpp);
-                up[j] = y ? (uint8_t)raw_byte(job, y - 1, j, direct, volume, bpp) : (uint8_t)0;
+                cur[j] = (uint8_t)pack_row(y, j);
+                up[j] = y ? (uint8_t)pack_row(y - 1, j) : (uint8_t)0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             uint32_t sc[5] = {0, 0, 0, 0, 0};
