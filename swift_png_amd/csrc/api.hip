@@ -469,14 +469,14 @@ static int32_t launch_plan(spng_ctx *c, const UnfilterPlan &plan, Arena &a, cons
                 uint64_t total_rows = 0; uint32_t max_rows = 1;
                 for (auto &j : plan.unf[k]) { total_rows += j.rows; max_rows = j.rows > max_rows ? j.rows : max_rows; }
                 uint32_t piece_rows = (uint32_t)c->cfg[SPNG_CFG_UNFILTER_PIECE_ROWS];
+                uint64_t widest = 0;
+                for (auto &j : plan.unf[k]) widest = (uint64_t)j.pitch > widest ? (uint64_t)j.pitch : widest;
                 if (!piece_rows) {
                     piece_rows = (uint32_t)((total_rows / 4096 + 63) & ~(uint64_t)63);
                     if (piece_rows < 128) piece_rows = 128;
                     // (round 6: a piece of 128 rows is two bands of 64 -- two of the workgroup's four waves have nothing to do.  Rows of
                     //  2 KiB and more take four bands at least: 128 x 4096^2 RGB16 15.2 -> 10.0 ms, 256 x RGB8 10.5 -> 10.0; rows of a
                     //  1-bit image, 512 bytes, want the workgroups more than the waves: profiles/r06_tuning.md 15)
-                    uint64_t widest = 0;
-                    for (auto &j : plan.unf[k]) widest = (uint64_t)j.pitch > widest ? (uint64_t)j.pitch : widest;
                     if (widest >= 2048 && k != 4 && k != 8) {
                         piece_rows = (uint32_t)((total_rows / 2048 + 63) & ~(uint64_t)63);
                         if (piece_rows < 256) piece_rows = 256;
@@ -498,7 +498,7 @@ static int32_t launch_plan(spng_ctx *c, const UnfilterPlan &plan, Arena &a, cons
                 }
                 const uint32_t pieces = (max_rows + piece_rows - 1) / piece_rows;
                 HIP_TRY(launch_unfilter(a.dev<UnfJob>(slots.unf[k]), (uint32_t)plan.unf[k].size(), k,
-                                        d_results, pieces, piece_rows, c->stream));
+                                        d_results, pieces, piece_rows, c->stream, (uint32_t)(widest > 0xffffffffull ? 0xffffffffull : widest)));
             }
     }
     if (!plan.scat.empty()) {

@@ -271,7 +271,7 @@ int passes(uint32_t w, uint32_t h, int volume, int interlaced, Pass out[7]);
 
 // kernel launchers (each returns the hipError_t of the launch)
 hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, spng_result *d_results,
-                           uint32_t pieces, uint32_t piece_rows, hipStream_t stream);
+                           uint32_t pieces, uint32_t piece_rows, hipStream_t stream, uint32_t widest = 0);   // widest: the longest row of the batch in bytes
 hipError_t launch_copy_probe(const void *d_src, void *d_dst, uint64_t bytes, int pattern, hipStream_t stream);
 hipError_t launch_scatter(const ScatterJob *d_jobs, uint32_t count, const uint32_t *d_job_image,
                           const spng_result *d_results, uint32_t blocks_x, hipStream_t stream);

@@ -50,8 +50,8 @@ struct __attribute__((packed)) U128u { u32x4 v; };       // 16 bytes, alignment 
 
 // BPP: bytes of a unit (what a lane reconstructs per step and the lanes' windows are skewed by); PX: bytes of a pixel -- the distance
 // of the left and upper-left neighbours.  PX < BPP (round 6): pixels of 1 and 2 bytes ride four and two to a unit of four bytes.
-template <int BPP, int PX = BPP> struct Cfg {
-    static constexpr int P    = (PX != BPP) ? SPNG_UNF_PSUB : (BPP <= 4) ? SPNG_UNF_P4 : SPNG_UNF_P8;   // units per tile window
+template <int BPP, int PX = BPP, int PT = 0> struct Cfg {          // (PT: tile width in units when it is not the format's own)
+    static constexpr int P    = PT ? PT : (PX != BPP) ? SPNG_UNF_PSUB : (BPP <= 4) ? SPNG_UNF_P4 : SPNG_UNF_P8;   // units per tile window
     static constexpr int K    = (63 + P - 1) / P;        // producer tiles a consumer tile reaches into
     static constexpr int TB   = P * BPP;                 // bytes per row per tile (multiple of 16)
     static constexpr int ROWB = TB + 16;                 // LDS row stride: conflict-free b128 columns
@@ -299,12 +299,12 @@ __device__ __forceinline__ void reconstruct_packed(uint8_t *tile, int rowb, int 
     }
 }
 
-template <int BPP, int PX = BPP>
+template <int BPP, int PX = BPP, int PT = 0>
 __global__ __launch_bounds__(SPNG_UNF_NW * 64) void unfilter_kernel(const UnfJob *__restrict__ jobs,
                                                                      const spng_result *__restrict__ results,
                                                                      uint32_t sb_rows)
 {
-    using C = Cfg<BPP, PX>;
+    using C = Cfg<BPP, PX, PT>;
     static_assert(PX == BPP || (BPP == 4 && (PX == 1 || PX == 2)), "sub-unit pixels ride in dwords");
     constexpr int NW = SPNG_UNF_NW;
     __shared__ __attribute__((aligned(16))) uint8_t tiles[NW][65 * C::ROWB];
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(SPNG_UNF_PK_NW * 64) void unfilter_pk_kernel(const 
 }
 
 hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, spng_result *d_results,
-                           uint32_t pieces, uint32_t piece_rows, hipStream_t stream)
+                           uint32_t pieces, uint32_t piece_rows, hipStream_t stream, uint32_t widest)
 {
     if (!count) return hipSuccess;
     constexpr int T = SPNG_UNF_NW * 64;
@@ -787,8 +787,16 @@ hipError_t launch_unfilter(const UnfJob *d_jobs, uint32_t count, uint32_t bpp, s
         return hipGetLastError();
     }
     switch (bpp) {
-    case 1: unfilter_kernel<4, 1><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
-    case 2: unfilter_kernel<4, 2><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
+    // (pixels of 1 and 2 bytes: tiles of 32 dword units for rows of 2 KiB and more, of SPNG_UNF_PSUB = 16 for narrower ones -- wide
+    //  tiles cost rows of 512 bytes a third and save rows of 4 KiB a sixth: profiles/r06_tuning.md 14)
+    case 1:
+        if (widest >= 2048) unfilter_kernel<4, 1, 32><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows);
+        else unfilter_kernel<4, 1><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows);
+        break;
+    case 2:
+        if (widest >= 2048) unfilter_kernel<4, 2, 32><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows);
+        else unfilter_kernel<4, 2><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows);
+        break;
     case 3: unfilter_kernel<3><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     case 6: unfilter_kernel<6><<<grid, T, 0, stream>>>(d_jobs, d_results, piece_rows); break;
     default: return hipErrorInvalidValue;

@@ -56,6 +56,11 @@ CASES = [
     ("rgb8 one pixel", 1, 1, 3, 8, 64, [4]), ("rgb8 sixteen pixels", 16, 3, 3, 8, 64, [4, 3, 4]), ("rgb8 seventeen pixels", 17, 130, 3, 8, 64, _f(10, 130)),
     ("rgb8 wide, three bands", 1500, 150, 3, 8, 64, _f(11, 150)), ("rgb16 wide, pieces", 900, 200, 3, 16, 32, _f(12, 61)),
     ("rgb8 no paeth row in a band", 300, 140, 3, 8, 128, [1, 2, 3, 0, 2] * 20 + [4] * 40),
+    # pixels of 1 and 2 bytes in dword units (round 6): every filter alone, rows that end inside a dword, and rows of 2 KiB and more
+    # (tiles of 32 units instead of 16)
+    ("gray8 sub", 70, 10, 1, 8, 64, [1]), ("gray8 average", 70, 10, 1, 8, 64, [0, 3]), ("gray8 paeth", 71, 10, 1, 8, 64, [1, 4]),
+    ("gray8 one pixel", 1, 1, 1, 8, 64, [4]), ("gray8 five pixels", 5, 130, 1, 8, 64, _f(13, 130)), ("va8 paeth", 33, 20, 2, 8, 64, [2, 4]),
+    ("gray16 mixed", 301, 70, 1, 16, 64, _f(14, 70)), ("gray8 wide", 3001, 140, 1, 8, 64, _f(15, 140)), ("va8 wide, pieces", 1100, 200, 2, 8, 32, _f(16, 61)),
 ]
 
 

@@ -35,7 +35,9 @@ int main(int argc, char **argv)
     if (bpp == 4) emu::launch(1, SPNG_UNF_PK_NW * 64, [&] { unfilter_pk_kernel<4>(&job, nullptr, piece_rows, np); }, (np + Pk<4>::NCH - 1) / Pk<4>::NCH);
     else if (bpp == 8) emu::launch(1, SPNG_UNF_PK_NW * 64, [&] { unfilter_pk_kernel<8>(&job, nullptr, piece_rows, np); }, (np + Pk<8>::NCH - 1) / Pk<8>::NCH);
     // the byte-wise kernel of the other pixel sizes (sub-byte depths defilter with bpp 1): a workgroup per piece
+    else if (bpp == 1 && job.pitch >= 2048) emu::launch(1, SPNG_UNF_NW * 64, [&] { unfilter_kernel<4, 1, 32>(&job, nullptr, piece_rows); }, np);
     else if (bpp == 1) emu::launch(1, SPNG_UNF_NW * 64, [&] { unfilter_kernel<4, 1>(&job, nullptr, piece_rows); }, np);
+    else if (bpp == 2 && job.pitch >= 2048) emu::launch(1, SPNG_UNF_NW * 64, [&] { unfilter_kernel<4, 2, 32>(&job, nullptr, piece_rows); }, np);
     else if (bpp == 2) emu::launch(1, SPNG_UNF_NW * 64, [&] { unfilter_kernel<4, 2>(&job, nullptr, piece_rows); }, np);
     else if (bpp == 3) emu::launch(1, SPNG_UNF_NW * 64, [&] { unfilter_kernel<3>(&job, nullptr, piece_rows); }, np);
     else if (bpp == 6) emu::launch(1, SPNG_UNF_NW * 64, [&] { unfilter_kernel<6>(&job, nullptr, piece_rows); }, np);
