@@ -494,6 +494,16 @@ static int32_t launch_plan(spng_ctx *c, const UnfilterPlan &plan, Arena &a, cons
                         const uint32_t fill = (uint32_t)(total_rows / 1536 / rr * rr);
                         const uint32_t floor4 = fill < 4 * rr ? fill : 4 * rr;
                         if (piece_rows < floor4) piece_rows = floor4;
+                        // (round 6, measured per batch size -- profiles/r06_tuning.md 16: 128 x 4096^2 RGBA8 want pieces of 256 rows
+                        //  (7.1 -> 5.9 ms), 32 images 128 (3.0 -> 2.3), 8 images 64 (1.8 -> 1.5): total rows / 1024, between 64 and 256)
+                        //  -- for 4-byte pixels in images of 1024 rows and more, what was measured: the 8192^2 RGBA16 image of configs[4], whose
+                        //  rows are 64 KiB, wants its 16-row bands one to a piece (3.9 ms; 64-row pieces 5.5), and images of 240 rows
+                        //  two pieces each)
+                        if (k == 4 && max_rows >= 1024) {
+                            uint32_t few = (uint32_t)((total_rows / 1024 + rr - 1) / rr * rr);
+                            few = few < 64 ? 64 : few > 256 ? 256 : few;
+                            if (piece_rows < few) piece_rows = few;
+                        }
                     }
                 }
                 const uint32_t pieces = (max_rows + piece_rows - 1) / piece_rows;
